@@ -1,0 +1,130 @@
+/*
+ * svinet_oracle.h -- CPU restatement of svinet's `-link-sampling` path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under svinet_amd/ may include, link or
+ * dlopen this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / reported CPU baseline.
+ *
+ * Parity status (see DESIGN.md section "Oracle"):
+ *   - reader, RNG, validation sampler, init_gamma2 and edge_likelihood are
+ *     PINNED against the real-GSL outputs the reference ships in
+ *     example/n1000-k28-LFR-linksampling.tgz and
+ *     example/n17903-k20-mmsb-linksampling.tgz (heldout-edges.txt and the
+ *     first row of heldout.txt) -- tests/test_oracle_golden.py.
+ *   - the sweep itself has no golden vector in the reference tree (the shipped
+ *     gamma/lambda come from an older revision) and the reference cannot be
+ *     built here (needs GSL, absent from the image), so beyond the
+ *     constructor the sweep is "parity unpinned" in the strict sense; it is
+ *     anchored on the reference-run values recorded in SURVEY.md section 8c.
+ *
+ * Every function cites the reference file:line it restates
+ * (paths relative to the reference tree, e.g. src/linksampling.cc:605-725).
+ */
+#ifndef SVINET_ORACLE_H
+#define SVINET_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- GSL-compatible primitives (third-party dependency restated) ------- */
+typedef struct orc_rng orc_rng;
+orc_rng *orc_rng_new(unsigned long seed);          /* gsl_rng_alloc(mt19937)+set */
+void orc_rng_free(orc_rng *r);
+uint32_t orc_rng_get(orc_rng *r);                  /* mt19937 raw output        */
+double orc_rng_uniform(orc_rng *r);                /* gsl_rng_uniform           */
+uint32_t orc_rng_uniform_int(orc_rng *r, uint32_t n); /* gsl_rng_uniform_int    */
+double orc_digamma(double x);                      /* gsl_sf_psi, x > 0         */
+
+/* ---- network (src/network.cc, src/network.hh) -------------------------- */
+typedef struct orc_net orc_net;
+orc_net *orc_net_read(const char *path, uint32_t n_declared);
+/* build from an in-memory list of (id1,id2) lines, same semantics as read */
+orc_net *orc_net_from_pairs(const int32_t *pairs, uint64_t nlines, uint32_t n_declared);
+void orc_net_free(orc_net *g);
+uint32_t orc_net_n(const orc_net *g);              /* nodes with >= 1 link      */
+uint32_t orc_net_ones(const orc_net *g);           /* unique undirected links   */
+uint32_t orc_net_deg(const orc_net *g, uint32_t p);
+const uint32_t *orc_net_adj(const orc_net *g, uint32_t p);
+const uint32_t *orc_net_edges(const orc_net *g);   /* [ones][2], file order     */
+const uint32_t *orc_net_seq2id(const orc_net *g);  /* [n]                       */
+int orc_net_y(const orc_net *g, uint32_t a, uint32_t b);
+
+/* ---- link-sampling engine (src/linksampling.{hh,cc}) ------------------- */
+typedef struct {
+  uint32_t k;
+  double seed;              /* -seed; 0 => generator default (4357)         */
+  double heldout_ratio;     /* -heldout-ratio, default 0.01                 */
+  double link_thresh;       /* -link-thresh, default 0.5                    */
+  uint32_t lt_min_deg;      /* -lt-min-deg, default 0                       */
+  int eta_type;             /* 0 uniform, 1 fromdata, 2 sparse, 3 dense     */
+  uint32_t reportfreq;      /* forced to 1 by -link-sampling                */
+  uint32_t max_iterations;  /* -max-iterations, 0 = none                    */
+  int use_validation_stop;  /* 0 with -no-stop                              */
+  int skip_init;            /* 1: caller provides gamma via orc_ls_set_state */
+} orc_config;
+
+void orc_config_default(orc_config *c, uint32_t k);
+
+typedef struct orc_ls orc_ls;
+/* = LinkSampling::LinkSampling + the prologue of infer() (converged=0,
+ * set_dir_exp, assign_training_links).  Writes validation row 0. */
+orc_ls *orc_ls_create(const orc_net *g, const orc_config *cfg);
+void orc_ls_free(orc_ls *m);
+
+/* One pass through the body of `while (1)` in LinkSampling::infer().
+ * Returns 0 = keep going, 1 = reference would have called do_on_stop+exit
+ * (max iterations reached BEFORE doing the sweep, state untouched),
+ * 2 = validation stop rule fired after this sweep (state is the saved one). */
+int orc_ls_sweep(orc_ls *m);
+
+/* benchmark helper: run the three link/node passes + expectations + prune
+ * only (no likelihood, no stop rule); used for cpu_baseline timing splits */
+void orc_ls_set_skip_validation(orc_ls *m, int skip);
+
+/* state access (pointers stay valid until free) */
+uint32_t orc_ls_n(const orc_ls *m);
+uint32_t orc_ls_k(const orc_ls *m);
+uint32_t orc_ls_nlinks(const orc_ls *m);
+const uint32_t *orc_ls_links(const orc_ls *m);         /* [L][2] p<q, CSR order */
+const double *orc_ls_training_links(const orc_ls *m);  /* [n] = 2*train deg    */
+double *orc_ls_gamma(orc_ls *m);                       /* [n][k] flat          */
+double *orc_ls_lambda(orc_ls *m);                      /* [k][2] flat          */
+const double *orc_ls_elogpi(const orc_ls *m);
+const double *orc_ls_elogbeta(const orc_ls *m);
+const double *orc_ls_mphi(const orc_ls *m);
+uint32_t *orc_ls_converged(orc_ls *m);                 /* [n]                  */
+const uint32_t *orc_ls_active_comms(const orc_ls *m);
+const double *orc_ls_fmap(const orc_ls *m);            /* [n][k] counts        */
+uint32_t orc_ls_nvalidation(const orc_ls *m);
+const uint32_t *orc_ls_validation_accept(const orc_ls *m); /* [V][3] a,b,y acceptance order */
+const uint32_t *orc_ls_validation_sorted(const orc_ls *m); /* [V][3] a,b,y std::map order   */
+uint32_t orc_ls_iter(const orc_ls *m);
+void orc_ls_set_iter(orc_ls *m, uint32_t iter);
+int orc_ls_annealing(const orc_ls *m);
+void orc_ls_set_annealing(orc_ls *m, int a);
+int orc_ls_write_comm(const orc_ls *m);
+double orc_ls_eta0(const orc_ls *m);
+double orc_ls_eta1(const orc_ls *m);
+double orc_ls_ones_prob(const orc_ls *m);
+double orc_ls_total_pairs(const orc_ls *m);
+uint32_t orc_ls_nrows(const orc_ls *m);                /* validation rows so far */
+const double *orc_ls_rows(const orc_ls *m);            /* [nrows][10]: iter, s/k, k, mean0, k0, mean1, k1, z*mean0, o*mean1, a */
+void orc_ls_link_counts(const orc_ls *m, uint32_t *dense, uint32_t *sparse, uint32_t *shortcut);
+/* re-derive Elogpi/Elogbeta/prune from the current gamma/lambda (after the
+ * caller poked gamma/lambda, e.g. -load) */
+void orc_ls_refresh(orc_ls *m);
+
+/* membership matrix of the last tagging sweep: out[n][k] bytes (1 = node p is
+ * written on line k of communities.txt); returns number of non-empty lines */
+uint32_t orc_ls_communities(const orc_ls *m, uint8_t *out);
+
+/* file writers with the reference's exact formats (src/linksampling.cc:804-917,1452-1476) */
+int orc_ls_write_model(const orc_ls *m, const char *dir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
