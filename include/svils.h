@@ -1,0 +1,193 @@
+/*
+ * svils.h -- C ABI of the MI355X link-sampling sweep engine (libsvils.so).
+ *
+ * The reference (premgopalan/svinet) has no plugin/FFI boundary: its only seam
+ * for this path is the C++ class used at src/main.cc:337-342
+ *
+ *     LinkSampling ls(env, network);   // src/linksampling.cc:5-155
+ *     ls.infer();                      // src/linksampling.cc:556-790
+ *
+ * This header is the boundary a maintainer would bind in its place: the host
+ * keeps parsing, RNG, initialisation and file formats; the library owns the
+ * device-resident state and runs the body of infer()'s `while (1)` loop
+ * (phi pass :605-725, compute_mean_indicators :526-545, s3 pass :731-746,
+ * lambda/swap/set_dir_exp/prune :748-761, validation_likelihood :966-1050
+ * including its stop rule and annealing switch) as HIP kernels for gfx950.
+ *
+ * Conventions: plain C, no exceptions cross the boundary, every function
+ * returns 0 on success or a negative svils_error; svils_last_error() gives
+ * the text for the calling thread.  A handle is not thread-safe.  The caller
+ * keeps ownership of every host buffer (copied in/out).  Indices are
+ * uint32_t, reals are IEEE double, matrices are flat row-major with leading
+ * dimension = number of columns.  There is NO CPU fallback: creating a handle
+ * without a usable HIP device fails with SVILS_ERR_DEVICE.
+ */
+#ifndef SVILS_H
+#define SVILS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVILS_ABI_VERSION 1
+
+typedef enum {
+  SVILS_OK = 0,
+  SVILS_ERR_ARG = -1,      /* bad argument / call order                     */
+  SVILS_ERR_DEVICE = -2,   /* no HIP device, HIP runtime error              */
+  SVILS_ERR_NOMEM = -3,    /* host or device allocation failed              */
+  SVILS_ERR_UNSUPPORTED = -4 /* e.g. k > SVILS_MAX_K                         */
+} svils_error;
+
+#define SVILS_MAX_K 2048
+
+typedef struct svils_handle svils_handle;
+
+/* Everything the sweep needs from Env / Network / the LinkSampling ctor.
+ * Replaces the Env& / Network& arguments of LinkSampling::LinkSampling
+ * (src/linksampling.cc:5-33) for the fields the loop actually reads. */
+typedef struct {
+  uint32_t n;             /* env.n after singleton removal, src/main.cc:291          */
+  uint32_t k;             /* env.k                                                   */
+  uint64_t ones;          /* network.ones(): ALL links incl. held-out (anneal scale,
+                             src/linksampling.cc:541-542)                            */
+  double alpha;           /* env.alpha = 1/k, src/env.hh:344                         */
+  double eta0, eta1;      /* Network::set_env_variables, src/network.cc:222-251      */
+  double epsilon;         /* env.epsilon = 1e-30, src/env.hh:395                     */
+  double link_thresh;     /* -link-thresh, src/linksampling.cc:672,708               */
+  uint32_t lt_min_deg;    /* -lt-min-deg,  src/linksampling.cc:676-679,712-715       */
+  uint32_t reportfreq;    /* env.reportfreq (1 under -link-sampling)                 */
+  int32_t use_validation_stop; /* 0 with -no-stop, src/linksampling.cc:1044-1048     */
+  double ones_prob;       /* _ones_prob,  src/linksampling.cc:49                     */
+  double zeros_prob;      /* _zeros_prob, src/linksampling.cc:50                     */
+  int32_t device;         /* HIP device ordinal                                      */
+  /* node-block ownership for multi-GPU runs (one process per GPU): this
+   * handle computes rows [node_begin, node_end); 0,n for a single GPU.     */
+  uint32_t node_begin, node_end;
+  /* rows allocated for the replicated n-by-k arrays (>= n; 0 = n).  A caller
+   * that all-gathers equal node blocks sets world_size * block_rows.        */
+  uint32_t n_alloc;
+} svils_config;
+
+/* fills the reference's defaults for a given n,k (alpha=1/k, eta=1,1, ...) */
+int svils_config_default(svils_config *cfg, uint32_t n, uint32_t k);
+
+int svils_create(const svils_config *cfg, svils_handle **out);
+int svils_destroy(svils_handle *h);
+
+/* Training links exactly as LinkSampling::assign_training_links leaves them
+ * (src/linksampling.cc:493-523): [nlinks][2], p < q, sorted by p then by
+ * adjacency order.  _training_links[p] (= 2 * training degree, quirk Q3) is
+ * derived from the list.  Builds the device CSR. */
+int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks);
+
+/* Held-out pairs in std::map<Edge,bool> order (src/linksampling.cc:974-992):
+ * [nv][3] = (p, q, y).  nv == 0 disables the likelihood/stop rule. */
+int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv);
+
+/* gamma [n][k], lambda [k][2] after init_gamma2/init_lambda (or -load);
+ * converged [n] or NULL (= all 0, as at the top of infer(), :559).
+ * Computes Elogpi / Elogbeta (set_dir_exp, src/linksampling.hh:170-187). */
+int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
+                    const uint32_t *converged);
+
+/* Loop-carried scalars of infer()/validation_likelihood(). */
+typedef struct {
+  uint32_t iter;          /* _iter                                               */
+  int32_t annealing;      /* _annealing_phase                                    */
+  int32_t write_comm;     /* write_comm for the NEXT sweep                       */
+  int32_t nh;             /* _nh                                                 */
+  double prev_h;          /* _prev_h                                             */
+  double max_h;           /* _max_h                                              */
+  int32_t stopped;        /* 1 once the stop rule fired with use_validation_stop;
+                             further sweeps are no-ops and the state is the one
+                             do_on_stop() would have saved                       */
+  int32_t why;            /* last `why` of validation_likelihood (:1007-1027)    */
+  uint32_t sweeps_done;   /* sweeps executed since create                        */
+  uint32_t rows;          /* validation rows recorded since create               */
+  uint64_t links_dense, links_sparse, links_shortcut; /* c, d and the one-converged
+                             count of the last sweep (:602,:726)                 */
+} svils_control;
+
+int svils_get_control(svils_handle *h, svils_control *out);   /* synchronises */
+/* only iter, annealing, write_comm, nh, prev_h, max_h are taken from `in` */
+int svils_set_control(svils_handle *h, const svils_control *in);
+
+/* validation_likelihood() on the current state WITHOUT the stop rule: the row
+ * the constructor writes (src/linksampling.cc:149-150).
+ * row[10] = iter, s/k, k, mean0, k0, mean1, k1, zeros_prob*mean0,
+ *           ones_prob*mean1, a   (the columns of :996-1001 minus duration). */
+int svils_validation_row(svils_handle *h, double *row10);
+
+/* Enqueue `nsweeps` iterations of the loop body; asynchronous.  The stop
+ * rule, the annealing switch and _iter++ run on the device, so no host
+ * round trip is needed between sweeps. */
+int svils_sweep(svils_handle *h, uint32_t nsweeps);
+int svils_synchronize(svils_handle *h);
+
+/* rows recorded by the in-loop validation_likelihood(): copies rows
+ * [first, first+count) (as numbered since create) into out[count][10]. */
+int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows);
+
+/* save_model() inputs (src/linksampling.cc:804-837): gamma [n][k],
+ * lambda [k][2]; any pointer may be NULL. */
+int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *converged);
+
+/* communities of the last tagging sweep (src/linksampling.cc:704-717,882-917):
+ * member[n][k] bytes, 1 = node p belongs on line k of communities.txt. */
+int svils_get_communities(svils_handle *h, uint8_t *member);
+
+/* Derived device arrays for parity tests and integrators:
+ * which = 0 Elogpi [n][k], 1 Elogbeta [k][2], 2 mphi [n][k],
+ *         3 active_comms [n] (uint32), 4 training_links [n] (double). */
+int svils_get_aux(svils_handle *h, int which, void *out);
+
+/* ---- measurement --------------------------------------------------------- */
+enum {
+  SVILS_KERNEL_PHI = 0, SVILS_KERNEL_REDUCE_SUM, SVILS_KERNEL_FINALIZE, SVILS_KERNEL_S3,
+  SVILS_KERNEL_VALIDATION, SVILS_KERNEL_REDUCE_S, SVILS_KERNEL_TAIL, SVILS_KERNEL_COUNT
+};
+/* mask: bit i set = bracket kernel i with hipEvents on the library's stream */
+int svils_enable_timing(svils_handle *h, uint32_t kernel_mask);
+/* synchronises; ms[i] = summed duration, launches[i] = launches timed since
+ * the last svils_enable_timing call.  Arrays of SVILS_KERNEL_COUNT. */
+int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches);
+const char *svils_kernel_name(int kernel);
+
+/* ---- multi-GPU hooks (one process per GPU; collectives stay with the caller) */
+/* The sweep split at its two exchange points.  With node-block ownership each
+ * handle runs phase A on its rows, the caller all-reduces the K-vector partial
+ * buffer, phase B finalises the owned rows, the caller all-gathers the row
+ * blocks, phase C does the s3 pass on owned rows, the caller all-reduces the
+ * second K-vector buffer, and phase D (replicated) closes the sweep.
+ * svils_sweep() == A,B,C,D with no exchange. */
+typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D } svils_phase;
+int svils_sweep_phase(svils_handle *h, svils_phase phase);
+
+typedef enum {
+  SVILS_BUF_KVEC_A = 0,   /* double[k]   : sum (phase A -> all-reduce SUM)          */
+  SVILS_BUF_KVEC_C,       /* double[3k+4]: s1,s2,s3, validation partials (C -> SUM) */
+  SVILS_BUF_GAMMA,        /* double[n_pad][ld] rows, all-gather by node block      */
+  SVILS_BUF_ELOGPI,       /* double[n_pad][ld]                                      */
+  SVILS_BUF_MPHI,         /* double[n_pad][ld]                                      */
+  SVILS_BUF_CONV,         /* uint32[n_pad] new converged flags                      */
+  SVILS_BUF_ACTIVE,       /* uint32[n_pad] active_comms                             */
+  SVILS_BUF_AMASK,        /* uint64[n_pad][kw] active-set bitmask                   */
+  SVILS_BUF_MEMBER        /* uint64[n_pad][kw] community bitmask                    */
+} svils_buffer;
+/* device pointer + geometry of an exchange buffer (valid until destroy) */
+int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr,
+                        size_t *bytes, size_t *row_bytes);
+/* the hipStream_t the library launches on, as void* */
+int svils_stream(svils_handle *h, void **stream);
+
+const char *svils_last_error(void);
+int svils_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""ctypes binding of the C ABI in include/svils.h (libsvils.so, HIP/gfx950).
+
+There is no CPU fallback: if the shared library is missing this module raises
+at load time, and if no HIP device is present `Engine(...)` raises
+`SvilsError` (SVILS_ERR_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsvils.so")
+
+KERNEL_NAMES = ("phi", "reduce_sum", "finalize", "s3", "validation", "reduce_s", "tail")
+KERNEL_PHI = 0
+
+# every symbol include/svils.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "svils_config_default", "svils_create", "svils_destroy", "svils_set_graph",
+    "svils_set_validation", "svils_set_state", "svils_get_control", "svils_set_control",
+    "svils_validation_row", "svils_sweep", "svils_synchronize", "svils_get_rows",
+    "svils_get_state", "svils_get_communities", "svils_get_aux", "svils_enable_timing",
+    "svils_get_timing", "svils_kernel_name", "svils_sweep_phase", "svils_device_buffer",
+    "svils_stream", "svils_last_error", "svils_abi_version",
+)
+
+
+class SvilsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("svils error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32), ("k", C.c_uint32), ("ones", C.c_uint64),
+        ("alpha", C.c_double), ("eta0", C.c_double), ("eta1", C.c_double),
+        ("epsilon", C.c_double), ("link_thresh", C.c_double),
+        ("lt_min_deg", C.c_uint32), ("reportfreq", C.c_uint32),
+        ("use_validation_stop", C.c_int32),
+        ("ones_prob", C.c_double), ("zeros_prob", C.c_double),
+        ("device", C.c_int32), ("node_begin", C.c_uint32), ("node_end", C.c_uint32),
+        ("n_alloc", C.c_uint32),
+    ]
+
+
+class Control(C.Structure):
+    _fields_ = [
+        ("iter", C.c_uint32), ("annealing", C.c_int32), ("write_comm", C.c_int32),
+        ("nh", C.c_int32), ("prev_h", C.c_double), ("max_h", C.c_double),
+        ("stopped", C.c_int32), ("why", C.c_int32), ("sweeps_done", C.c_uint32),
+        ("rows", C.c_uint32), ("links_dense", C.c_uint64), ("links_sparse", C.c_uint64),
+        ("links_shortcut", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libsvils.so; raises OSError (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s not found: build it with `python -m svinet_amd.build` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.svils_last_error.restype = C.c_char_p
+    L.svils_kernel_name.restype = C.c_char_p
+    L.svils_kernel_name.argtypes = [C.c_int]
+    L.svils_abi_version.restype = C.c_int
+    L.svils_config_default.argtypes = [C.POINTER(Config), C.c_uint32, C.c_uint32]
+    L.svils_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.svils_destroy.argtypes = [vp]
+    L.svils_set_graph.argtypes = [vp, vp, C.c_uint64]
+    L.svils_set_validation.argtypes = [vp, vp, C.c_uint64]
+    L.svils_set_state.argtypes = [vp, vp, vp, vp]
+    L.svils_get_control.argtypes = [vp, C.POINTER(Control)]
+    L.svils_set_control.argtypes = [vp, C.POINTER(Control)]
+    L.svils_validation_row.argtypes = [vp, vp]
+    L.svils_sweep.argtypes = [vp, C.c_uint32]
+    L.svils_synchronize.argtypes = [vp]
+    L.svils_get_rows.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.svils_get_state.argtypes = [vp, vp, vp, vp]
+    L.svils_get_communities.argtypes = [vp, vp]
+    L.svils_get_aux.argtypes = [vp, C.c_int, vp]
+    L.svils_enable_timing.argtypes = [vp, C.c_uint32]
+    L.svils_get_timing.argtypes = [vp, vp, vp]
+    L.svils_sweep_phase.argtypes = [vp, C.c_int]
+    L.svils_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t)]
+    L.svils_stream.argtypes = [vp, C.POINTER(vp)]
+    for name in EXPORTS:
+        f = getattr(L, name)
+        if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise SvilsError(rc, load().svils_last_error().decode("utf-8", "replace"))
+
+
+BUF_KVEC_A, BUF_KVEC_C, BUF_GAMMA, BUF_ELOGPI, BUF_MPHI, BUF_CONV, BUF_ACTIVE, BUF_AMASK, \
+    BUF_MEMBER = range(9)
+PHASE_A, PHASE_B, PHASE_C, PHASE_D = range(4)
+
+
+class Engine:
+    """One svils_handle: the device-resident body of LinkSampling::infer()."""
+
+    def __init__(self, n, k, ones, ones_prob, eta=(1.0, 1.0), link_thresh=0.5, lt_min_deg=0,
+                 reportfreq=1, use_validation_stop=True, device=0, node_block=None, n_alloc=0):
+        L = load()
+        cfg = Config()
+        _chk(L.svils_config_default(C.byref(cfg), n, k))
+        cfg.ones = int(ones)
+        cfg.eta0, cfg.eta1 = float(eta[0]), float(eta[1])
+        cfg.link_thresh = link_thresh
+        cfg.lt_min_deg = lt_min_deg
+        cfg.reportfreq = reportfreq
+        cfg.use_validation_stop = int(use_validation_stop)
+        cfg.ones_prob = float(ones_prob)
+        cfg.zeros_prob = 1 - float(ones_prob)   # src/linksampling.cc:50
+        cfg.device = device
+        if node_block is not None:
+            cfg.node_begin, cfg.node_end = node_block
+        cfg.n_alloc = n_alloc
+        self.n, self.k = n, k
+        self._h = C.c_void_p()
+        _chk(L.svils_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().svils_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_graph(self, links):
+        links = np.ascontiguousarray(links, dtype=np.uint32)
+        assert links.ndim == 2 and links.shape[1] == 2
+        self.nlinks = links.shape[0]
+        _chk(load().svils_set_graph(self._h, links.ctypes.data, links.shape[0]))
+
+    def set_validation(self, pairs_y):
+        pairs_y = np.ascontiguousarray(pairs_y, dtype=np.uint32).reshape(-1, 3)
+        _chk(load().svils_set_validation(self._h, pairs_y.ctypes.data, pairs_y.shape[0]))
+
+    def set_state(self, gamma, lam, converged=None):
+        gamma = np.ascontiguousarray(gamma, dtype=np.float64)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        assert gamma.shape == (self.n, self.k) and lam.shape == (self.k, 2)
+        cptr = None
+        if converged is not None:
+            converged = np.ascontiguousarray(converged, dtype=np.uint32)
+            assert converged.shape == (self.n,)
+            cptr = converged.ctypes.data
+        _chk(load().svils_set_state(self._h, gamma.ctypes.data, lam.ctypes.data, cptr))
+
+    def control(self):
+        c = Control()
+        _chk(load().svils_get_control(self._h, C.byref(c)))
+        return c
+
+    def set_control(self, **kw):
+        c = self.control()
+        for key, val in kw.items():
+            setattr(c, key, val)
+        _chk(load().svils_set_control(self._h, C.byref(c)))
+
+    def validation_row(self):
+        row = np.zeros(10, dtype=np.float64)
+        _chk(load().svils_validation_row(self._h, row.ctypes.data))
+        return row
+
+    def sweep(self, nsweeps=1):
+        _chk(load().svils_sweep(self._h, nsweeps))
+
+    def sweep_phase(self, phase):
+        _chk(load().svils_sweep_phase(self._h, phase))
+
+    def synchronize(self):
+        _chk(load().svils_synchronize(self._h))
+
+    def rows(self, first=0, count=None):
+        if count is None:
+            count = self.control().rows - first
+        out = np.zeros((count, 10), dtype=np.float64)
+        if count:
+            _chk(load().svils_get_rows(self._h, first, count, out.ctypes.data))
+        return out
+
+    def state(self):
+        g = np.zeros((self.n, self.k), dtype=np.float64)
+        lam = np.zeros((self.k, 2), dtype=np.float64)
+        conv = np.zeros(self.n, dtype=np.uint32)
+        _chk(load().svils_get_state(self._h, g.ctypes.data, lam.ctypes.data, conv.ctypes.data))
+        return g, lam, conv
+
+    def communities(self):
+        m = np.zeros((self.n, self.k), dtype=np.uint8)
+        _chk(load().svils_get_communities(self._h, m.ctypes.data))
+        return m
+
+    def aux(self, which):
+        shapes = {0: ((self.n, self.k), np.float64), 1: ((self.k, 2), np.float64),
+                  2: ((self.n, self.k), np.float64), 3: ((self.n,), np.uint32),
+                  4: ((self.n,), np.float64)}
+        shape, dt = shapes[which]
+        out = np.zeros(shape, dtype=dt)
+        _chk(load().svils_get_aux(self._h, which, out.ctypes.data))
+        return out
+
+    def enable_timing(self, mask):
+        _chk(load().svils_enable_timing(self._h, mask))
+
+    def timing(self):
+        ms = np.zeros(len(KERNEL_NAMES), dtype=np.float64)
+        cnt = np.zeros(len(KERNEL_NAMES), dtype=np.uint64)
+        _chk(load().svils_get_timing(self._h, ms.ctypes.data, cnt.ctypes.data))
+        return {KERNEL_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(len(KERNEL_NAMES))}
+
+    def device_buffer(self, which):
+        p, b, r = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _chk(load().svils_device_buffer(self._h, which, C.byref(p), C.byref(b), C.byref(r)))
+        return p.value, b.value, r.value
+
+    def stream(self):
+        s = C.c_void_p()
+        _chk(load().svils_stream(self._h, C.byref(s)))
+        return s.value

@@ -1,0 +1,607 @@
+// svils_api.hip -- the C ABI of include/svils.h on top of the gfx950 kernels.
+// Host-side work here is plumbing only: argument checks, CSR construction,
+// uploads/downloads, launch sequencing and hipEvent timing.  There is no CPU
+// compute path: without a HIP device svils_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "svils_internal.h"
+
+using namespace svils;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(e_ == hipErrorOutOfMemory ? SVILS_ERR_NOMEM : SVILS_ERR_DEVICE,        \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+  } while (0)
+
+struct EvPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct svils_handle {
+  svils_config cfg;
+  Geometry geo;
+  DeviceState d;
+  Params prm;
+  hipStream_t stream = nullptr;
+  bool have_graph = false, have_state = false;
+  std::vector<void *> allocs;
+  double *row_scratch = nullptr;  // device [10]
+  // timing
+  uint32_t tmask = 0;
+  std::vector<EvPair> pending[SVILS_KERNEL_COUNT];
+  std::vector<EvPair> freelist;
+  double t_ms[SVILS_KERNEL_COUNT] = {0};
+  uint64_t t_n[SVILS_KERNEL_COUNT] = {0};
+  std::vector<uint64_t> h_rowptr;  // kept for training_links / aux
+};
+
+namespace {
+
+template <class T>
+int dalloc(svils_handle *h, T **p, size_t count, bool zero = true) {
+  *p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  void *q = nullptr;
+  HIPCHK(hipMalloc(&q, bytes));
+  h->allocs.push_back(q);
+  if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, h->stream));
+  *p = (T *)q;
+  return 0;
+}
+
+int drain_timing(svils_handle *h) {
+  for (int i = 0; i < SVILS_KERNEL_COUNT; ++i) {
+    for (auto &ev : h->pending[i]) {
+      HIPCHK(hipEventSynchronize(ev.b));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+      h->t_ms[i] += ms;
+      h->t_n[i]++;
+      h->freelist.push_back(ev);
+    }
+    h->pending[i].clear();
+  }
+  return 0;
+}
+
+struct Timed {
+  svils_handle *h;
+  int k;
+  EvPair ev{};
+  bool on;
+  Timed(svils_handle *h_, int k_) : h(h_), k(k_), on((h_->tmask >> k_) & 1u) {
+    if (!on) return;
+    if (h->freelist.empty()) {
+      if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+    } else {
+      ev = h->freelist.back();
+      h->freelist.pop_back();
+    }
+    (void)hipEventRecord(ev.a, h->stream);
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, h->stream);
+    h->pending[k].push_back(ev);
+  }
+};
+
+int run_phase(svils_handle *h, svils_phase ph) {
+  const Geometry &g = h->geo;
+  const DeviceState &d = h->d;
+  hipStream_t s = h->stream;
+  switch (ph) {
+    case SVILS_PHASE_A: {
+      { Timed t(h, SVILS_KERNEL_PHI); launch_phi(g, d, h->prm, s); }
+      { Timed t(h, SVILS_KERNEL_REDUCE_SUM); launch_reduce_a(g, d, s); }
+    } break;
+    case SVILS_PHASE_B: {
+      Timed t(h, SVILS_KERNEL_FINALIZE);
+      launch_finalize(g, d, h->prm, s);
+    } break;
+    case SVILS_PHASE_C: {
+      { Timed t(h, SVILS_KERNEL_S3); launch_s3(g, d, s); }
+      { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
+    } break;
+    case SVILS_PHASE_D: {
+      { Timed t(h, SVILS_KERNEL_VALIDATION); launch_validation(g, d, h->prm, 1, s); }
+      { Timed t(h, SVILS_KERNEL_TAIL); launch_tail(g, d, h->prm, s); }
+    } break;
+    default:
+      return fail(SVILS_ERR_ARG, "unknown phase %d", (int)ph);
+  }
+  HIPCHK(hipGetLastError());
+  // keep the event pools bounded
+  for (int i = 0; i < SVILS_KERNEL_COUNT; ++i)
+    if (h->pending[i].size() > 8192) return drain_timing(h);
+  return 0;
+}
+
+// chunk a row segment [off, off+len) of node p into items of <= ch neighbours
+void chunk_row(std::vector<Item> &items, uint32_t p, uint32_t off, uint32_t len, uint32_t ch,
+               int32_t *next_slot, int32_t *first_slot, uint32_t *nsplit) {
+  if (len == 0) { if (first_slot) { *first_slot = -1; *nsplit = 0; } return; }
+  uint32_t nch = (len + ch - 1) / ch;
+  if (nch <= 1 || !next_slot) {
+    if (nch <= 1) {
+      items.push_back(Item{p, off, len, -1});
+      if (first_slot) { *first_slot = -1; *nsplit = 0; }
+      return;
+    }
+  }
+  uint32_t base = len / nch, rem = len % nch, o = off;
+  if (first_slot) { *first_slot = *next_slot; *nsplit = nch; }
+  for (uint32_t c = 0; c < nch; ++c) {
+    uint32_t l = base + (c < rem ? 1u : 0u);
+    int32_t slot = -1;
+    if (next_slot) slot = (*next_slot)++;
+    items.push_back(Item{p, o, l, slot});
+    o += l;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *svils_last_error(void) { return g_err.c_str(); }
+int svils_abi_version(void) { return SVILS_ABI_VERSION; }
+
+const char *svils_kernel_name(int k) {
+  static const char *names[SVILS_KERNEL_COUNT] = {"phi", "reduce_sum", "finalize", "s3",
+                                                  "validation", "reduce_s", "tail"};
+  return (k >= 0 && k < SVILS_KERNEL_COUNT) ? names[k] : "?";
+}
+
+int svils_config_default(svils_config *cfg, uint32_t n, uint32_t k) {
+  if (!cfg || k == 0) return fail(SVILS_ERR_ARG, "svils_config_default: bad arguments");
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->n = n;
+  cfg->k = k;
+  cfg->alpha = (double)1 / k;   // src/env.hh:344
+  cfg->eta0 = 1.0;              // eta_type "uniform", src/network.cc:236-238
+  cfg->eta1 = 1.0;
+  cfg->epsilon = 1e-30;         // src/env.hh:395
+  cfg->link_thresh = 0.5;       // src/main.cc: link_thresh
+  cfg->lt_min_deg = 0;
+  cfg->reportfreq = 1;          // src/main.cc:149-153
+  cfg->use_validation_stop = 1;
+  cfg->ones_prob = 0.0;
+  cfg->zeros_prob = 1.0;
+  cfg->device = 0;
+  cfg->node_begin = 0;
+  cfg->node_end = n;
+  cfg->n_alloc = 0;
+  return 0;
+}
+
+int svils_create(const svils_config *cfg, svils_handle **out) {
+  if (!cfg || !out) return fail(SVILS_ERR_ARG, "svils_create: null argument");
+  *out = nullptr;
+  if (cfg->n == 0 || cfg->k == 0) return fail(SVILS_ERR_ARG, "svils_create: n and k must be > 0");
+  if (cfg->k > SVILS_MAX_K) return fail(SVILS_ERR_UNSUPPORTED, "k=%u exceeds SVILS_MAX_K=%d", cfg->k, SVILS_MAX_K);
+  if (cfg->reportfreq == 0) return fail(SVILS_ERR_ARG, "reportfreq must be >= 1");
+  uint32_t nb = cfg->node_begin, ne = cfg->node_end ? cfg->node_end : cfg->n;
+  if (nb > ne || ne > cfg->n) return fail(SVILS_ERR_ARG, "bad node block [%u,%u) for n=%u", nb, ne, cfg->n);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(SVILS_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(SVILS_ERR_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+  HIPCHK(hipSetDevice(cfg->device));
+
+  svils_handle *h = new (std::nothrow) svils_handle();
+  if (!h) return fail(SVILS_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  Geometry &g = h->geo;
+  g.n = cfg->n;
+  g.n_alloc = std::max(cfg->n_alloc, cfg->n);
+  g.K = cfg->k;
+  g.ld = (cfg->k + 15u) & ~15u;  // rows are 128-byte aligned
+  g.k10 = cfg->k / 10;           // integer division, src/linksampling.cc:465,634
+  g.node_begin = nb;
+  g.node_end = ne;
+  if (!pick_layout(cfg->k, &g.W, &g.V)) { delete h; return fail(SVILS_ERR_UNSUPPORTED, "unsupported k"); }
+  g.kw = (uint32_t)g.V;
+  Params &p = h->prm;
+  p.ones = cfg->ones; p.alpha = cfg->alpha; p.eta0 = cfg->eta0; p.eta1 = cfg->eta1;
+  p.epsilon = cfg->epsilon; p.link_thresh = cfg->link_thresh; p.lt_min_deg = cfg->lt_min_deg;
+  p.reportfreq = cfg->reportfreq; p.use_validation_stop = cfg->use_validation_stop;
+  p.ones_prob = cfg->ones_prob; p.zeros_prob = cfg->zeros_prob;
+  memset(&h->d, 0, sizeof(h->d));
+
+  int rc = 0;
+  auto guard = [&](int r) { if (r && !rc) rc = r; };
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(SVILS_ERR_DEVICE, "hipStreamCreate failed");
+  }
+  DeviceState &d = h->d;
+  const size_t nk = (size_t)g.n_alloc * g.ld;
+  guard(dalloc(h, &d.gamma, nk));
+  guard(dalloc(h, &d.elogpi, nk));
+  guard(dalloc(h, &d.mphi, nk));
+  guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
+  guard(dalloc(h, &d.active_cnt, g.n_alloc));
+  guard(dalloc(h, &d.amask, (size_t)g.n_alloc * g.kw));
+  guard(dalloc(h, &d.member, (size_t)g.n_alloc * g.kw));
+  guard(dalloc(h, &d.lambda, 2 * (size_t)g.K));
+  guard(dalloc(h, &d.elogbeta, 2 * (size_t)g.K));
+  guard(dalloc(h, &d.kvec_a, g.K));
+  guard(dalloc(h, &d.kvec_c, 3 * (size_t)g.K + 4));
+  d.rows_cap = 1u << 16;
+  guard(dalloc(h, &d.rows, (size_t)d.rows_cap * 10));
+  guard(dalloc(h, &d.ctrl, 1));
+  guard(dalloc(h, &h->row_scratch, 10));
+  if (rc) { svils_destroy(h); return rc; }
+  DevCtrl c;
+  memset(&c, 0, sizeof c);
+  c.annealing = 1;             // _annealing_phase(true), src/linksampling.cc:33
+  c.prev_h = -2147483647;      // :21
+  c.max_h = -2147483647;       // :19
+  c.iter = 0;                  // quirk Q1
+  if (hipMemcpyAsync(d.ctrl, &c, sizeof c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess) {
+    svils_destroy(h);
+    return fail(SVILS_ERR_DEVICE, "control block upload failed");
+  }
+  *out = h;
+  return 0;
+}
+
+int svils_destroy(svils_handle *h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int i = 0; i < SVILS_KERNEL_COUNT; ++i)
+    for (auto &ev : h->pending[i]) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (auto &ev : h->freelist) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
+  if (!h || (!links && nlinks)) return fail(SVILS_ERR_ARG, "svils_set_graph: null argument");
+  if (h->have_graph) return fail(SVILS_ERR_ARG, "svils_set_graph: graph already set");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  Geometry &g = h->geo;
+  const uint32_t n = g.n;
+  // symmetric CSR; row x = {p < x, ascending} ++ {q > x in link-list order}: the order in
+  // which the reference's link loop touches gammanext[x] (src/linksampling.cc:605-701)
+  std::vector<uint64_t> rowptr(n + 1, 0);
+  for (uint64_t l = 0; l < nlinks; ++l) {
+    uint32_t p = links[2 * l], q = links[2 * l + 1];
+    if (p >= q || q >= n) return fail(SVILS_ERR_ARG, "link %llu = (%u,%u): need p < q < n", (unsigned long long)l, p, q);
+    if (l && links[2 * l - 2] > p) return fail(SVILS_ERR_ARG, "links must be sorted by first endpoint (link %llu)", (unsigned long long)l);
+    rowptr[p + 1]++;
+    rowptr[q + 1]++;
+  }
+  for (uint32_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+  std::vector<uint32_t> col(std::max<uint64_t>(2 * nlinks, 1));
+  std::vector<uint32_t> upper(n, 0);
+  {
+    std::vector<uint64_t> fill(rowptr.begin(), rowptr.end() - 1);
+    // lower parts: links arrive sorted by p, so appending p to row q keeps ascending order
+    for (uint64_t l = 0; l < nlinks; ++l) col[fill[links[2 * l + 1]]++] = links[2 * l];
+    for (uint32_t i = 0; i < n; ++i) upper[i] = (uint32_t)(fill[i] - rowptr[i]);
+    for (uint64_t l = 0; l < nlinks; ++l) col[fill[links[2 * l]]++] = links[2 * l + 1];
+  }
+  // work items over the owned node block
+  const int G = 64 / g.W;
+  const uint32_t ch = 32u * (uint32_t)G;
+  std::vector<Item> items_phi, items_s3;
+  std::vector<int32_t> split_first(n, -1);
+  std::vector<uint32_t> split_cnt(n, 0);
+  int32_t next_slot = 0;
+  for (uint32_t p = g.node_begin; p < g.node_end; ++p) {
+    const uint32_t deg = (uint32_t)(rowptr[p + 1] - rowptr[p]);
+    chunk_row(items_phi, p, 0, deg, ch, &next_slot, &split_first[p], &split_cnt[p]);
+    chunk_row(items_s3, p, upper[p], deg - upper[p], ch, nullptr, nullptr, nullptr);
+  }
+  DeviceState &d = h->d;
+  d.nitems_phi = (uint32_t)items_phi.size();
+  d.nitems_s3 = (uint32_t)items_s3.size();
+  d.nslots = (uint32_t)next_slot;
+  auto cap = [](uint64_t x, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(x, lim)); };
+  d.nb_a = cap((d.nitems_phi + 3) / 4, 2048);
+  d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), 1024);
+  d.nb_c = cap((d.nitems_s3 + 3) / 4, 2048);
+
+  int rc = 0;
+  auto guard = [&](int r) { if (r && !rc) rc = r; };
+  guard(dalloc(h, &d.rowptr, (size_t)n + 1, false));
+  guard(dalloc(h, &d.col, col.size(), false));
+  guard(dalloc(h, &d.upper, n, false));
+  guard(dalloc(h, &d.items_phi, items_phi.size(), false));
+  guard(dalloc(h, &d.items_s3, items_s3.size(), false));
+  guard(dalloc(h, &d.split_first, n, false));
+  guard(dalloc(h, &d.split_cnt, n, false));
+  guard(dalloc(h, &d.parts, (size_t)d.nslots * g.ld));
+  guard(dalloc(h, &d.part_cnt, (size_t)d.nslots * g.ld));
+  guard(dalloc(h, &d.part_a, (size_t)d.nb_a * g.K));
+  guard(dalloc(h, &d.part_b, (size_t)d.nb_b * 2 * g.K));
+  guard(dalloc(h, &d.part_c, (size_t)d.nb_c * g.K));
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(d.rowptr, rowptr.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.col, col.data(), col.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.upper, upper.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  if (!items_phi.empty())
+    HIPCHK(hipMemcpyAsync(d.items_phi, items_phi.data(), items_phi.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
+  if (!items_s3.empty())
+    HIPCHK(hipMemcpyAsync(d.items_s3, items_s3.data(), items_s3.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.split_first, split_first.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.split_cnt, split_cnt.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->h_rowptr.swap(rowptr);
+  h->have_graph = true;
+  return 0;
+}
+
+int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) {
+  if (!h || (!pairs_y && nv)) return fail(SVILS_ERR_ARG, "svils_set_validation: null argument");
+  if (nv > 0xffffffffull) return fail(SVILS_ERR_UNSUPPORTED, "too many validation pairs");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  for (uint64_t i = 0; i < nv; ++i)
+    if (pairs_y[3 * i] >= h->geo.n || pairs_y[3 * i + 1] >= h->geo.n || pairs_y[3 * i + 2] > 1)
+      return fail(SVILS_ERR_ARG, "validation pair %llu out of range", (unsigned long long)i);
+  DeviceState &d = h->d;
+  int rc = dalloc(h, &d.vpairs, 3 * (size_t)nv, false);
+  if (!rc) rc = dalloc(h, &d.uval, nv);
+  if (rc) return rc;
+  if (nv) HIPCHK(hipMemcpyAsync(d.vpairs, pairs_y, 3 * nv * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  d.nv = (uint32_t)nv;
+  return 0;
+}
+
+int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
+                    const uint32_t *converged) {
+  if (!h || !gamma || !lambda) return fail(SVILS_ERR_ARG, "svils_set_state: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const Geometry &g = h->geo;
+  DeviceState &d = h->d;
+  HIPCHK(hipMemsetAsync(d.gamma, 0, (size_t)g.n_alloc * g.ld * sizeof(double), h->stream));
+  HIPCHK(hipMemcpy2DAsync(d.gamma, g.ld * sizeof(double), gamma, g.K * sizeof(double),
+                          g.K * sizeof(double), g.n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.lambda, lambda, 2 * (size_t)g.K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  DevCtrl c;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  uint32_t *cur = d.conv + (size_t)c.parity * g.n_alloc;
+  if (converged) HIPCHK(hipMemcpyAsync(cur, converged, g.n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(hipMemsetAsync(cur, 0, g.n * sizeof(uint32_t), h->stream));
+  launch_dir_exp(g, d, h->stream);
+  launch_lambda_exp(g, d, h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_state = true;
+  return 0;
+}
+
+int svils_get_control(svils_handle *h, svils_control *out) {
+  if (!h || !out) return fail(SVILS_ERR_ARG, "svils_get_control: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DevCtrl c;
+  HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  out->iter = c.iter; out->annealing = c.annealing; out->write_comm = c.write_comm; out->nh = c.nh;
+  out->prev_h = c.prev_h; out->max_h = c.max_h; out->stopped = c.stopped; out->why = c.why;
+  out->sweeps_done = c.sweeps_done; out->rows = c.rows;
+  out->links_dense = c.links_dense; out->links_sparse = c.links_sparse; out->links_shortcut = c.links_shortcut;
+  return 0;
+}
+
+int svils_set_control(svils_handle *h, const svils_control *in) {
+  if (!h || !in) return fail(SVILS_ERR_ARG, "svils_set_control: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DevCtrl c;
+  HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  c.iter = in->iter; c.annealing = in->annealing; c.write_comm = in->write_comm; c.nh = in->nh;
+  c.prev_h = in->prev_h; c.max_h = in->max_h;
+  HIPCHK(hipMemcpy(h->d.ctrl, &c, sizeof c, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int svils_validation_row(svils_handle *h, double *row10) {
+  if (!h || !row10) return fail(SVILS_ERR_ARG, "svils_validation_row: null argument");
+  if (!h->have_state) return fail(SVILS_ERR_ARG, "svils_validation_row: call svils_set_state first");
+  if (h->d.nv == 0) return fail(SVILS_ERR_ARG, "svils_validation_row: no validation set");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  launch_validation(h->geo, h->d, h->prm, 0, h->stream);
+  launch_row_only(h->geo, h->d, h->prm, h->row_scratch, h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(row10, h->row_scratch, 10 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int svils_sweep_phase(svils_handle *h, svils_phase phase) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_phase: null handle");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep_phase: set graph and state first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  return run_phase(h, phase);
+}
+
+int svils_sweep(svils_handle *h, uint32_t nsweeps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  for (uint32_t i = 0; i < nsweeps; ++i) {
+    int rc;
+    if ((rc = run_phase(h, SVILS_PHASE_A))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_B))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_C))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_D))) return rc;
+  }
+  return 0;
+}
+
+int svils_synchronize(svils_handle *h) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_synchronize: null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows) {
+  if (!h || (!rows && count)) return fail(SVILS_ERR_ARG, "svils_get_rows: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DevCtrl c;
+  HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if ((uint64_t)first + count > c.rows) return fail(SVILS_ERR_ARG, "rows [%u,%u) not recorded yet (have %u)", first, first + count, c.rows);
+  if (c.rows - first > h->d.rows_cap) return fail(SVILS_ERR_ARG, "row %u already overwritten in the ring", first);
+  for (uint32_t i = 0; i < count; ++i) {
+    uint32_t slot = (first + i) % h->d.rows_cap;
+    HIPCHK(hipMemcpy(rows + (size_t)i * 10, h->d.rows + (size_t)slot * 10, 10 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *converged) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_get_state: null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const Geometry &g = h->geo;
+  if (gamma)
+    HIPCHK(hipMemcpy2D(gamma, g.K * sizeof(double), h->d.gamma, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
+  if (lambda) HIPCHK(hipMemcpy(lambda, h->d.lambda, 2 * (size_t)g.K * sizeof(double), hipMemcpyDeviceToHost));
+  if (converged) {
+    DevCtrl c;
+    HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(converged, h->d.conv + (size_t)c.parity * g.n_alloc, g.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int svils_get_communities(svils_handle *h, uint8_t *member) {
+  if (!h || !member) return fail(SVILS_ERR_ARG, "svils_get_communities: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const Geometry &g = h->geo;
+  std::vector<uint64_t> bits((size_t)g.n * g.kw);
+  HIPCHK(hipMemcpy(bits.data(), h->d.member, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  memset(member, 0, (size_t)g.n * g.K);
+  for (uint32_t p = 0; p < g.n; ++p)
+    for (int v = 0; v < g.V; ++v) {
+      uint64_t b = bits[(size_t)p * g.kw + v];
+      while (b) {
+        int lw = __builtin_ctzll(b);
+        b &= b - 1;
+        uint32_t k = kmap_host(g.W, g.V, lw, v);
+        if (k < g.K) member[(size_t)p * g.K + k] = 1;
+      }
+    }
+  return 0;
+}
+
+int svils_get_aux(svils_handle *h, int which, void *out) {
+  if (!h || !out) return fail(SVILS_ERR_ARG, "svils_get_aux: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const Geometry &g = h->geo;
+  switch (which) {
+    case 0:
+      HIPCHK(hipMemcpy2D(out, g.K * sizeof(double), h->d.elogpi, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
+      return 0;
+    case 1:
+      HIPCHK(hipMemcpy(out, h->d.elogbeta, 2 * (size_t)g.K * sizeof(double), hipMemcpyDeviceToHost));
+      return 0;
+    case 2:
+      HIPCHK(hipMemcpy2D(out, g.K * sizeof(double), h->d.mphi, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
+      return 0;
+    case 3:
+      HIPCHK(hipMemcpy(out, h->d.active_cnt, g.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      return 0;
+    case 4: {
+      if (!h->have_graph) return fail(SVILS_ERR_ARG, "svils_get_aux: graph not set");
+      double *tl = (double *)out;
+      for (uint32_t p = 0; p < g.n; ++p) tl[p] = 2.0 * (double)(h->h_rowptr[p + 1] - h->h_rowptr[p]);
+      return 0;
+    }
+    default:
+      return fail(SVILS_ERR_ARG, "svils_get_aux: unknown selector %d", which);
+  }
+}
+
+int svils_enable_timing(svils_handle *h, uint32_t kernel_mask) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_enable_timing: null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int rc = drain_timing(h);
+  if (rc) return rc;
+  h->tmask = kernel_mask;
+  for (int i = 0; i < SVILS_KERNEL_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+  return 0;
+}
+
+int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches) {
+  if (!h || !ms || !launches) return fail(SVILS_ERR_ARG, "svils_get_timing: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int rc = drain_timing(h);
+  if (rc) return rc;
+  for (int i = 0; i < SVILS_KERNEL_COUNT; ++i) { ms[i] = h->t_ms[i]; launches[i] = h->t_n[i]; }
+  return 0;
+}
+
+int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr, size_t *bytes,
+                        size_t *row_bytes) {
+  if (!h || !dptr || !bytes || !row_bytes) return fail(SVILS_ERR_ARG, "svils_device_buffer: null argument");
+  const Geometry &g = h->geo;
+  const DeviceState &d = h->d;
+  switch (which) {
+    case SVILS_BUF_KVEC_A: *dptr = d.kvec_a; *bytes = g.K * sizeof(double); *row_bytes = *bytes; return 0;
+    case SVILS_BUF_KVEC_C: *dptr = d.kvec_c; *bytes = 3 * (size_t)g.K * sizeof(double); *row_bytes = *bytes; return 0;
+    case SVILS_BUF_GAMMA: *dptr = d.gamma; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_ELOGPI: *dptr = d.elogpi; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_MPHI: *dptr = d.mphi; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_CONV: {
+      // the buffer prune() writes during phase B = conv[parity ^ 1]; parity flips once per
+      // sweep in phase D, and the host can mirror it as (sweeps_done & 1)
+      *dptr = d.conv; *row_bytes = sizeof(uint32_t); *bytes = 2 * (size_t)g.n_alloc * sizeof(uint32_t); return 0;
+    }
+    case SVILS_BUF_ACTIVE: *dptr = d.active_cnt; *row_bytes = sizeof(uint32_t); *bytes = (size_t)g.n_alloc * sizeof(uint32_t); return 0;
+    case SVILS_BUF_AMASK: *dptr = d.amask; *row_bytes = g.kw * sizeof(uint64_t); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_MEMBER: *dptr = d.member; *row_bytes = g.kw * sizeof(uint64_t); *bytes = *row_bytes * g.n_alloc; return 0;
+    default: return fail(SVILS_ERR_ARG, "svils_device_buffer: unknown buffer %d", (int)which);
+  }
+}
+
+int svils_stream(svils_handle *h, void **stream) {
+  if (!h || !stream) return fail(SVILS_ERR_ARG, "svils_stream: null argument");
+  *stream = (void *)h->stream;
+  return 0;
+}
+
+}  // extern "C"

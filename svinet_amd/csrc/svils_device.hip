@@ -1,0 +1,793 @@
+// svils_device.hip -- gfx950 (MI355X, CDNA4) kernels for one sweep of svinet's
+// link-sampling inference loop.  fp64 throughout; no atomics on floating-point
+// data (every reduction has a fixed order => bit-reproducible run to run).
+//
+// The reference loop (src/linksampling.cc:600-761) is push-style: for each
+// link (p,q) add phi to gammanext[p] AND gammanext[q].  Here it is pull-style
+// over a symmetric CSR: the wavefront that owns node x walks x's row, computes
+// phi for each incident link and accumulates only gammanext[x] in registers.
+// Every undirected link is evaluated twice, nothing is scattered, node
+// ownership makes multi-GPU sharding trivial, and HBM traffic per link drops
+// from (2 row reads + 2 row RMWs) to (2 row reads).
+//
+// Register layout of a K-vector: a "group" of W lanes (W = 8..64, 64/W groups
+// per wavefront) holds one row; each lane keeps V doubles.  V == 1: lane l
+// owns k = l.  V >= 2: lane l owns the double2 chunks c = j*W + l, i.e.
+// k = 2c, 2c+1, so each global load instruction moves W*16 contiguous bytes.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "svils_internal.h"
+
+namespace svils {
+
+#define NEG_INF (-__builtin_huge_val())
+
+// ---------------------------------------------------------------- lane maps
+template <int W, int V>
+__device__ __forceinline__ int kmap(int lw, int v) {
+  return V == 1 ? lw : 2 * ((v >> 1) * W + lw) + (v & 1);
+}
+
+// ------------------------------------------------------- group reductions
+template <int W>
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+template <int W>
+__device__ __forceinline__ double group_max(double x) {
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) x = fmax(x, __shfl_xor(x, o, 64));
+  return x;
+}
+// sum across the 64/W groups of a wavefront (lane lw of every group ends with the total)
+template <int W>
+__device__ __forceinline__ double cross_group_sum(double x) {
+#pragma unroll
+  for (int o = W; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+template <int W>
+__device__ __forceinline__ uint32_t cross_group_sum_u32(uint32_t x) {
+#pragma unroll
+  for (int o = W; o < 64; o <<= 1) x += __shfl_xor((int)x, o, 64);
+  return x;
+}
+
+// --------------------------------------------------------------- row loads
+template <int W, int V>
+__device__ __forceinline__ void load_row(const double *__restrict__ row, int lw, uint32_t ld,
+                                         double (&x)[V]) {
+  if constexpr (V == 1) {
+    x[0] = (uint32_t)lw < ld ? row[lw] : 0.0;
+  } else {
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+      const uint32_t k0 = 2u * (uint32_t)(j * W + lw);
+      double2 t = make_double2(0.0, 0.0);
+      if (k0 < ld) t = *reinterpret_cast<const double2 *>(row + k0);
+      x[2 * j] = t.x;
+      x[2 * j + 1] = t.y;
+    }
+  }
+}
+template <int W, int V>
+__device__ __forceinline__ void store_row(double *__restrict__ row, int lw, uint32_t ld,
+                                          const double (&x)[V]) {
+  if constexpr (V == 1) {
+    if ((uint32_t)lw < ld) row[lw] = x[0];
+  } else {
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+      const uint32_t k0 = 2u * (uint32_t)(j * W + lw);
+      if (k0 < ld) *reinterpret_cast<double2 *>(row + k0) = make_double2(x[2 * j], x[2 * j + 1]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------- digamma
+// psi(x), x > 0: upward recurrence to x >= 10, then the asymptotic series
+// (double-accurate; stands where the reference calls gsl_sf_psi,
+// src/linksampling.hh:181,184).
+__device__ __forceinline__ double digamma(double x) {
+  double acc = 0.0;
+  while (x < 10.0) {
+    acc -= 1.0 / x;
+    x += 1.0;
+  }
+  const double xi = 1.0 / x, xi2 = xi * xi;
+  const double ser =
+      xi2 * (1.0 / 12.0 -
+             xi2 * (1.0 / 120.0 -
+                    xi2 * (1.0 / 252.0 -
+                           xi2 * (1.0 / 240.0 -
+                                  xi2 * (1.0 / 132.0 - xi2 * (691.0 / 32760.0 - xi2 * (1.0 / 12.0)))))));
+  return acc + log(x) - 0.5 * xi - ser;
+}
+
+// block-level reduction of per-lane K-vector partials into one row of `out`:
+// out[k] = sum over the block's 4 wavefronts and 64/W groups, fixed order.
+template <int W, int V, int NV>
+__device__ __forceinline__ void block_reduce_store(double (&part)[NV][V], double *__restrict__ out,
+                                                   uint32_t K, double *lds /*[NV][V][64]*/) {
+  constexpr int G = 64 / W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wavefronts add their partials one after the other (order 0,1,2,3)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < NV; ++a)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const int i = (a * V + v) * 64 + lane;
+          lds[i] = (w == 0) ? part[a][v] : lds[i] + part[a][v];
+        }
+    }
+    __syncthreads();
+  }
+  // then the 64/W groups (order 0..G-1); thread t handles (a, v, lw) triples
+  for (int idx = threadIdx.x; idx < NV * V * W; idx += blockDim.x) {
+    const int lw = idx % W, v = (idx / W) % V, a = idx / (W * V);
+    const int k = kmap<W, V>(lw, v);
+    if ((uint32_t)k < K) {
+      double s = 0.0;
+      for (int g = 0; g < G; ++g) s += lds[(a * V + v) * 64 + g * W + lw];
+      out[(size_t)a * K + k] = s;
+    }
+  }
+}
+
+// ============================================================== phi pass (A6)
+// src/linksampling.cc:605-725, pull-style.  One wavefront per Item; its 64/W
+// groups take the chunk's neighbours round-robin.
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params prm) {
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  constexpr int G = 64 / W;
+  __shared__ double lds[V * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool write_comm = ctrl->write_comm != 0;
+  const bool sparse_iter = ctrl->iter > 1000;  // src/linksampling.cc:634
+  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const double *__restrict__ elogpi = d.elogpi;
+
+  int kidx[V];
+  bool kval[V];
+  double eb[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)kidx[v] < K;
+    eb[v] = kval[v] ? d.elogbeta[2 * kidx[v]] : 0.0;
+  }
+  double csum[1][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) csum[0][v] = 0.0;
+  unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
+
+  for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_phi; it += gridDim.x * 4) {
+    const Item item = d.items_phi[it];
+    const uint32_t p = item.node;
+    const uint64_t base = d.rowptr[p] + item.off;
+    const uint32_t pc = conv[p];
+    double ap[V];
+    load_row<W, V>(elogpi + (size_t)p * ld, lw, ld, ap);
+    double acc[V];
+    uint32_t cnt[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { acc[v] = 0.0; cnt[v] = 0; }
+    uint32_t p_active = 0;
+    uint64_t pmask[V];
+    if (sparse_iter) {
+      p_active = d.active_cnt[p];
+#pragma unroll
+      for (int v = 0; v < V; ++v) pmask[v] = d.amask[(size_t)p * geo.kw + v];
+    }
+
+    for (uint32_t j = g; j < item.len; j += G) {
+      const uint32_t q = d.col[base + j];
+      const uint32_t qc = conv[q];
+      const bool count_me = q > p;  // count each undirected link once
+      if ((pc != 0) != (qc != 0)) {
+        // exactly one endpoint converged: src/linksampling.cc:622-631
+        const int c = (int)(pc ? pc : qc) - 1;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (kidx[v] == c) acc[v] += 1.0;
+        if (count_me && lw == 0) n_short++;
+      } else {
+        double aq[V];
+        load_row<W, V>(elogpi + (size_t)q * ld, lw, ld, aq);
+        bool inset[V];
+        bool sparse = false;
+        if (sparse_iter) {
+          const uint32_t q_active = d.active_cnt[q];
+          sparse = p_active < geo.k10 && q_active < geo.k10;
+        }
+        if (sparse) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const uint64_t um = pmask[v] | d.amask[(size_t)q * geo.kw + v];
+            inset[v] = kval[v] && ((um >> lw) & 1ull);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) inset[v] = kval[v];
+        }
+        double x[V];
+        double m = NEG_INF;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          x[v] = inset[v] ? (ap[v] + aq[v]) + eb[v] : NEG_INF;
+          m = fmax(m, x[v]);
+        }
+        m = group_max<W>(m);
+        if (m != NEG_INF) {  // an empty active-set union contributes nothing (:642-664)
+          double e[V];
+          double s = 0.0;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            e[v] = inset[v] ? exp(x[v] - m) : 0.0;
+            s += e[v];
+          }
+          s = group_sum<W>(s);
+          const double inv = 1.0 / s;
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[v] += e[v] * inv;
+          // community tagging, src/linksampling.cc:668-681,704-717: the first
+          // strict maximum of phi is the first k with x_k == max; its phi is 1/s.
+          if (write_comm && inv > prm.link_thresh) {
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+              if (inset[v] && x[v] == m) best = min(best, kidx[v]);
+#pragma unroll
+            for (int o = 1; o < W; o <<= 1) best = min(best, __shfl_xor(best, o, 64));
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+              if (kidx[v] == best) cnt[v]++;
+          }
+        }
+        if (count_me && lw == 0) { if (sparse) n_sparse++; else n_dense++; }
+      }
+    }
+
+    // combine the groups' partial accumulators (fixed order)
+    if constexpr (G > 1) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        acc[v] = cross_group_sum<W>(acc[v]);
+        cnt[v] = cross_group_sum_u32<W>(cnt[v]);
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) csum[0][v] += acc[v];
+    }
+    if (item.slot < 0) {
+      if (g == 0) store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
+      if (write_comm) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const unsigned long long b = __ballot(g == 0 && kval[v] && cnt[v] > prm.lt_min_deg);
+          if (lane == 0) d.member[(size_t)p * geo.kw + v] = b;
+        }
+      }
+    } else {
+      if (g == 0) {
+        store_row<W, V>(d.parts + (size_t)item.slot * ld, lw, ld, acc);
+        if (write_comm) {
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kval[v]) d.part_cnt[(size_t)item.slot * ld + kidx[v]] = cnt[v];
+        }
+      }
+    }
+  }
+
+  // per-block partial of `sum` (src/linksampling.cc:625,630,663,700 summed per node)
+  block_reduce_store<W, V, 1>(csum, d.part_a + (size_t)blockIdx.x * K, K, lds);
+  // link statistics (integers: order-free)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n_dense += __shfl_xor((long long)n_dense, o, 64);
+    n_sparse += __shfl_xor((long long)n_sparse, o, 64);
+    n_short += __shfl_xor((long long)n_short, o, 64);
+  }
+  if (lane == 0) {
+    if (n_dense) atomicAdd(&ctrl->cur_dense, n_dense);
+    if (n_sparse) atomicAdd(&ctrl->cur_sparse, n_sparse);
+    if (n_short) atomicAdd(&ctrl->cur_shortcut, n_short);
+  }
+}
+
+// ===================================================== column reduce of partials
+// out[c] = sum_b part[b][c], c in [0, ncols): 16 columns x 16 row-segments per block.
+__global__ __launch_bounds__(256) void k_colreduce(const double *__restrict__ part, uint32_t nb,
+                                                   uint32_t ncols, double *__restrict__ out,
+                                                   const DevCtrl *ctrl) {
+  if (ctrl->stopped) return;
+  __shared__ double lds[16][17];
+  const int cl = threadIdx.x & 15, seg = threadIdx.x >> 4;
+  const uint32_t c = blockIdx.x * 16 + cl;
+  double s = 0.0;
+  if (c < ncols)
+    for (uint32_t b = seg; b < nb; b += 16) s += part[(size_t)b * ncols + c];
+  lds[seg][cl] = s;
+  __syncthreads();
+  if (seg == 0 && c < ncols) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += lds[i][cl];
+    out[c] = t;
+  }
+}
+
+// ======================================= node finalise (A7 + swap + A5 + A9)
+// compute_mean_indicators (src/linksampling.cc:526-545), the gamma swap/reset
+// (:751-755), set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491),
+// one group per owned node.
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, Params prm) {
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  constexpr int G = 64 / W;
+  __shared__ double lds[2 * V * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool annealing = ctrl->annealing != 0;
+  const bool write_comm = ctrl->write_comm != 0;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
+
+  int kidx[V];
+  bool kval[V];
+  double scale[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)kidx[v] < K;
+    // _network.ones() / _sum[k], src/linksampling.cc:542
+    scale[v] = (annealing && kval[v]) ? (double)prm.ones / d.kvec_a[kidx[v]] : 1.0;
+  }
+  double s12[2][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
+
+  const uint32_t nown = geo.node_end - geo.node_begin;
+  for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < nown; i += gridDim.x * 4 * G) {
+    const uint32_t p = geo.node_begin + i;
+    const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
+    double acc[V];
+    const int32_t sf = d.split_first[p];
+    if (sf < 0) {
+      load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = 0.0;
+      const uint32_t sc = d.split_cnt[p];
+      for (uint32_t t = 0; t < sc; ++t) {
+        double part[V];
+        load_row<W, V>(d.parts + (size_t)(sf + t) * ld, lw, ld, part);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += part[v];
+      }
+      if (write_comm) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          uint32_t c = 0;
+          if (kval[v])
+            for (uint32_t t = 0; t < sc; ++t) c += d.part_cnt[(size_t)(sf + t) * ld + kidx[v]];
+          const unsigned long long b = __ballot(kval[v] && c > prm.lt_min_deg);
+          if (lw == 0) d.member[(size_t)p * geo.kw + v] = (b >> (g * W)) & (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull));
+        }
+      }
+    }
+    double gn[V];
+    if (tl > 0.0) {
+      double m[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const double g0 = prm.alpha + acc[v];
+        m[v] = (g0 - prm.alpha) / tl;
+        gn[v] = g0 + ((double)geo.n - tl - 1.0) * m[v];
+        if (annealing) gn[v] *= scale[v];
+        if (kval[v]) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; }
+        else { m[v] = 0.0; gn[v] = 0.0; }
+      }
+      store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+    } else {
+      // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
+#pragma unroll
+      for (int v = 0; v < V; ++v) gn[v] = kval[v] ? prm.alpha : 0.0;
+    }
+    store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    double rs = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) rs += gn[v];
+    rs = group_sum<W>(rs);
+    const double psi_rs = digamma(rs);
+    double el[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v]) - psi_rs : 0.0;
+    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    // prune / check_and_set_converged, src/linksampling.cc:455-475
+    uint32_t active = 0;
+    int last_k = -1;
+    unsigned long long bits[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const bool a = kval[v] && (gn[v] - prm.alpha >= 1.0);
+      const unsigned long long b =
+          (__ballot(a) >> (g * W)) & (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull));
+      bits[v] = b;
+      active += (uint32_t)__popcll(b);
+      if (a) last_k = max(last_k, kidx[v]);
+    }
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) last_k = max(last_k, __shfl_xor(last_k, o, 64));
+    if (lw == 0) {
+      conv_new[p] = (active == 1) ? (uint32_t)last_k + 1u : conv_old[p];
+      d.active_cnt[p] = active;
+#pragma unroll
+      for (int v = 0; v < V; ++v) d.amask[(size_t)p * geo.kw + v] = (active <= geo.k10) ? bits[v] : 0ull;
+    }
+  }
+  block_reduce_store<W, V, 2>(s12, d.part_b + (size_t)blockIdx.x * 2 * K, K, lds);
+}
+
+// Elogpi from gamma only (LinkSampling ctor / top of infer(), src/linksampling.cc:123,561)
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_dir_exp(Geometry geo, DeviceState d) {
+  constexpr int G = 64 / W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  for (uint32_t p = (blockIdx.x * 4 + wave) * G + g; p < geo.n; p += gridDim.x * 4 * G) {
+    double gn[V];
+    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    double rs = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if ((uint32_t)kmap<W, V>(lw, v) >= K) gn[v] = 0.0;
+      rs += gn[v];
+    }
+    rs = group_sum<W>(rs);
+    const double psi_rs = digamma(rs);
+    double el[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v]) - psi_rs : 0.0;
+    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+  }
+}
+
+// ================================================================ s3 pass (A8)
+// src/linksampling.cc:731-746 over the upper half (q > p) of each owned row,
+// including quirk Q2 (mphi[q][pc], one past the converged community).
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  constexpr int G = 64 / W;
+  __shared__ double lds[V * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const double *__restrict__ mphi = d.mphi;
+  int kidx[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) kidx[v] = kmap<W, V>(lw, v);
+  double s3[1][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s3[0][v] = 0.0;
+
+  for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_s3; it += gridDim.x * 4) {
+    const Item item = d.items_s3[it];
+    const uint32_t p = item.node;
+    const uint64_t base = d.rowptr[p] + item.off;
+    const uint32_t pc = conv[p];
+    double mp[V];
+    load_row<W, V>(mphi + (size_t)p * ld, lw, ld, mp);
+    for (uint32_t j = g; j < item.len; j += G) {
+      const uint32_t q = d.col[base + j];
+      const uint32_t qc = conv[q];
+      if (pc && !qc) {
+        const double val = pc < K ? mphi[(size_t)q * ld + pc] : 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (kidx[v] == (int)pc - 1) s3[0][v] += val;
+      } else if (!pc && qc) {
+        const double val = qc < K ? mphi[(size_t)p * ld + qc] : 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (kidx[v] == (int)qc - 1) s3[0][v] += val;
+      } else {
+        double mq[V];
+        load_row<W, V>(mphi + (size_t)q * ld, lw, ld, mq);
+#pragma unroll
+        for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
+      }
+    }
+  }
+  block_reduce_store<W, V, 1>(s3, d.part_c + (size_t)blockIdx.x * K, K, lds);
+}
+
+// ================================================== validation likelihood (A10)
+// edge_likelihood (src/linksampling.hh:258-292), one group per held-out pair.
+// The non-link K^2 double loop collapses exactly:
+//   sum_{z,z'} pi_p[z] pi_q[z'] (1 - [z==z'] beta_z - [z!=z'] eps), 1 - eps == 1.0 in double
+//   = (sum pi_p)(sum pi_q) - sum_z pi_p[z] pi_q[z] beta_z .
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d, Params prm,
+                                                    int in_loop) {
+  const DevCtrl *ctrl = d.ctrl;
+  if (in_loop) {
+    if (ctrl->stopped) return;
+    if (ctrl->iter % prm.reportfreq != 0) return;
+  }
+  constexpr int G = 64 / W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  double beta[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int k = kmap<W, V>(lw, v);
+    beta[v] = 0.0;
+    if ((uint32_t)k < K) {
+      double l0, l1;
+      if (in_loop) {  // lambda of this sweep, same expression as k_tail
+        l0 = prm.eta0 + d.kvec_a[k];
+        const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
+        l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+      } else {
+        l0 = d.lambda[2 * k];
+        l1 = d.lambda[2 * k + 1];
+      }
+      beta[v] = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
+    }
+  }
+  for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < d.nv; i += gridDim.x * 4 * G) {
+    const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1];
+    const uint32_t y = d.vpairs[3 * (size_t)i + 2];
+    double gp[V], gq[V];
+    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gp);
+    load_row<W, V>(d.gamma + (size_t)q * ld, lw, ld, gq);
+    double sp = 0.0, sq = 0.0, dot = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      sp += gp[v];
+      sq += gq[v];
+      dot += gp[v] * gq[v] * beta[v];
+    }
+    sp = group_sum<W>(sp);
+    sq = group_sum<W>(sq);
+    dot = group_sum<W>(dot);
+    const double pq = dot / (sp * sq);
+    double s = y ? pq : 1.0 - pq;
+    if (s < 1e-30) s = 1e-30;
+    if (lw == 0) d.uval[i] = log(s);
+  }
+}
+
+// =============================================================== tail (A8/A10/A11)
+// lambda update + set_dir_exp(lambda) (src/linksampling.cc:748-759), the
+// likelihood row, stop rule and annealing switch of validation_likelihood
+// (:994-1049), write_comm for the next sweep (:768-774) and _iter++ (:787).
+__global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Params prm) {
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double red[2][256];
+  __shared__ unsigned int cntz[256];
+  const uint32_t K = geo.K;
+  for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
+    const double l0 = prm.eta0 + d.kvec_a[k];
+    const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
+    const double l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+    d.lambda[2 * k] = l0;
+    d.lambda[2 * k + 1] = l1;
+    const double ps = digamma(l0 + l1);
+    d.elogbeta[2 * k] = digamma(l0) - ps;
+    d.elogbeta[2 * k + 1] = digamma(l1) - ps;
+  }
+  const uint32_t iter = ctrl->iter;
+  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
+  double sz = 0.0, so = 0.0;
+  unsigned int kz = 0;
+  if (do_val) {
+    // contiguous slices per thread, then a fixed-order tree
+    const uint32_t per = (d.nv + blockDim.x - 1) / blockDim.x;
+    const uint32_t b = threadIdx.x * per, e = min(d.nv, b + per);
+    for (uint32_t i = b; i < e; ++i) {
+      const double u = d.uval[i];
+      if (d.vpairs[3 * (size_t)i + 2]) so += u; else { sz += u; kz++; }
+    }
+  }
+  red[0][threadIdx.x] = sz;
+  red[1][threadIdx.x] = so;
+  cntz[threadIdx.x] = kz;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      cntz[threadIdx.x] += cntz[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ctrl->parity ^= 1u;  // prune()'s flags become current
+    ctrl->links_dense = ctrl->cur_dense; ctrl->links_sparse = ctrl->cur_sparse;
+    ctrl->links_shortcut = ctrl->cur_shortcut;
+    ctrl->cur_dense = ctrl->cur_sparse = ctrl->cur_shortcut = 0;
+    ctrl->sweeps_done++;
+    ctrl->write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+    bool exit_now = false;
+    if (do_val) {
+      const double szeros = red[0][0], sones = red[1][0];
+      const uint32_t kzeros = cntz[0], kones = d.nv - cntz[0];
+      const double mean0 = szeros / kzeros, mean1 = sones / kones;
+      const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
+      double *row = d.rows + (size_t)(ctrl->rows % d.rows_cap) * 10;
+      row[0] = (double)iter; row[1] = (szeros + sones) / d.nv; row[2] = (double)d.nv;
+      row[3] = mean0; row[4] = (double)kzeros; row[5] = mean1; row[6] = (double)kones;
+      row[7] = prm.zeros_prob * mean0; row[8] = prm.ones_prob * mean1; row[9] = a;
+      ctrl->rows++;
+      bool stop = false;
+      int why = -1;
+      if (iter > 10) {
+        const double prev = ctrl->prev_h;
+        if (a > prev && prev != 0 && fabs((a - prev) / prev) < 0.00001) { stop = true; why = 100; }
+        else if (a < prev) ctrl->nh++;
+        else if (a > prev) ctrl->nh = 0;
+        if (a > ctrl->max_h) ctrl->max_h = a;
+        if (ctrl->nh > 2) { why = 1; stop = true; }
+      }
+      ctrl->prev_h = a;
+      if (ctrl->annealing && stop) {
+        ctrl->annealing = 0; ctrl->nh = 0; ctrl->prev_h = 0; why = 0;
+      } else if (!ctrl->annealing && stop) {
+        if (prm.use_validation_stop) exit_now = true;
+      }
+      ctrl->why = why;
+    }
+    if (exit_now) ctrl->stopped = 1;  // do_on_stop(); exit(0): _iter is not advanced
+    else ctrl->iter = iter + 1;
+  }
+}
+
+// likelihood row without the stop rule (the constructor's call, :149-150)
+__global__ __launch_bounds__(256) void k_row_only(DeviceState d, Params prm, double *row_out) {
+  __shared__ double red[2][256];
+  __shared__ unsigned int cntz[256];
+  double sz = 0.0, so = 0.0;
+  unsigned int kz = 0;
+  const uint32_t per = (d.nv + blockDim.x - 1) / blockDim.x;
+  const uint32_t b = threadIdx.x * per, e = min(d.nv, b + per);
+  for (uint32_t i = b; i < e; ++i) {
+    const double u = d.uval[i];
+    if (d.vpairs[3 * (size_t)i + 2]) so += u; else { sz += u; kz++; }
+  }
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cntz[threadIdx.x] = kz;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      cntz[threadIdx.x] += cntz[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double szeros = red[0][0], sones = red[1][0];
+    const uint32_t kzeros = cntz[0], kones = d.nv - cntz[0];
+    const double mean0 = szeros / kzeros, mean1 = sones / kones;
+    row_out[0] = (double)d.ctrl->iter; row_out[1] = (szeros + sones) / d.nv; row_out[2] = (double)d.nv;
+    row_out[3] = mean0; row_out[4] = (double)kzeros; row_out[5] = mean1; row_out[6] = (double)kones;
+    row_out[7] = prm.zeros_prob * mean0; row_out[8] = prm.ones_prob * mean1;
+    row_out[9] = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
+  }
+}
+
+// Elogbeta from lambda (set_dir_exp(_lambda, _Elogbeta), src/linksampling.cc:124,563)
+__global__ __launch_bounds__(256) void k_lambda_exp(Geometry geo, DeviceState d) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < geo.K; k += gridDim.x * blockDim.x) {
+    const double l0 = d.lambda[2 * k], l1 = d.lambda[2 * k + 1];
+    const double ps = digamma(l0 + l1);
+    d.elogbeta[2 * k] = digamma(l0) - ps;
+    d.elogbeta[2 * k + 1] = digamma(l1) - ps;
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+bool pick_layout(uint32_t K, int *W, int *V) {
+  if (K == 0 || K > SVILS_MAX_K) return false;
+  if (K <= 8) { *W = 8; *V = 1; }
+  else if (K <= 16) { *W = 16; *V = 1; }
+  else if (K <= 32) { *W = 32; *V = 1; }
+  else if (K <= 64) { *W = 64; *V = 1; }
+  else if (K <= 128) { *W = 64; *V = 2; }
+  else if (K <= 256) { *W = 64; *V = 4; }
+  else if (K <= 512) { *W = 64; *V = 8; }
+  else if (K <= 1024) { *W = 64; *V = 16; }
+  else { *W = 64; *V = 32; }
+  return true;
+}
+
+#define SVILS_DISPATCH(geo, CALL)                                              \
+  do {                                                                         \
+    if ((geo).W == 8) { CALL(8, 1); }                                          \
+    else if ((geo).W == 16) { CALL(16, 1); }                                   \
+    else if ((geo).W == 32) { CALL(32, 1); }                                   \
+    else if ((geo).V == 1) { CALL(64, 1); }                                    \
+    else if ((geo).V == 2) { CALL(64, 2); }                                    \
+    else if ((geo).V == 4) { CALL(64, 4); }                                    \
+    else if ((geo).V == 8) { CALL(64, 8); }                                    \
+    else if ((geo).V == 16) { CALL(64, 16); }                                  \
+    else { CALL(64, 32); }                                                     \
+  } while (0)
+
+void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+#define CALL(W_, V_) hipLaunchKernelGGL((k_phi<W_, V_>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
+}
+void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_colreduce, dim3((g.K + 15) / 16), dim3(256), 0, s, d.part_a, d.nb_a, g.K,
+                     d.kvec_a, d.ctrl);
+}
+void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+#define CALL(W_, V_) hipLaunchKernelGGL((k_finalize<W_, V_>), dim3(d.nb_b), dim3(256), 0, s, g, d, p)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
+}
+void launch_s3(const Geometry &g, const DeviceState &d, hipStream_t s) {
+#define CALL(W_, V_) hipLaunchKernelGGL((k_s3<W_, V_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
+}
+void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_colreduce, dim3((2 * g.K + 15) / 16), dim3(256), 0, s, d.part_b, d.nb_b,
+                     2 * g.K, d.kvec_c, d.ctrl);
+  hipLaunchKernelGGL(k_colreduce, dim3((g.K + 15) / 16), dim3(256), 0, s, d.part_c, d.nb_c, g.K,
+                     d.kvec_c + 2 * (size_t)g.K, d.ctrl);
+}
+void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
+                       hipStream_t s) {
+  if (d.nv == 0) return;
+  const int G = 64 / g.W;
+  uint32_t nb = (d.nv + 4 * G - 1) / (4 * G);
+  if (nb > 2048) nb = 2048;
+#define CALL(W_, V_) \
+  hipLaunchKernelGGL((k_validation<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, p, in_loop)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
+}
+void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, g, d, p);
+}
+void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  const int G = 64 / g.W;
+  uint32_t nb = (g.n + 4 * G - 1) / (4 * G);
+  if (nb > 2048) nb = 2048;
+#define CALL(W_, V_) hipLaunchKernelGGL((k_dir_exp<W_, V_>), dim3(nb), dim3(256), 0, s, g, d)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
+}
+void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_lambda_exp, dim3((g.K + 255) / 256), dim3(256), 0, s, g, d);
+}
+void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
+                     hipStream_t s) {
+  (void)g;
+  hipLaunchKernelGGL(k_row_only, dim3(1), dim3(256), 0, s, d, p, row_out);
+}
+
+}  // namespace svils

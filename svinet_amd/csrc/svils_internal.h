@@ -1,0 +1,113 @@
+// svils_internal.h -- types shared by the C-ABI layer and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svils.h"
+
+namespace svils {
+
+// One unit of work of the phi pass: a contiguous chunk of a node's CSR row.
+// Rows longer than the chunk limit are split so a hub (ca-AstroPh: degree 504
+// vs mean 22) does not serialise a wavefront; partial accumulators of split
+// rows go to `slot` and are combined in fixed order by the finalise kernel.
+struct Item {
+  uint32_t node;
+  uint32_t off;   // offset inside the node's row
+  uint32_t len;   // neighbours in this chunk
+  int32_t slot;   // -1: row not split, result goes straight to gamma[node]
+};
+
+// Device-resident loop state of LinkSampling::infer() /
+// validation_likelihood() (src/linksampling.cc:556-790, :966-1050).
+struct DevCtrl {
+  uint32_t iter;
+  int32_t annealing;
+  int32_t write_comm;
+  int32_t nh;
+  double prev_h;
+  double max_h;
+  int32_t stopped;
+  int32_t why;
+  uint32_t sweeps_done;
+  uint32_t rows;
+  unsigned long long links_dense, links_sparse, links_shortcut;       // published (last sweep)
+  unsigned long long cur_dense, cur_sparse, cur_shortcut;             // being counted
+  uint32_t parity;  // conv[parity] is the current _converged, conv[parity^1] receives prune()'s
+  uint32_t pad;
+};
+
+struct Geometry {
+  uint32_t n, n_alloc, K, ld, kw, k10;
+  uint32_t node_begin, node_end;
+  int W, V;  // lanes per row group, doubles per lane (K <= W*V)
+};
+
+struct DeviceState {
+  // graph
+  uint64_t *rowptr;     // [n+1] symmetric CSR of training links
+  uint32_t *col;        // row x = {p < x ascending} ++ {q > x in adjacency order}
+  uint32_t *upper;      // [n] offset of the first q > x inside row x
+  Item *items_phi;      // chunks over owned rows
+  uint32_t nitems_phi;
+  Item *items_s3;       // chunks over the upper part of owned rows
+  uint32_t nitems_s3;
+  int32_t *split_first; // [n] first slot of a split row or -1
+  uint32_t *split_cnt;  // [n]
+  uint32_t nslots;
+  double *parts;        // [nslots][ld] partial accumulators of split rows
+  uint32_t *part_cnt;   // [nslots][ld] partial fmap counts of split rows
+  // state
+  double *gamma;        // [n_alloc][ld]; doubles as gammanext-accumulator inside a sweep
+  double *elogpi;       // [n_alloc][ld]
+  double *mphi;         // [n_alloc][ld]
+  uint32_t *conv;       // [2][n_alloc]
+  uint32_t *active_cnt; // [n_alloc]
+  uint64_t *amask;      // [n_alloc][kw] lane-layout bitmask of _active_k
+  uint64_t *member;     // [n_alloc][kw] lane-layout bitmask of communities
+  double *lambda;       // [K][2]
+  double *elogbeta;     // [K][2]
+  // K-vectors / partials
+  double *part_a;       // [nb_a][K]      per-block partial of `sum`
+  double *part_b;       // [nb_b][2K]     per-block partials of s1,s2
+  double *part_c;       // [nb_c][K]      per-block partial of s3
+  double *kvec_a;       // [K]            sum
+  double *kvec_c;       // [3K+4]         s1,s2,s3
+  uint32_t nb_a, nb_b, nb_c;
+  // validation
+  uint32_t *vpairs;     // [nv][3]
+  double *uval;         // [nv]
+  uint32_t nv;
+  double *rows;         // [rows_cap][10]
+  uint32_t rows_cap;
+  DevCtrl *ctrl;
+};
+
+struct Params {
+  uint64_t ones;
+  double alpha, eta0, eta1, epsilon, link_thresh;
+  uint32_t lt_min_deg, reportfreq;
+  int32_t use_validation_stop;
+  double ones_prob, zeros_prob;
+};
+
+// launchers (svils_device.hip); all asynchronous on `s`
+void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_s3(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
+                       hipStream_t s);
+void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
+                     hipStream_t s);
+bool pick_layout(uint32_t K, int *W, int *V);
+// k owned by (lane-in-group lw, register v) for layout (W,V); host copy of the device mapping
+inline uint32_t kmap_host(int W, int V, int lw, int v) {
+  return V == 1 ? (uint32_t)lw : (uint32_t)(2 * ((v >> 1) * W + lw) + (v & 1));
+}
+
+}  // namespace svils

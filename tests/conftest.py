@@ -1,0 +1,29 @@
+import gzip
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def graph_files(tmp_path_factory):
+    """Decompressed copies of the example graphs the reference ships (tests/golden/graphs)."""
+    d = tmp_path_factory.mktemp("graphs")
+    out = {}
+    for name, key in (("LFR-network-n1000-k28.txt.gz", "lfr"), ("ca-AstroPh.csv.gz", "astroph")):
+        dst = os.path.join(str(d), name[:-3])
+        with gzip.open(os.path.join(GOLDEN, "graphs", name), "rb") as f, open(dst, "wb") as g:
+            g.write(f.read())
+        out[key] = dst
+    out["assort"] = os.path.join(GOLDEN, "graphs", "assort-75-4.txt")
+    return out
