@@ -59,12 +59,12 @@ def build_host(force=False):
     hostlib = os.path.join(LIBDIR, "libsvinet_host.so")
     if force or _stale(hostlib, deps):
         _run([CXX] + CXX_FLAGS + ["-shared", "-o", hostlib] + lib_srcs +
-             ["-I", os.path.join(ROOT, "include"), "-ldl"])
+             ["-I", os.path.join(ROOT, "include"), "-L", LIBDIR, "-lsvils", "-Wl,-rpath,$ORIGIN"])
     exe = os.path.join(BINDIR, "svinet")
     main = os.path.join(HOST, "main.cc")
     if os.path.exists(main) and (force or _stale(exe, deps + [hostlib])):
         _run([CXX] + CXX_FLAGS + ["-o", exe, main, "-I", os.path.join(ROOT, "include"),
-              "-L", LIBDIR, "-lsvinet_host", "-ldl", "-Wl,-rpath,$ORIGIN/../lib"])
+              "-L", LIBDIR, "-lsvinet_host", "-lsvils", "-Wl,-rpath,$ORIGIN/../lib"])
     return hostlib
 
 

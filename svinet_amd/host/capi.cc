@@ -1,0 +1,89 @@
+// capi.cc -- C entry points over the host-side C++ classes, for Python
+// (bench.py, tests) to obtain the product's own inputs for the C ABI of
+// include/svils.h: graph reading, held-out sampling, gamma/lambda
+// initialisation and the training-link list.  No device is touched here.
+#include <cstring>
+#include <memory>
+
+#include "env.hh"
+#include "linksampling.hh"
+#include "network.hh"
+
+using namespace svinet;
+
+extern "C" {
+
+typedef struct {
+  uint32_t n, k;
+  double seed;
+  double heldout_ratio;
+  double link_thresh;
+  uint32_t lt_min_deg;
+  int32_t eta_type;        // 0 uniform, 1 fromdata, 2 sparse, 3 dense
+  int32_t accuracy;
+} svih_options;
+
+struct svih_setup {
+  std::unique_ptr<Env> env;
+  std::unique_ptr<Network> net;
+  std::unique_ptr<LinkSampling> ls;
+};
+
+static svih_setup *make_setup(const svih_options *o, const char *path, const int32_t *pairs,
+                              uint64_t nlines) {
+  static const char *eta_names[] = {"uniform", "fromdata", "sparse", "dense"};
+  Env::Args a;
+  a.n = o->n;
+  a.k = o->k;
+  a.link_sampling = true;
+  a.rand_seed = o->seed;
+  a.hol_ratio = o->heldout_ratio;
+  a.link_thresh = o->link_thresh;
+  a.lt_min_deg = o->lt_min_deg;
+  a.eta_type = eta_names[(o->eta_type >= 0 && o->eta_type < 4) ? o->eta_type : 0];
+  a.accuracy = o->accuracy != 0;
+  a.write_files = false;
+  svih_setup *s = new svih_setup();
+  s->env.reset(new Env(a));
+  s->net.reset(new Network(*s->env));
+  if (path) {
+    if (s->net->read(path) < 0) { delete s; return nullptr; }
+  } else {
+    s->net->read_pairs(pairs, nlines);
+  }
+  s->env->n = s->net->n() - s->net->singles();   // src/main.cc:291
+  s->ls.reset(new LinkSampling(*s->env, *s->net, /*attach_device=*/false));
+  return s;
+}
+
+void svih_options_default(svih_options *o, uint32_t n, uint32_t k) {
+  memset(o, 0, sizeof *o);
+  o->n = n; o->k = k; o->seed = 0; o->heldout_ratio = 0.01; o->link_thresh = 0.5;
+  o->lt_min_deg = 0; o->eta_type = 0; o->accuracy = 0;
+}
+svih_setup *svih_setup_from_file(const char *path, const svih_options *o) { return make_setup(o, path, nullptr, 0); }
+svih_setup *svih_setup_from_pairs(const int32_t *pairs, uint64_t nlines, const svih_options *o) {
+  return make_setup(o, nullptr, pairs, nlines);
+}
+void svih_setup_free(svih_setup *s) { delete s; }
+
+uint32_t svih_n(const svih_setup *s) { return s->ls->n(); }
+uint32_t svih_k(const svih_setup *s) { return s->ls->k(); }
+uint32_t svih_ones(const svih_setup *s) { return s->net->ones(); }
+uint32_t svih_singles(const svih_setup *s) { return s->net->singles(); }
+double svih_total_pairs(const svih_setup *s) { return s->ls->total_pairs(); }
+double svih_ones_prob(const svih_setup *s) { return s->ls->ones_prob(); }
+double svih_eta0(const svih_setup *s) { return s->env->eta0; }
+double svih_eta1(const svih_setup *s) { return s->env->eta1; }
+const uint32_t *svih_seq2id(const svih_setup *s) { return s->net->seq2id().data(); }
+const double *svih_gamma(const svih_setup *s) { return s->ls->gamma().data(); }
+const double *svih_lambda(const svih_setup *s) { return s->ls->lambda().data(); }
+uint64_t svih_nvalidation(const svih_setup *s) { return s->ls->validation_sorted().size() / 3; }
+const uint32_t *svih_validation_sorted(const svih_setup *s) { return s->ls->validation_sorted().data(); }
+const uint32_t *svih_validation_accept(const svih_setup *s) { return s->ls->validation_accept().data(); }
+uint64_t svih_nlinks(svih_setup *s) { return s->ls->training_links().size() / 2; }
+const uint32_t *svih_links(svih_setup *s) { return s->ls->training_links().data(); }
+const uint32_t *svih_edges(const svih_setup *s) { return &s->net->edges()[0].first; }
+uint32_t svih_deg(const svih_setup *s, uint32_t p) { return s->net->deg(p); }
+
+}  // extern "C"

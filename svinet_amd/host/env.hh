@@ -1,0 +1,95 @@
+// env.hh -- run configuration, output directory and param.txt, for the flags
+// the link-sampling path reads.  Mirrors the reference's Env (src/env.hh):
+// same defaults (ctor init list :305-483), same output-directory naming
+// (:503-568), same param.txt keys (:577-619) and the network.dat symlink.
+#pragma once
+#include <cinttypes>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace svinet {
+
+class Env {
+ public:
+  struct Args {
+    uint32_t n = 0, k = 0;
+    std::string datfname = "network.dat";
+    std::string label = "mmsb";
+    bool batch = false, link_sampling = false;
+    bool load = false;
+    std::string location;
+    bool val_load = false;
+    std::string val_file_location;
+    bool test_load = false;
+    std::string test_file_location;
+    double hol_ratio = 0.01;
+    std::string eta_type = "uniform";
+    uint32_t rfreq = 1;
+    bool accuracy = false;
+    uint32_t max_iterations = 0;
+    bool use_validation_stop = true;
+    double rand_seed = 0;
+    double link_thresh = 0.5;
+    uint32_t lt_min_deg = 0;
+    bool nmi = false;
+    std::string ground_truth_fname;
+    uint32_t nthreads = 0;
+    // extensions of this build (not in the reference)
+    int device = 0;
+    uint32_t sweep_batch = 1;   // sweeps enqueued between host polls
+    std::string outdir_root;    // directory in which the output dir is created ("" = cwd)
+    bool write_files = true;    // false: library use (bench / tests), nothing touches the disk
+  };
+
+  explicit Env(const Args &a);
+  ~Env();
+
+  uint32_t n, k, t;
+  double alpha;
+  double heldout_ratio;
+  double eta0, eta1;
+  const double eta0_dense, eta1_dense, eta0_sparse, eta1_sparse;
+  uint32_t reportfreq;
+  double epsilon;
+  uint32_t max_iterations;
+  double seed;
+  std::string eta_type;
+  bool use_validation_stop;
+  bool accuracy;
+  double link_thresh;
+  uint32_t lt_min_deg;
+  bool model_load;
+  std::string gamma_location;
+  bool load_heldout;
+  std::string load_heldout_fname;
+  bool load_test;
+  std::string load_test_fname;
+  bool nmi;
+  std::string ground_truth_fname;
+  std::string datfname, label;
+  bool batch_mode, link_sampling;
+  volatile int terminate;
+  // set by Network::set_env_variables
+  uint64_t total_pairs;
+  double ones_prob, zeros_prob;
+  // extensions
+  int device;
+  uint32_t sweep_batch;
+  bool write_files;
+
+  static std::string prefix;
+  static std::string file_str(const std::string &fname) { return prefix + fname; }
+  static void plog(const std::string &s, const std::string &v);
+  static void plog(const std::string &s, const char *v) { plog(s, std::string(v)); }
+  static void plog(const std::string &s, double v);
+  static void plog(const std::string &s, bool v);
+  static void plog(const std::string &s, int v);
+  static void plog(const std::string &s, uint32_t v);
+  static void plog(const std::string &s, uint64_t v);
+
+ private:
+  static FILE *plogf_;
+};
+
+}  // namespace svinet

@@ -1,0 +1,433 @@
+#include "linksampling.hh"
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "svils.h"
+
+namespace svinet {
+
+namespace {
+void die_svils(const char *what) {
+  fprintf(stderr, "error: %s: %s\n", what, svils_last_error());
+  exit(-1);
+}
+FILE *open_or_die(const std::string &path, const char *what) {
+  FILE *f = fopen(path.c_str(), "w");
+  if (!f) {
+    printf("cannot open %s file:%s\n", what, strerror(errno));
+    exit(-1);
+  }
+  return f;
+}
+}  // namespace
+
+// LinkSampling::LinkSampling, src/linksampling.cc:5-155
+LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
+    : env_(env), network_(network), n_(env.n), k_(env.k),
+      rng_(env.seed ? (unsigned long)env.seed : 0ul),   // :70-75
+      start_time_(time(0)) {
+  // `_n * (_n - 1) / 2` in 32-bit unsigned arithmetic (:36-37, quirk Q5)
+  total_pairs_ = (double)((uint32_t)(n_ * (n_ - 1u)) / 2u);
+  Env::plog("inference n", n_);
+  Env::plog("total pairs", total_pairs_);
+  ones_prob_ = double(network_.ones()) / total_pairs_;
+  zeros_prob_ = 1 - ones_prob_;
+  Env::plog("ones_prob", ones_prob_);
+  Env::plog("zeros_prob", zeros_prob_);
+  uint32_t maxd;
+  double avgd;
+  network_.deg_stats(maxd, avgd);
+  Env::plog("avg degree", avgd);
+  Env::plog("max degree", maxd);
+  {
+    std::ostringstream sa;  // D2Array::s(), src/matrix.hh:898-923 (row/col limits 512/32)
+    sa << "\n[ ";
+    for (uint32_t i = 0; i < std::min<uint32_t>(k_, 512); ++i) {
+      if (i > 0) sa << "  ";
+      sa << env_.eta0 << " " << env_.eta1 << " " << "\n";
+    }
+    sa << "]";
+    Env::plog("eta", sa.str());
+  }
+
+  FILE *vef = nullptr;
+  if (env_.write_files) {
+    vef = open_or_die(Env::file_str("/validation-edges.txt"), "validation edges");
+    fclose(open_or_die(Env::file_str("/test-edges.txt"), "test edges"));
+  }
+  if (!env_.load_heldout) {
+    Env::plog("load validation from file:", false);
+    init_validation();
+    Env::plog("heldout ratio", env_.heldout_ratio);
+    Env::plog("validation pairs (1s and 0s)", (uint32_t)validation_map_.size());
+  } else {
+    Env::plog("load validation from file:", true);
+    load_validation();
+  }
+  if (vef) {
+    fprintf(vef, "%s\n", edgelist_s(val_accept_).c_str());
+    fclose(vef);
+  }
+  if (env_.load_test) {
+    fprintf(stderr, "error: -load-test is not supported by this build\n");
+    exit(-1);
+  }
+
+  gamma_.assign((size_t)n_ * k_, 0.0);
+  lambda_.assign(2 * (size_t)k_, 0.0);
+  if (env_.model_load) {
+    if (load_model() < 0) exit(-1);
+  } else {
+    init_gamma2();
+    init_lambda();
+  }
+
+  if (env_.write_files) {
+    tf_ = open_or_die(Env::file_str("/test.txt"), "test");
+    vf_ = open_or_die(Env::file_str("/validation.txt"), "validation");
+    fclose(open_or_die(Env::file_str("/logl.txt"), "logl"));
+  }
+  Env::plog("network ones", network_.ones());
+  Env::plog("network singles", network_.singles());
+
+  // std::map<Edge,bool> iteration order for the likelihood loop (:974-992)
+  val_sorted_.reserve(validation_map_.size() * 3);
+  for (const auto &kv : validation_map_) {
+    val_sorted_.push_back(kv.first.first);
+    val_sorted_.push_back(kv.first.second);
+    val_sorted_.push_back(network_.y(kv.first.first, kv.first.second) ? 1u : 0u);
+  }
+
+  if (attach_device) {
+    attach();
+    if (!env_.accuracy && !val_sorted_.empty()) {
+      // constructor-time validation_likelihood (:149-150): row "iter 0"
+      if (svils_validation_row(h_, row0_)) die_svils("svils_validation_row");
+      have_row0_ = true;
+      if (vf_) {
+        write_validation_row(row0_, vf_);
+        write_max(row0_, -1, -2147483647.0);
+      }
+    }
+  }
+  start_time_ = time(0);
+}
+
+LinkSampling::~LinkSampling() {
+  if (h_) svils_destroy(h_);
+  if (vf_) fclose(vf_);
+  if (tf_) fclose(tf_);
+}
+
+void LinkSampling::attach() {
+  svils_config cfg;
+  svils_config_default(&cfg, n_, k_);
+  cfg.ones = network_.ones();
+  cfg.alpha = env_.alpha;
+  cfg.eta0 = env_.eta0;
+  cfg.eta1 = env_.eta1;
+  cfg.epsilon = env_.epsilon;
+  cfg.link_thresh = env_.link_thresh;
+  cfg.lt_min_deg = env_.lt_min_deg;
+  cfg.reportfreq = env_.reportfreq;
+  cfg.use_validation_stop = env_.use_validation_stop ? 1 : 0;
+  cfg.ones_prob = ones_prob_;
+  cfg.zeros_prob = zeros_prob_;
+  cfg.device = env_.device;
+  if (svils_create(&cfg, &h_)) die_svils("svils_create");
+  // with -accuracy validation_likelihood() returns at once (:969-970)
+  if (!env_.accuracy && !val_sorted_.empty())
+    if (svils_set_validation(h_, val_sorted_.data(), val_sorted_.size() / 3)) die_svils("svils_set_validation");
+  if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
+}
+
+// ---------------------------------------------------------------- validation set
+bool LinkSampling::edge_ok(const Edge &e) const {       // src/linksampling.hh:296-326
+  if (e.first == e.second) return false;
+  return validation_map_.find(e) == validation_map_.end();
+}
+
+void LinkSampling::get_random_edge(bool link, Edge &e) {  // src/linksampling.hh:328-349
+  if (!link) {
+    do {
+      uint32_t a = rng_.uniform_int(n_);
+      uint32_t b = rng_.uniform_int(n_);
+      e = a < b ? Edge(a, b) : Edge(b, a);
+    } while (!edge_ok(e));
+  } else {
+    do {
+      e = network_.edges()[rng_.uniform_int(network_.ones())];
+    } while (!edge_ok(e));
+  }
+}
+
+void LinkSampling::accept_pair(const Edge &e, bool y) {
+  val_accept_.push_back(e.first);
+  val_accept_.push_back(e.second);
+  val_accept_.push_back(y ? 1u : 0u);
+  validation_map_[e] = true;
+}
+
+void LinkSampling::set_validation_sample(int s) {         // src/linksampling.cc:281-309
+  int c0 = 0, c1 = 0;
+  const int p = s / 2;
+  while (c0 < p || c1 < p) {
+    Edge e;
+    get_random_edge(c0 == p, e);   // non-links first; a sampled pair that is a link counts as one
+    const bool y = network_.y(e.first, e.second);
+    if (!y && c0 < p) { c0++; accept_pair(e, false); }
+    if (y && c1 < p) { c1++; accept_pair(e, true); }
+  }
+}
+
+void LinkSampling::init_validation() {                    // src/linksampling.cc:164-188
+  const int s1 = env_.heldout_ratio * network_.ones();
+  set_validation_sample(s1);
+}
+
+void LinkSampling::load_validation() {                    // src/linksampling.cc:1382-1414
+  FILE *f = fopen(env_.load_heldout_fname.c_str(), "r");
+  if (!f) {
+    fprintf(stderr, "error: cannot read test validation file %s\n", env_.load_heldout_fname.c_str());
+    exit(-1);
+  }
+  int a, b;
+  uint32_t cnt = 0;
+  while (fscanf(f, "%d %d", &a, &b) == 2) {
+    uint32_t p, q;
+    if (!network_.id2seq((uint32_t)a, &p) || !network_.id2seq((uint32_t)b, &q)) {
+      fprintf(stderr, "error: id %d or id %d not found in original network\n", a, b);
+      exit(-1);
+    }
+    Edge e = p < q ? Edge(p, q) : Edge(q, p);
+    accept_pair(e, network_.y(p, q));
+    ++cnt;
+  }
+  fclose(f);
+  Env::plog("link sampling: loaded validation heldout pairs:", cnt);
+}
+
+std::string LinkSampling::edgelist_s(const std::vector<uint32_t> &t) const {  // :190-206
+  std::ostringstream sa;
+  const std::vector<uint32_t> &s2i = network_.seq2id();
+  for (size_t i = 0; i + 2 < t.size(); i += 3)
+    sa << s2i[t[i]] << "\t" << s2i[t[i + 1]] << "\t" << (int)t[i + 2] << "\n";
+  return sa.str();
+}
+
+// ------------------------------------------------------------------ initialisation
+void LinkSampling::init_gamma2() {                        // src/linksampling.cc:374-401
+  std::vector<double> phi(k_);
+  for (uint32_t p = 0; p < n_; ++p)
+    for (uint32_t q : network_.get_edges(p)) {
+      if (p >= q) continue;   // all links, held-out ones included
+      double s = .0;
+      for (uint32_t k = 0; k < k_; ++k) { phi[k] = rng_.uniform(); }
+      for (uint32_t k = 0; k < k_; ++k) s += phi[k];
+      double *gp = &gamma_[(size_t)p * k_], *gq = &gamma_[(size_t)q * k_];
+      for (uint32_t k = 0; k < k_; ++k) phi[k] = phi[k] / s;
+      for (uint32_t k = 0; k < k_; ++k) gp[k] += phi[k];
+      for (uint32_t k = 0; k < k_; ++k) gq[k] += phi[k];
+    }
+}
+
+int LinkSampling::init_lambda() {                         // src/linksampling.cc:364-372
+  for (uint32_t k = 0; k < k_; ++k) {
+    lambda_[2 * k] = env_.eta0;
+    lambda_[2 * k + 1] = env_.eta1;
+  }
+  return 0;
+}
+
+// gamma.txt: 2 leading columns skipped; lambda.txt: 1 (src/linksampling.cc:1266-1352).
+// The path is gamma_location + "gamma.txt" with no separator added (src/env.hh:277-282).
+int LinkSampling::load_model() {
+  auto parse = [&](const std::string &path, uint32_t skip, uint32_t cols, uint32_t rows,
+                   std::vector<double> &out) -> int {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) { fprintf(stderr, "no %s found\n", path.c_str()); return -1; }
+    std::vector<char> line(32 * (size_t)k_ + 64);
+    uint32_t r = 0;
+    while (fgets(line.data(), (int)line.size(), f)) {
+      if (r >= rows) { r++; break; }
+      char *p = line.data();
+      uint32_t c = 0;
+      for (;;) {
+        char *q = nullptr;
+        double d = strtod(p, &q);
+        if (q == p) break;
+        p = q;
+        if (c >= skip && c - skip < cols) out[(size_t)r * cols + (c - skip)] = d;
+        c++;
+      }
+      if (c < skip + cols) { fprintf(stderr, "error parsing %s\n", path.c_str()); fclose(f); return -1; }
+      r++;
+    }
+    fclose(f);
+    if (r != rows) { fprintf(stderr, "%s: expected %u rows, read %u\n", path.c_str(), rows, r); return -1; }
+    return 0;
+  };
+  if (parse(env_.gamma_location + "gamma.txt", 2, k_, n_, gamma_) < 0) return -1;
+  if (parse(env_.gamma_location + "lambda.txt", 1, 2, k_, lambda_) < 0) return -1;
+  return 0;
+}
+
+// assign_training_links, src/linksampling.cc:493-523.  (p,q) with p<q in
+// (p, adjacency order) order; _training_links[] = 2 * degree is derived by the
+// device library from this list.
+const std::vector<uint32_t> &LinkSampling::training_links() {
+  if (links_done_) return links_;
+  links_.clear();
+  for (uint32_t p = 0; p < n_; ++p)
+    for (uint32_t q : network_.get_edges(p)) {
+      if (p >= q) continue;
+      if (!env_.accuracy && !edge_ok(Edge(p, q))) continue;   // held out
+      links_.push_back(p);
+      links_.push_back(q);
+    }
+  links_done_ = true;
+  return links_;
+}
+
+// ----------------------------------------------------------------------- outputs
+void LinkSampling::write_validation_row(const double *r, FILE *f) const {   // :996-1002
+  fprintf(f, "%d\t%d\t%.9f\t%d\t%.9f\t%d\t%.9f\t%d\t%.9f\t%.9f\t%.9f\n", (int)r[0], duration(), r[1],
+          (int)r[2], r[3], (int)r[4], r[5], (int)r[6], r[7], r[8], r[9]);
+  fflush(f);
+}
+
+void LinkSampling::write_max(const double *r, int why, double max_h) const {   // :1030-1034
+  FILE *f = fopen(Env::file_str("/max.txt").c_str(), "w");
+  if (!f) return;
+  fprintf(f, "%d\t%d\t%.5f\t%.5f\t%.5f\t%d\n", (int)r[0], duration(), r[9], 0.0, max_h, why);
+  fclose(f);
+}
+
+void LinkSampling::save_model() {                          // src/linksampling.cc:804-837
+  std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
+  if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
+  FILE *gf = open_or_die(Env::file_str("/gamma.txt"), "gamma");
+  const std::vector<uint32_t> &s2i = network_.seq2id();
+  for (uint32_t i = 0; i < n_; ++i) {
+    fprintf(gf, "%d\t", i);
+    fprintf(gf, "%d\t", s2i[i]);
+    for (uint32_t k = 0; k < k_; ++k)
+      fprintf(gf, k == k_ - 1 ? "%.5f\n" : "%.5f\t", g[(size_t)i * k_ + k]);
+  }
+  fclose(gf);
+  FILE *lf = open_or_die(Env::file_str("/lambda.txt"), "lambda");
+  for (uint32_t k = 0; k < k_; ++k) fprintf(lf, "%d\t%.5f\t%.5f\n", k, l[2 * k], l[2 * k + 1]);
+  fclose(lf);
+  gamma_.swap(g);
+  lambda_.swap(l);
+}
+
+void LinkSampling::write_groups() {                        // src/linksampling.cc:1452-1476
+  FILE *f = open_or_die(Env::file_str("/groups.txt"), "groups");
+  const std::vector<uint32_t> &s2i = network_.seq2id();
+  for (uint32_t i = 0; i < n_; ++i) {
+    const double *g = &gamma_[(size_t)i * k_];
+    double s = .0;
+    for (uint32_t k = 0; k < k_; ++k) s += g[k];
+    fprintf(f, "%d\t%d\t", i, s2i[i]);
+    for (uint32_t k = 0; k < k_; ++k) fprintf(f, k == k_ - 1 ? "%.3f\n" : "%.3f\t", g[k] / s);
+  }
+  fclose(f);
+}
+
+void LinkSampling::log_communities() {                     // :839-852, :882-917
+  member_.assign((size_t)n_ * k_, 0);
+  if (svils_get_communities(h_, member_.data())) die_svils("svils_get_communities");
+  FILE *f = open_or_die(Env::file_str("/communities.txt"), "communities");
+  const std::vector<uint32_t> &s2i = network_.seq2id();
+  std::vector<uint32_t> ids;
+  for (uint32_t c = 0; c < k_; ++c) {
+    ids.clear();
+    for (uint32_t p = 0; p < n_; ++p)
+      if (member_[(size_t)p * k_ + c]) ids.push_back(s2i[p]);
+    if (ids.empty()) continue;            // empty communities have no map entry => no line
+    std::sort(ids.begin(), ids.end());
+    for (uint32_t id : ids) fprintf(f, "%d ", id);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+}
+
+void LinkSampling::do_on_stop() {                          // src/linksampling.cc:792-802
+  if (!env_.write_files) return;
+  log_communities();
+  save_model();
+  write_groups();
+}
+
+void LinkSampling::fetch_and_log_rows() {
+  svils_control c;
+  if (svils_get_control(h_, &c)) die_svils("svils_get_control");
+  if (c.rows > rows_logged_) {
+    std::vector<double> rows((size_t)(c.rows - rows_logged_) * 10);
+    if (svils_get_rows(h_, rows_logged_, c.rows - rows_logged_, rows.data())) die_svils("svils_get_rows");
+    if (vf_)
+      for (uint32_t i = 0; i < c.rows - rows_logged_; ++i) {
+        write_validation_row(&rows[(size_t)i * 10], vf_);
+        // test_likelihood over the empty test map prints 0/0 ratios (:1147-1182)
+        fprintf(tf_, "%d\t%d\t-nan\t0\t-nan\t0\t-nan\t0\t-nan\t-nan\t-nan\n", (int)rows[(size_t)i * 10], duration());
+        fflush(tf_);
+      }
+    if (vf_) write_max(&rows[(size_t)(c.rows - rows_logged_ - 1) * 10], c.why, c.max_h);
+    rows_logged_ = c.rows;
+  }
+}
+
+// LinkSampling::infer, src/linksampling.cc:556-790.  The loop body lives on
+// the device; the host decides how many sweeps to enqueue, polls the
+// device-resident control block, and writes the per-report files.
+int LinkSampling::infer() {
+  if (!h_) {
+    fprintf(stderr, "error: LinkSampling::infer() without a device (attach_device=false)\n");
+    exit(-1);
+  }
+  if (!graph_sent_) {
+    const std::vector<uint32_t> &L = training_links();
+    if (svils_set_graph(h_, L.data(), L.size() / 2)) die_svils("svils_set_graph");
+    graph_sent_ = true;
+  }
+  const uint64_t nlinks = links_.size() / 2;
+  svils_control c;
+  if (svils_get_control(h_, &c)) die_svils("svils_get_control");
+  for (;;) {
+    if (env_.max_iterations && c.iter > env_.max_iterations) {     // :573-579
+      printf("+ Quitting: reached max iterations.\n");
+      Env::plog("maxiterations reached", true);
+      env_.terminate = 1;
+      do_on_stop();
+      return 0;
+    }
+    if (env_.max_iterations == 1 && !c.write_comm) {              // :581-582
+      c.write_comm = 1;
+      if (svils_set_control(h_, &c)) die_svils("svils_set_control");
+    }
+    uint32_t batch = env_.sweep_batch;
+    if (env_.max_iterations) batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - c.iter);
+    printf("\riteration %d: processing %d links", c.iter, (int)nlinks);
+    fflush(stdout);
+    if (svils_sweep(h_, batch)) die_svils("svils_sweep");
+    fetch_and_log_rows();
+    if (svils_get_control(h_, &c)) die_svils("svils_get_control");
+    if (env_.write_files && !c.stopped) log_communities();        // :785
+    if (c.stopped) {                                              // :1044-1048
+      do_on_stop();
+      return 1;
+    }
+    if (env_.terminate) {                                         // :763-766 (SIGTERM)
+      do_on_stop();
+      env_.terminate = 0;
+    }
+  }
+}
+
+}  // namespace svinet

@@ -1,0 +1,93 @@
+// linksampling.hh -- host side of the `-link-sampling` engine.
+//
+// Same seam as the reference (src/linksampling.hh:21-31, used at
+// src/main.cc:337-342):
+//     LinkSampling ls(env, network);   ls.infer();
+// The constructor does what the reference's does on the host (held-out
+// sampling, gamma/lambda initialisation, output files, constructor-time
+// likelihood row); infer() drives the device-resident sweep through the C ABI
+// of include/svils.h and writes the reference's output files.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <ctime>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "env.hh"
+#include "network.hh"
+#include "rng.hh"
+
+struct svils_handle;
+
+namespace svinet {
+
+class LinkSampling {
+ public:
+  // attach_device = false builds the host-side state only (no HIP device is
+  // touched): used by the CPU test-suite and by callers that drive the C ABI
+  // themselves (bench.py).
+  LinkSampling(Env &env, Network &network, bool attach_device = true);
+  ~LinkSampling();
+
+  // Runs until the reference would call exit(0): returns 0 when
+  // -max-iterations was reached, 1 when the validation stop rule fired.
+  int infer();
+  void save_model();
+  void do_on_stop();
+
+  // ---- host-side state (flat row-major) ----
+  uint32_t n() const { return n_; }
+  uint32_t k() const { return k_; }
+  const std::vector<double> &gamma() const { return gamma_; }
+  const std::vector<double> &lambda() const { return lambda_; }
+  const std::vector<uint32_t> &validation_accept() const { return val_accept_; }   // [V][3]
+  const std::vector<uint32_t> &validation_sorted() const { return val_sorted_; }   // [V][3]
+  // assign_training_links (src/linksampling.cc:493-523); idempotent
+  const std::vector<uint32_t> &training_links();                                   // [L][2]
+  double total_pairs() const { return total_pairs_; }
+  double ones_prob() const { return ones_prob_; }
+  double zeros_prob() const { return zeros_prob_; }
+  const double *row0() const { return have_row0_ ? row0_ : nullptr; }
+
+ private:
+  void init_validation();
+  void load_validation();
+  void set_validation_sample(int s);
+  void get_random_edge(bool link, Edge &e);
+  bool edge_ok(const Edge &e) const;
+  void accept_pair(const Edge &e, bool y);
+  std::string edgelist_s(const std::vector<uint32_t> &triples) const;
+  void init_gamma2();
+  int init_lambda();
+  int load_model();
+  void attach();
+  void write_validation_row(const double *row, FILE *f) const;
+  void write_max(const double *row, int why, double max_h) const;
+  void log_communities();
+  void write_groups();
+  uint32_t duration() const { return (uint32_t)(time(0) - start_time_); }
+  void fetch_and_log_rows();
+
+  Env &env_;
+  Network &network_;
+  uint32_t n_, k_;
+  double total_pairs_, ones_prob_, zeros_prob_;
+  GslMt19937 rng_;
+  std::map<Edge, bool> validation_map_;        // std::map: the likelihood loop runs in key order
+  std::vector<uint32_t> val_accept_, val_sorted_;
+  std::vector<double> gamma_, lambda_;
+  std::vector<uint32_t> links_;
+  bool links_done_ = false;
+  std::vector<uint8_t> member_;                // last downloaded communities [n][k]
+  svils_handle *h_ = nullptr;
+  bool graph_sent_ = false;
+  uint32_t rows_logged_ = 0;
+  double row0_[10];
+  bool have_row0_ = false;
+  time_t start_time_;
+  FILE *vf_ = nullptr, *tf_ = nullptr;
+};
+
+}  // namespace svinet

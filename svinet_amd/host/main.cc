@@ -1,0 +1,137 @@
+// svinet -- command line of the MI355X link-sampling build.
+//
+// Accepts the reference's flag set (src/main.cc:114-242, same spelling, same
+// positional/order-sensitive semantics: e.g. -link-sampling resets rfreq to 1,
+// so -rfreq must follow it).  Only the -link-sampling engine is provided; the
+// flags that select the reference's other engines are recognised and rejected
+// with a message instead of being silently ignored.
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "env.hh"
+#include "linksampling.hh"
+#include "network.hh"
+
+using namespace svinet;
+
+static Env *env_global = nullptr;
+
+static void term_handler(int sig) {   // src/main.cc:29-40
+  if (env_global) {
+    printf("\nGot signal. Saving model and groups.\n");
+    fflush(stdout);
+    env_global->terminate = 1;
+  } else {
+    signal(sig, SIG_DFL);
+    raise(sig);
+  }
+}
+
+static void usage() {
+  fprintf(stdout,
+          "\nSVINET (MI355X link-sampling build): stochastic variational inference of undirected networks\n"
+          "svinet [OPTIONS]\n"
+          "\t-help\t\tusage\n\n"
+          "\t-file <name>\tinput tab-separated file with a list of undirected links\n\n"
+          "\t-n <N>\t\tnumber of nodes in network\n\n"
+          "\t-k <K>\t\tnumber of communities\n\n"
+          "\t-link-sampling\tinference using link sampling (the engine this build provides)\n\n"
+          "\t-load-validation <fname>\tuse the pairs in the file as the validation set for convergence\n\n"
+          "\t-load <dir>\tresume from <dir>gamma.txt / <dir>lambda.txt\n\n"
+          "\t-label\t\ttag output directory\n\n"
+          "\t-rfreq\t\tset the frequency at which convergence is estimated (give it after -link-sampling)\n\n"
+          "\t-max-iterations\tmaximum number of iterations (use with -no-stop to avoid stopping earlier)\n\n"
+          "\t-no-stop\tdisable stopping criteria\n\n"
+          "\t-seed\t\tset random generator seed\n\n"
+          "\t-heldout-ratio, -link-thresh, -lt-min-deg, -eta-type, -accuracy\tas in the reference\n\n"
+          "\t-device <d>\tHIP device ordinal (default 0)\n\n"
+          "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n");
+  fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+  signal(SIGTERM, term_handler);
+  Env::Args a;
+  bool unsupported = false;
+  std::string unsupported_flag;
+  if (argc == 1) {
+    usage();
+    exit(-1);
+  }
+  auto need = [&](int i) {
+    if (i + 1 > argc - 1) {
+      fprintf(stderr, "+ insufficient arguments!\n");
+      exit(-1);
+    }
+  };
+  for (int i = 1; i <= argc - 1; ++i) {
+    const char *f = argv[i];
+    auto is = [&](const char *s) { return strcmp(f, s) == 0; };
+    if (is("-help")) { usage(); exit(0); }
+    else if (is("-force") || is("-online") || is("-nodelay")) {}
+    else if (is("-file")) { need(i); a.datfname = argv[++i]; }
+    else if (is("-batch")) { a.batch = true; a.link_sampling = false; a.rfreq = 1; }
+    else if (is("-link-sampling")) { a.link_sampling = true; a.batch = false; a.rfreq = 1; }
+    else if (is("-load")) { need(i); a.load = true; a.location = argv[++i]; }
+    else if (is("-load-validation")) { need(i); a.val_load = true; a.val_file_location = argv[++i]; }
+    else if (is("-load-test")) { need(i); a.test_load = true; a.test_file_location = argv[++i]; }
+    else if (is("-n")) { need(i); a.n = atoi(argv[++i]); }
+    else if (is("-k")) { need(i); a.k = atoi(argv[++i]); }
+    else if (is("-label")) { need(i); a.label = argv[++i]; }
+    else if (is("-nthreads")) { need(i); a.nthreads = atoi(argv[++i]); }
+    else if (is("-eta-type")) { need(i); a.eta_type = argv[++i]; }
+    else if (is("-nmi")) { need(i); a.ground_truth_fname = argv[++i]; a.nmi = true; }
+    else if (is("-rfreq")) { need(i); a.rfreq = atoi(argv[++i]); }
+    else if (is("-accuracy")) { a.accuracy = true; }
+    else if (is("-max-iterations")) { need(i); a.max_iterations = atoi(argv[++i]); }
+    else if (is("-no-stop")) { a.use_validation_stop = false; }
+    else if (is("-seed")) { need(i); a.rand_seed = atof(argv[++i]); }
+    else if (is("-heldout-ratio")) { need(i); a.hol_ratio = atof(argv[++i]); }
+    else if (is("-link-thresh")) { need(i); a.link_thresh = atof(argv[++i]); }
+    else if (is("-lt-min-deg")) { need(i); a.lt_min_deg = atof(argv[++i]); }
+    else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
+    else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
+    else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
+    else if (is("-stopthresh") || is("-inf") || is("-scale") || is("-itype") || is("-groups-file") ||
+             is("-init-communities")) {
+      need(i); ++i;   // value flags of other engines: consumed, no effect on this path
+      if (is("-init-communities")) { unsupported = true; unsupported_flag = f; }
+    }
+    else if (is("-gen") || is("-ppc") || is("-lcstats") || is("-gml") || is("-findk") || is("-stratified") ||
+             is("-rnode") || is("-rpair") || is("-orig") || is("-infset") || is("-single") ||
+             is("-preprocess") || is("-gp") || is("-adamic-adar") || is("-disjoint") || is("-strid") ||
+             is("-load-test-sets")) {
+      unsupported = true;
+      unsupported_flag = f;
+    }
+    // unknown flags are ignored, as in the reference
+  }
+  if (unsupported || a.batch || !a.link_sampling) {
+    fprintf(stderr,
+            "svinet (MI355X build): only the -link-sampling engine is implemented here%s%s.\n"
+            "Use the reference build for the other engines.\n",
+            unsupported ? "; unsupported option " : "", unsupported ? unsupported_flag.c_str() : "");
+    return 2;
+  }
+  if (a.n == 0 || a.k == 0) {
+    fprintf(stderr, "error: -n and -k are required\n");
+    return -1;
+  }
+  if (a.nmi) fprintf(stderr, "warning: -nmi needs the external /usr/local/bin/mutual tool; ignored\n");
+  a.nmi = false;
+
+  Env env(a);
+  env_global = &env;
+  Network network(env);
+  if (network.read(a.datfname) < 0) {
+    fprintf(stderr, "error reading %s; quitting\n", a.datfname.c_str());
+    return -1;
+  }
+  env.n = network.n() - network.singles();   // src/main.cc:291
+  LinkSampling ls(env, network);
+  ls.infer();
+  exit(0);
+}

@@ -1,0 +1,119 @@
+#include "network.hh"
+
+#include <cstdio>
+
+#include "env.hh"
+
+namespace svinet {
+
+Network::Network(Env &env) : env_(env), declared_n_(env.n), adj_(env.n) {
+  id2seq_.reserve(env.n * 2 + 16);
+}
+
+bool Network::id2seq(uint32_t id, uint32_t *seq) const {
+  auto it = id2seq_.find(id);
+  if (it == id2seq_.end()) return false;
+  *seq = it->second;
+  return true;
+}
+
+// Network::add (src/network.hh:134-148): refuse new ids once n are known
+bool Network::intern(uint32_t id, uint32_t *seq) {
+  auto it = id2seq_.find(id);
+  if (it != id2seq_.end()) { *seq = it->second; return true; }
+  if (seq2id_.size() >= declared_n_) return false;
+  *seq = (uint32_t)seq2id_.size();
+  id2seq_.emplace(id, *seq);
+  seq2id_.push_back(id);
+  return true;
+}
+
+static inline uint64_t pair_key(uint32_t a, uint32_t b) {
+  return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+}
+
+bool Network::y(uint32_t a, uint32_t b) const { return pair_set_.count(pair_key(a, b)) != 0; }
+
+bool Network::add_line(uint32_t id1, uint32_t id2) {
+  uint32_t p, q;
+  if (!intern(id1, &p)) return false;   // note: id1 stays interned even if id2 is refused
+  if (!intern(id2, &q)) return false;
+  if (p == q) return false;
+  if (!pair_set_.insert(pair_key(p, q)).second) return false;  // both directions listed / duplicates
+  edges_.push_back(p < q ? Edge(p, q) : Edge(q, p));
+  adj_[p].push_back(q);
+  adj_[q].push_back(p);
+  return true;
+}
+
+int Network::read(const std::string &path) {
+  const bool chat = env_.write_files;
+  if (chat) fprintf(stdout, "+ Reading network from %s\n", path.c_str());
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int a, b;
+  // the reference's format string is "%d\t%d\n": any white space separates
+  // fields, so CRLF files (example/assort-75-4.txt) parse as well
+  while (fscanf(f, "%d %d", &a, &b) == 2) {
+    if (add_line((uint32_t)a, (uint32_t)b) && chat && ones() % 10000 == 0) {
+      printf("\r+ %d entries", ones());
+      fflush(stdout);
+    }
+  }
+  fclose(f);
+  if (chat && singles())
+    printf("n = %d, curr_seq = %d\n+ Creating ids for %d single nodes\n", declared_n_, nodes_seen(), singles());
+  if (chat) fprintf(stdout, "\n+ Done reading network\n");
+  fflush(stdout);
+  set_env_variables();
+  return 0;
+}
+
+void Network::read_pairs(const int32_t *pairs, uint64_t nlines) {
+  for (uint64_t i = 0; i < nlines; ++i) add_line((uint32_t)pairs[2 * i], (uint32_t)pairs[2 * i + 1]);
+  set_env_variables();
+}
+
+void Network::deg_stats(uint32_t &max, double &avg) const {
+  max = 0;
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < declared_n_; ++i) {
+    if (deg(i) > max) max = deg(i);
+    s += deg(i);
+  }
+  avg = (double)s / declared_n_;
+}
+
+void Network::set_env_variables() {
+  // `_env.n * (_env.n - 1) / 2` is evaluated in 32-bit unsigned arithmetic in
+  // the reference and wraps for n >= 65537; kept for parity.
+  const uint32_t n = env_.n;
+  env_.total_pairs = (uint32_t)(n * (n - 1u)) / 2u;
+  if ((uint64_t)n * (n - 1) / 2 != env_.total_pairs)
+    fprintf(stderr, "warning: n(n-1)/2 wraps in 32 bits (%u nodes): total_pairs=%llu as in the reference\n",
+            n, (unsigned long long)env_.total_pairs);
+  Env::plog("total pairs", env_.total_pairs);
+  env_.ones_prob = (double)ones() / env_.total_pairs;
+  env_.zeros_prob = 1 - env_.ones_prob;
+  Env::plog("ones_prob", env_.ones_prob);
+  Env::plog("zeros_prob", env_.zeros_prob);
+  if (env_.eta_type == "fromdata") {
+    env_.eta0 = env_.total_pairs * env_.ones_prob / env_.k;
+    env_.eta1 = env_.total_pairs * 1.0 / (env_.k * env_.k) - env_.eta0;
+    if (env_.eta1 <= 0) env_.eta1 = 1.0;
+  } else if (env_.eta_type == "uniform") {
+    env_.eta0 = 1;
+    env_.eta1 = 1;
+  } else if (env_.eta_type == "sparse") {
+    env_.eta0 = env_.eta0_sparse;
+    env_.eta1 = env_.eta1_sparse;
+  } else if (env_.eta_type == "dense") {
+    env_.eta0 = env_.eta0_dense;
+    env_.eta1 = env_.eta1_dense;
+  } else {
+    fprintf(stderr, "unknown eta_type %s\n", env_.eta_type.c_str());
+    exit(-1);
+  }
+}
+
+}  // namespace svinet

@@ -1,0 +1,142 @@
+"""Node-block sharding of the link-sampling sweep over the GPUs of one node.
+
+One process per GPU.  Rank r owns the node block [r*B, (r+1)*B), B = ceil(n/G):
+it evaluates phi for its nodes' CSR rows (pull-style: every link is evaluated
+once per endpoint, so no floating-point scatter crosses GPUs) and finalises
+its rows.  The reference has no distributed path; the exchange below is the
+multi-GPU form of the sums inside LinkSampling::infer()
+(src/linksampling.cc:605-761):
+
+  phase A  phi pass over owned rows      -> all-reduce(SUM)  `sum[k]`           (K doubles)
+  phase B  mean indicators, new gamma,   -> all-gather by node block of gamma,
+           Elogpi, prune over owned rows    Elogpi, mphi rows + converged / active flags
+  phase C  s3 pass over owned upper rows -> all-reduce(SUM)  s1,s2,s3          (3K doubles)
+  phase D  lambda, likelihood, stop rule    (replicated, identical on every rank)
+
+The collectives are `torch.distributed` calls (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" for the CPU protocol tests) on tensors that alias the
+engine's device buffers, issued on the engine's own HIP stream.
+"""
+import numpy as np
+
+from . import _svils
+
+
+def block_size(n, world):
+    return (n + world - 1) // world
+
+
+def node_block(n, world, rank):
+    b = block_size(n, world)
+    return min(rank * b, n), min((rank + 1) * b, n)
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of a raw device pointer (no ownership)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _as_tensor(torch, ptr, nbytes, dtype_str, device):
+    itemsize = {"<f8": 8, "<u4": 4, "<u8": 8, "<i4": 4, "<i8": 8}[dtype_str]
+    arr = _DevArray(ptr, (nbytes // itemsize,), dtype_str)
+    return torch.as_tensor(arr, device=device)
+
+
+class HipShard:
+    """Adapter: an svils Engine restricted to this rank's node block, plus torch
+    tensors aliasing its exchange buffers."""
+
+    def __init__(self, setup, rank, world, device_index, **engine_kw):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank, world
+        n = setup.n
+        self.B = block_size(n, world)
+        self.n_alloc = self.B * world
+        self.engine = setup.engine(device=device_index, node_block=node_block(n, world, rank),
+                                   n_alloc=self.n_alloc, **engine_kw)
+        dev = torch.device("cuda", device_index)
+        self.stream = torch.cuda.ExternalStream(self.engine.stream(), device=dev)
+        e = self.engine
+
+        def t(which, ts):
+            p, nb, rb = e.device_buffer(which)
+            return _as_tensor(torch, p, nb, ts, dev), rb
+
+        self.kvec_a, _ = t(_svils.BUF_KVEC_A, "<f8")
+        self.kvec_c, _ = t(_svils.BUF_KVEC_C, "<f8")
+        self.rows = []
+        for which in (_svils.BUF_GAMMA, _svils.BUF_ELOGPI, _svils.BUF_MPHI):
+            ten, rb = t(which, "<f8")
+            self.rows.append(ten.view(self.n_alloc, rb // 8))
+        conv, _ = t(_svils.BUF_CONV, "<i4")
+        self.conv = conv.view(2, self.n_alloc)
+        act, _ = t(_svils.BUF_ACTIVE, "<i4")
+        self.active = act.view(self.n_alloc, 1)
+        am, rb = t(_svils.BUF_AMASK, "<i8")
+        self.amask = am.view(self.n_alloc, rb // 8)
+        mem, rb = t(_svils.BUF_MEMBER, "<i8")
+        self.member = mem.view(self.n_alloc, rb // 8)
+        self.sweeps = 0
+
+    def phase(self, ph):
+        self.engine.sweep_phase(ph)
+
+    def gather_list(self):
+        # prune() writes conv[parity ^ 1]; parity flips once per sweep (k_tail)
+        new = (self.sweeps & 1) ^ 1
+        return self.rows + [self.conv[new].view(self.n_alloc, 1), self.active, self.amask]
+
+    def end_sweep(self):
+        self.sweeps += 1
+
+
+class ShardedSweep:
+    """Runs sweeps over `shard` (HipShard or a test double with the same
+    surface), doing the exchanges with `dist` (torch.distributed)."""
+
+    def __init__(self, shard, dist, group=None):
+        self.s, self.dist, self.group = shard, dist, group
+        self.world = shard.world
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def _allgather_rows(self, t):
+        if self.world > 1:
+            B, r = self.s.B, self.s.rank
+            mine = t[r * B:(r + 1) * B]
+            if t.is_cuda:
+                self.dist.all_gather_into_tensor(t, mine, group=self.group)   # in place
+            else:
+                self.dist.all_gather_into_tensor(t, mine.clone(), group=self.group)
+
+    def _ctx(self):
+        st = getattr(self.s, "stream", None)
+        if st is None:
+            import contextlib
+            return contextlib.nullcontext()
+        return self.s.torch.cuda.stream(st)
+
+    def sweep(self, nsweeps=1):
+        s = self.s
+        with self._ctx():
+            for _ in range(nsweeps):
+                s.phase(_svils.PHASE_A)
+                self._allreduce(s.kvec_a)
+                s.phase(_svils.PHASE_B)
+                for t in s.gather_list():
+                    self._allgather_rows(t)
+                s.phase(_svils.PHASE_C)
+                self._allreduce(s.kvec_c)
+                s.phase(_svils.PHASE_D)
+                s.end_sweep()
+
+    def gather_communities(self):
+        with self._ctx():
+            self._allgather_rows(self.s.member)
