@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
       }
       ctrl->prev_h = a;
       if (ctrl->annealing && stop) {
-        ctrl->annealing = 0; ctrl->nh = 0; ctrl->prev_h = 0; why = 0;
+        ctrl->annealing = 0; ctrl->nh = 0; ctrl->prev_h = 0;  // max.txt keeps the pre-switch `why`
       } else if (!ctrl->annealing && stop) {
         if (prm.use_validation_stop) exit_now = true;
       }

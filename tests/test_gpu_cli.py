@@ -1,0 +1,77 @@
+"""-m gpu: the `svinet` command line end to end against the oracle's writers
+(gamma.txt / lambda.txt / communities.txt / groups.txt / validation.txt formats of
+src/linksampling.cc:804-917,996-1001,1452-1476)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+SVINET = os.path.join(ROOT, "svinet_amd", "bin", "svinet")
+
+
+def _run(args, cwd):
+    return subprocess.run([SVINET] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+
+
+def _cmp_numeric(path_a, path_b, skip, atol):
+    a, b = np.loadtxt(path_a), np.loadtxt(path_b)
+    assert a.shape == b.shape
+    assert np.array_equal(a[:, :skip], b[:, :skip])
+    np.testing.assert_allclose(a[:, skip:], b[:, skip:], rtol=1e-5, atol=atol)
+
+
+@pytest.mark.parametrize("batch", [1, 7])
+def test_cli_max_iterations(graph_files, tmp_path, batch):
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop",
+              "-max-iterations", "20", "-sweep-batch", str(batch)], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert "+ Quitting: reached max iterations." in r.stdout
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False, max_iterations=20)
+    n = 0
+    while ref.sweep() == 0:
+        n += 1
+    assert n == 21                                   # quirk Q8: N+1 sweeps
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    _cmp_numeric(d / "groups.txt", rd / "groups.txt", 2, 1.1e-3)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    # validation.txt: ctor row + one row per sweep; columns other than duration equal the oracle's
+    v = np.loadtxt(d / "validation.txt")
+    assert v.shape == (22, 11)
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+    assert (d / "validation-edges.txt").read_bytes() == open(os.path.join(GOLDEN, "ref_lfr_k28", "heldout-edges.txt"), "rb").read()
+    t = (d / "test.txt").read_text().split("\n")
+    assert len([l for l in t if l]) == 21 and "-nan" in t[0]
+    mx = (d / "max.txt").read_text().split("\t")
+    assert mx[0] == "20" and len(mx) == 6
+
+
+def test_cli_validation_stop_and_resume(graph_files, tmp_path):
+    r = _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n75-k4-mmsb-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4)
+    while ref.sweep() != 2:
+        assert ref.iter < 2000
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    v = np.loadtxt(d / "validation.txt")
+    assert int(v[-1, 0]) == ref.iter
+    # -load: resume from the saved model (path is dir + "gamma.txt", no separator added)
+    r2 = _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling", "-label", "resumed",
+               "-load", str(d) + "/", "-no-stop", "-max-iterations", "2"], str(tmp_path))
+    assert r2.returncode == 0, r2.stderr
+    g0 = np.loadtxt(d / "gamma.txt")
+    g1 = np.loadtxt(tmp_path / "n75-k4-resumed-linksampling" / "gamma.txt")
+    assert g0.shape == g1.shape and np.isfinite(g1).all()

@@ -1,0 +1,109 @@
+"""-m gpu: the HIP engine in node-block mode.  Two (three) virtual ranks share the
+one GPU of the test box; the exchanges of svinet_amd/sharded.py are done
+in-process on the torch tensors that alias the engines' device buffers.  The
+result must equal the oracle (and hence the single-engine run)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _exchange_sum(ts):
+    tot = ts[0].clone()
+    for t in ts[1:]:
+        tot += t
+    for t in ts:
+        t.copy_(tot)
+
+
+@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 70), (3, 28, 12), (2, 100, 5)])
+def test_virtual_ranks_equal_oracle(graph_files, world, k, sweeps):
+    import torch
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    from svinet_amd.sharded import HipShard
+
+    path, n = graph_files["lfr"], 1000
+    setup = Setup(path, n, k)
+    shards = [HipShard(setup, r, world, 0, use_validation_stop=False) for r in range(world)]
+    B = shards[0].B
+
+    def sync():
+        for s in shards:
+            s.engine.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(sweeps):
+        for s in shards:
+            s.phase(_svils.PHASE_A)
+        sync()
+        _exchange_sum([s.kvec_a for s in shards])
+        sync()
+        for s in shards:
+            s.phase(_svils.PHASE_B)
+        sync()
+        lists = [s.gather_list() for s in shards]
+        for i in range(len(lists[0])):
+            for dst in range(world):
+                for src in range(world):
+                    if src != dst:
+                        lists[dst][i][src * B:(src + 1) * B].copy_(lists[src][i][src * B:(src + 1) * B])
+        sync()
+        for s in shards:
+            s.phase(_svils.PHASE_C)
+        sync()
+        _exchange_sum([s.kvec_c for s in shards])
+        sync()
+        for s in shards:
+            s.phase(_svils.PHASE_D)
+            s.end_sweep()
+    sync()
+
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    states = [s.engine.state() for s in shards]
+    for g, lam, conv in states:
+        assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-5
+        assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-5
+        assert np.array_equal(conv, ref.converged)
+    # replicated state is bit-identical across ranks
+    for g, lam, conv in states[1:]:
+        assert np.array_equal(g, states[0][0]) and np.array_equal(lam, states[0][1])
+    c = shards[0].engine.control()
+    assert c.iter == ref.iter and bool(c.annealing) == ref.annealing
+    # communities: each rank tagged its own rows
+    want = ref.communities()
+    for r, s in enumerate(shards):
+        lo, hi = r * B, min((r + 1) * B, n)
+        assert np.array_equal(s.engine.communities()[lo:hi], want[lo:hi])
+
+
+def test_sharded_driver_world1(graph_files):
+    """ShardedSweep over a real process group of size 1 (nccl == RCCL) equals the plain engine."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from svinet_amd.host_api import Setup
+    from svinet_amd.sharded import HipShard, ShardedSweep
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        setup = Setup(graph_files["lfr"], 1000, 28)
+        shard = HipShard(setup, 0, 1, 0, use_validation_stop=False)
+        ShardedSweep(shard, dist).sweep(10)
+        plain = setup.engine(use_validation_stop=False)
+        plain.sweep(10)
+        a, b = shard.engine.state(), plain.state()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        # the aliasing tensors really see the device buffers
+        shard.engine.synchronize()
+        torch.cuda.synchronize()
+        assert np.allclose(shard.rows[0][:1000, :28].cpu().numpy(), a[0], rtol=0, atol=0)
+    finally:
+        dist.destroy_process_group()

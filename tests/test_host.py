@@ -1,0 +1,105 @@
+"""Product host side (C++: Network / Env / LinkSampling ctor / CLI) on CPU:
+against the reference's shipped goldens and against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from svinet_amd.host_api import Setup
+from conftest import GOLDEN, ROOT
+
+SVINET = os.path.join(ROOT, "svinet_amd", "bin", "svinet")
+
+
+@pytest.mark.parametrize("key,n,k,hr", [("lfr", 1000, 28, 0.01), ("assort", 75, 4, 0.01),
+                                        ("astroph", 17903, 20, 0.02), ("astroph", 17903, 20, 0.01)])
+def test_setup_equals_oracle(graph_files, key, n, k, hr):
+    s = Setup(graph_files[key], n, k, heldout_ratio=hr)
+    net = O.Network(graph_files[key], n)
+    ref = O.LinkSampling(net, k, heldout_ratio=hr)
+    assert (s.n, s.ones, s.nlinks) == (net.n, net.ones, ref.nlinks)
+    assert np.array_equal(s.edges, net.edges())
+    assert np.array_equal(s.seq2id, net.seq2id())
+    assert np.array_equal(s.validation_accept, ref.validation_accept)
+    assert np.array_equal(s.validation_sorted, ref.validation_sorted)
+    assert np.array_equal(s.links, ref.links)
+    assert np.array_equal(s.gamma, ref.gamma)          # bit-identical init_gamma2
+    assert np.array_equal(s.lam, ref.lam)
+    assert s.ones_prob == ref.ones_prob and s.total_pairs == ref.total_pairs
+
+
+def test_setup_matches_reference_goldens(graph_files):
+    s = Setup(graph_files["astroph"], 17903, 20, heldout_ratio=0.02)
+    gold = np.loadtxt(os.path.join(GOLDEN, "ref_astroph_k20", "heldout-edges.txt"), dtype=np.int64)
+    va = s.validation_accept
+    mine = np.stack([s.seq2id[va[:, 0]], s.seq2id[va[:, 1]], va[:, 2]], 1)
+    assert np.array_equal(mine, gold)
+
+
+@pytest.mark.parametrize("eta_type", ["uniform", "fromdata", "sparse", "dense"])
+def test_eta_types(graph_files, eta_type):
+    s = Setup(graph_files["assort"], 75, 4, eta_type=eta_type)
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4, eta_type=eta_type)
+    assert s.eta == ref.eta
+
+
+def test_seed_changes_the_stream(graph_files):
+    a = Setup(graph_files["assort"], 75, 4, seed=7)
+    b = Setup(graph_files["assort"], 75, 4)
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4, seed=7)
+    assert np.array_equal(a.gamma, ref.gamma) and not np.array_equal(a.gamma, b.gamma)
+
+
+def test_in_memory_pairs_and_singletons():
+    pairs = np.array([[10, 11], [11, 12], [12, 10], [12, 13], [13, 10], [11, 13], [20, 21], [21, 22], [22, 20], [13, 20]], np.int32)
+    s = Setup(n=9, k=3, pairs=pairs, heldout_ratio=0.0)     # declared n larger than the graph
+    assert s.n == 7 and s.singles == 2 and s.ones == 10 and s.nlinks == 10
+    assert s.validation_sorted.shape == (0, 3)
+    ref = O.LinkSampling(O.Network(n=9, pairs=pairs), 3, heldout_ratio=0.0)
+    assert np.array_equal(s.gamma, ref.gamma) and np.array_equal(s.links, ref.links)
+
+
+def _run(args, cwd):
+    return subprocess.run([SVINET] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_cli_usage_and_rejections(tmp_path):
+    assert _run([], str(tmp_path)).returncode != 0
+    r = _run(["-help"], str(tmp_path))
+    assert r.returncode == 0 and "-link-sampling" in r.stdout
+    r = _run(["-file", "x", "-n", "10", "-k", "2", "-batch"], str(tmp_path))
+    assert r.returncode == 2 and "only the -link-sampling engine" in r.stderr
+    r = _run(["-file", "x", "-n", "10", "-k", "2", "-link-sampling", "-rnode"], str(tmp_path))
+    assert r.returncode == 2 and "-rnode" in r.stderr
+    r = _run(["-file", "/nonexistent", "-n", "10", "-k", "2", "-link-sampling"], str(tmp_path))
+    assert r.returncode != 0 and "error reading" in r.stderr
+
+
+def test_cli_host_outputs_and_loud_failure_without_gpu(graph_files, tmp_path):
+    """On a CPU-only box the CLI must do the reference's host-side setup (output
+    dir, param.txt, validation-edges.txt identical to the shipped golden) and then
+    fail loudly when it reaches the device -- never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_cli.py")
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-seed", "0"], str(tmp_path))
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    assert d.is_dir()
+    gold = open(os.path.join(GOLDEN, "ref_lfr_k28", "heldout-edges.txt"), "rb").read()
+    assert (d / "validation-edges.txt").read_bytes() == gold
+    params = dict(l.split(": ", 1) for l in (d / "param.txt").read_text().split("\n") if ": " in l)
+    assert params["nodes"] == "1000" and params["groups"] == "28" and params["alpha"] == "0.035714286"
+    assert params["total pairs"] == "499500.000000000" or params["total pairs"] == "499500"
+    assert params["ones_prob"] == "0.059801802" and params["heldout_ratio"] == "0.010000000"
+    assert params["validation pairs (1s and 0s)"] == "298" and params["network ones"] == "29871"
+    assert os.path.islink(str(d / "network.dat"))
+    for f in ("infer.log", "test-edges.txt", "logl.txt", "validation.txt", "test.txt"):
+        assert (d / f).exists()
+
+
+def test_output_dir_naming(graph_files, tmp_path):
+    _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling", "-label", "run1", "-seed", "3"], str(tmp_path))
+    assert (tmp_path / "n75-k4-run1-seed3-linksampling").is_dir()

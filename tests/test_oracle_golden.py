@@ -1,0 +1,152 @@
+"""The oracle against the reference's own golden data and
+against reference-run values recorded in SURVEY.md.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import GOLDEN
+
+
+def test_mt19937_known_answers():
+    # Matsumoto-Nishimura reference: the 10000th output of mt19937 seeded with 5489
+    r = O.Rng(5489)
+    for _ in range(9999):
+        r.get()
+    assert r.get() == 4123659995
+    # GSL maps seed 0 to 4357: first outputs of std::mt19937(4357)
+    r0, r1 = O.Rng(0), O.Rng(4357)
+    assert [r0.get() for _ in range(5)] == [r1.get() for _ in range(5)]
+
+
+def test_uniform_int_and_uniform_mapping():
+    r, s = O.Rng(4357), O.Rng(4357)
+    for n in (2, 7, 1000, 17903, 196972):
+        raw = s.get()
+        scale = 0xFFFFFFFF // n
+        while raw // scale >= n:
+            raw = s.get()
+        assert r.uniform_int(n) == raw // scale
+    assert r.uniform() == s.get() / 4294967296.0
+
+
+def test_digamma_matches_scipy():
+    sp = pytest.importorskip("scipy.special")
+    xs = np.concatenate([np.logspace(-6, 4, 400), np.array([0.05, 1 / 28, 1 / 512, 1.0, 1.4616321449683623, 9.999, 10.0])])
+    got = np.array([O.digamma(x) for x in xs])
+    want = sp.digamma(xs)
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 5e-15
+
+
+def _ext_triples(ls, net):
+    va, s2i = ls.validation_accept, net.seq2id()
+    return np.stack([s2i[va[:, 0]], s2i[va[:, 1]], va[:, 2]], 1).astype(np.int64)
+
+
+def _first_row(path):
+    with open(path) as f:
+        cols = f.readline().split()
+    return cols
+
+
+def _fmt_row(row):
+    # iter, [duration], s/k, k, mean0, k0, mean1, k1, zp*mean0, op*mean1, a
+    return ["%d" % row[0], "%.9f" % row[1], "%d" % row[2], "%.9f" % row[3], "%d" % row[4],
+            "%.9f" % row[5], "%d" % row[6], "%.9f" % row[7], "%.9f" % row[8], "%.9f" % row[9]]
+
+
+def test_G1_G3_lfr(graph_files):
+    net = O.Network(graph_files["lfr"], 1000)
+    assert (net.n, net.ones) == (1000, 29871)
+    ls = O.LinkSampling(net, 28)
+    gold = np.loadtxt(os.path.join(GOLDEN, "ref_lfr_k28", "heldout-edges.txt"), dtype=np.int64)
+    assert np.array_equal(_ext_triples(ls, net), gold)              # G1: same pairs, same order
+    g = _first_row(os.path.join(GOLDEN, "ref_lfr_k28", "heldout.txt"))
+    assert _fmt_row(ls.rows[0]) == [g[0]] + g[2:]                   # G3 (all but the duration column)
+    assert ls.nlinks == 29722                                       # SURVEY 8 size table
+
+
+def test_G2_G4_astroph(graph_files):
+    net = O.Network(graph_files["astroph"], 17903)
+    assert (net.n, net.ones) == (17903, 196972)
+    ls = O.LinkSampling(net, 20, heldout_ratio=0.02)
+    gold = np.loadtxt(os.path.join(GOLDEN, "ref_astroph_k20", "heldout-edges.txt"), dtype=np.int64)
+    assert np.array_equal(_ext_triples(ls, net), gold)              # G2
+    g = _first_row(os.path.join(GOLDEN, "ref_astroph_k20", "heldout.txt"))
+    assert _fmt_row(ls.rows[0]) == [g[0]] + g[2:]                   # G4
+
+
+def test_sweep_values_recorded_from_the_reference(graph_files):
+    """values printed by the compiled reference (current revision):
+    LFR -max-iterations 20 => a at iterations 19,20; -max-iterations 60 => last a, 490 converged."""
+    net = O.Network(graph_files["lfr"], 1000)
+    ls = O.LinkSampling(net, 28, use_validation_stop=False)
+    for _ in range(21):
+        assert ls.sweep() == 0
+    rows = ls.rows
+    assert "%.9f" % rows[20, 9] == "-0.119617813" and "%.9f" % rows[21, 9] == "-0.118669658"
+    for _ in range(40):
+        ls.sweep()
+    assert "%.9f" % ls.rows[61, 9] == "-0.114231586"
+    assert int((ls.converged > 0).sum()) == 490
+    d, s, sh = ls.link_counts()
+    assert d + s + sh == ls.nlinks and sh > 0
+
+
+def test_astroph_values_recorded_from_the_reference(graph_files):
+    net = O.Network(graph_files["astroph"], 17903)
+    ls = O.LinkSampling(net, 20, use_validation_stop=False)
+    assert ls.nlinks == 195988
+    for _ in range(6):
+        ls.sweep()
+    assert "%.9f" % ls.rows[5, 9] == "-0.011000660" and "%.9f" % ls.rows[6, 9] == "-0.010883064"
+
+
+def test_max_iterations_runs_n_plus_one_sweeps(graph_files):
+    net = O.Network(graph_files["assort"], 75)
+    ls = O.LinkSampling(net, 4, max_iterations=3, use_validation_stop=False)
+    n = 0
+    while ls.sweep() == 0:
+        n += 1
+    assert n == 4                                                    # quirk Q8
+
+
+def test_reader_edge_cases(tmp_path):
+    p = tmp_path / "g.txt"
+    # CRLF, both directions, a self loop, a duplicate, and ids beyond -n
+    p.write_text("5\t7\r\n7\t5\r\n5\t5\r\n7\t9\n9\t5\n5\t7\n11\t5\n9\t12\n")
+    net = O.Network(str(p), 3)
+    assert net.n == 3 and net.ones == 3
+    assert net.seq2id().tolist() == [5, 7, 9]
+    assert net.edges().tolist() == [[0, 1], [1, 2], [0, 2]]
+    assert net.adj(0).tolist() == [1, 2]
+    net4 = O.Network(str(p), 4)
+    assert net4.n == 4 and net4.seq2id().tolist() == [5, 7, 9, 11] and net4.ones == 4
+
+
+def test_total_pairs_wraps_like_the_reference():
+    # quirk Q5: n(n-1)/2 in 32-bit unsigned arithmetic
+    n = 70000
+    pairs = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1).astype(np.int32)
+    net = O.Network(n=n, pairs=pairs)
+    ls = O.LinkSampling(net, 4, skip_init=True)
+    assert ls.total_pairs == float(((n * (n - 1)) & 0xFFFFFFFF) // 2)
+
+
+def test_writers_round_trip(graph_files, tmp_path):
+    net = O.Network(graph_files["assort"], 75)
+    ls = O.LinkSampling(net, 4, use_validation_stop=False)
+    for _ in range(8):
+        ls.sweep()
+    ls.write_model(str(tmp_path))
+    g = np.loadtxt(tmp_path / "gamma.txt")
+    assert g.shape == (75, 6)
+    np.testing.assert_allclose(g[:, 2:], ls.gamma, atol=5.1e-6)
+    lam = np.loadtxt(tmp_path / "lambda.txt")
+    np.testing.assert_allclose(lam[:, 1:], ls.lam, atol=5.1e-6)
+    member = ls.communities()
+    s2i = net.seq2id()
+    lines = [l for l in (tmp_path / "communities.txt").read_text().split("\n") if l]
+    want = [sorted(int(s2i[p]) for p in np.nonzero(member[:, k])[0]) for k in range(4) if member[:, k].any()]
+    assert [[int(x) for x in l.split()] for l in lines] == want
