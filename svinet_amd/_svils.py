@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsvils.so")
+LIB_PATH = os.environ.get("SVILS_LIB", os.path.join(_HERE, "lib", "libsvils.so"))  # SVILS_LIB: A/B kernel builds
 
 KERNEL_NAMES = ("phi", "reduce_sum", "finalize", "s3", "validation", "reduce_s", "tail")
 KERNEL_PHI = 0

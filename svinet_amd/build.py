@@ -40,7 +40,7 @@ def _glob(d, exts):
 def build_svils(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     out = os.path.join(LIBDIR, "libsvils.so")
-    srcs = [os.path.join(CSRC, "svils_api.hip"), os.path.join(CSRC, "svils_device.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip")]
     deps = srcs + _glob(CSRC, (".h",)) + [os.path.join(ROOT, "include", "svils.h")]
     if force or _stale(out, deps):
         _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out] + srcs)

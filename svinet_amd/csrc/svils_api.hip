@@ -260,6 +260,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   d.rows_cap = 1u << 16;
   guard(dalloc(h, &d.rows, (size_t)d.rows_cap * 10));
   guard(dalloc(h, &d.ctrl, 1));
+  guard(dalloc(h, &d.prof, 16));
   guard(dalloc(h, &h->row_scratch, 10));
   if (rc) { svils_destroy(h); return rc; }
   DevCtrl c;
@@ -336,6 +337,31 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   d.nb_a = cap((d.nitems_phi + 3) / 4, 2048);
   d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), 1024);
   d.nb_c = cap((d.nitems_s3 + 3) / 4, 2048);
+  // lane-per-link layout for small K: wave-items of 64 consecutive CSR entries
+  d.lpl = use_lpl(g.K) ? 1 : 0;
+  d.nlinks = nlinks;
+  d.ent_begin = rowptr[g.node_begin];
+  d.ent_end = rowptr[g.node_end];
+  d.lpl_w0 = d.ent_begin >> 6;
+  d.lpl_nitems = d.ent_end > d.ent_begin ? (uint32_t)(((d.ent_end + 63) >> 6) - d.lpl_w0) : 0;
+  {
+    // owned links = those whose first endpoint is in the node block (list is sorted by p)
+    uint64_t lb = 0, le = nlinks;
+    while (lb < nlinks && links[2 * lb] < g.node_begin) ++lb;
+    le = lb;
+    while (le < nlinks && links[2 * le] < g.node_end) ++le;
+    d.link_begin = lb;
+    d.link_end = le;
+  }
+  std::vector<uint32_t> erow;
+  if (d.lpl) {
+    erow.resize(std::max<uint64_t>(2 * nlinks, 1));
+    for (uint32_t p = 0; p < n; ++p)
+      for (uint64_t e = rowptr[p]; e < rowptr[p + 1]; ++e) erow[e] = p;
+    const int nw = lpl_phi_waves(g.K);
+    d.nb_a = cap((d.lpl_nitems + nw - 1) / nw, 768);   // 3 resident blocks per CU (LDS)
+    d.nb_c = cap((d.link_end - d.link_begin + 255) / 256, 1024);
+  }
 
   int rc = 0;
   auto guard = [&](int r) { if (r && !rc) rc = r; };
@@ -348,7 +374,16 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   guard(dalloc(h, &d.split_cnt, n, false));
   guard(dalloc(h, &d.parts, (size_t)d.nslots * g.ld));
   guard(dalloc(h, &d.part_cnt, (size_t)d.nslots * g.ld));
+  if (d.lpl) {
+    guard(dalloc(h, &d.erow, erow.size(), false));
+    guard(dalloc(h, &d.links, std::max<uint64_t>(2 * nlinks, 1), false));
+    guard(dalloc(h, &d.slot_f, (size_t)d.lpl_nitems * g.ld));
+    guard(dalloc(h, &d.slot_l, (size_t)d.lpl_nitems * g.ld));
+    guard(dalloc(h, &d.member_acc, g.n_alloc));
+    if (h->prm.lt_min_deg > 0) guard(dalloc(h, &d.fcnt, (size_t)g.n_alloc * g.ld));
+  }
   guard(dalloc(h, &d.part_a, (size_t)d.nb_a * g.K));
+  guard(dalloc(h, &d.part_links, (size_t)d.nb_a * 3));
   guard(dalloc(h, &d.part_b, (size_t)d.nb_b * 2 * g.K));
   guard(dalloc(h, &d.part_c, (size_t)d.nb_c * g.K));
   if (rc) return rc;
@@ -361,6 +396,11 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     HIPCHK(hipMemcpyAsync(d.items_s3, items_s3.data(), items_s3.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.split_first, split_first.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.split_cnt, split_cnt.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  if (d.lpl) {
+    HIPCHK(hipMemcpyAsync(d.erow, erow.data(), erow.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    if (nlinks)
+      HIPCHK(hipMemcpyAsync(d.links, links, 2 * nlinks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->h_rowptr.swap(rowptr);
   h->have_graph = true;
@@ -543,6 +583,10 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
       return 0;
     case 3:
       HIPCHK(hipMemcpy(out, h->d.active_cnt, g.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      return 0;
+    case 5:
+      HIPCHK(hipMemcpy(out, h->d.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemset(h->d.prof, 0, 16 * sizeof(unsigned long long)));
       return 0;
     case 4: {
       if (!h->have_graph) return fail(SVILS_ERR_ARG, "svils_get_aux: graph not set");

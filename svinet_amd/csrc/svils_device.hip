@@ -17,95 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
-#include "svils_internal.h"
+#include "svils_devutil.h"
 
 namespace svils {
-
-#define NEG_INF (-__builtin_huge_val())
-
-// ---------------------------------------------------------------- lane maps
-template <int W, int V>
-__device__ __forceinline__ int kmap(int lw, int v) {
-  return V == 1 ? lw : 2 * ((v >> 1) * W + lw) + (v & 1);
-}
-
-// ------------------------------------------------------- group reductions
-template <int W>
-__device__ __forceinline__ double group_sum(double x) {
-#pragma unroll
-  for (int o = 1; o < W; o <<= 1) x += __shfl_xor(x, o, 64);
-  return x;
-}
-template <int W>
-__device__ __forceinline__ double group_max(double x) {
-#pragma unroll
-  for (int o = 1; o < W; o <<= 1) x = fmax(x, __shfl_xor(x, o, 64));
-  return x;
-}
-// sum across the 64/W groups of a wavefront (lane lw of every group ends with the total)
-template <int W>
-__device__ __forceinline__ double cross_group_sum(double x) {
-#pragma unroll
-  for (int o = W; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
-  return x;
-}
-template <int W>
-__device__ __forceinline__ uint32_t cross_group_sum_u32(uint32_t x) {
-#pragma unroll
-  for (int o = W; o < 64; o <<= 1) x += __shfl_xor((int)x, o, 64);
-  return x;
-}
-
-// --------------------------------------------------------------- row loads
-template <int W, int V>
-__device__ __forceinline__ void load_row(const double *__restrict__ row, int lw, uint32_t ld,
-                                         double (&x)[V]) {
-  if constexpr (V == 1) {
-    x[0] = (uint32_t)lw < ld ? row[lw] : 0.0;
-  } else {
-#pragma unroll
-    for (int j = 0; j < V / 2; ++j) {
-      const uint32_t k0 = 2u * (uint32_t)(j * W + lw);
-      double2 t = make_double2(0.0, 0.0);
-      if (k0 < ld) t = *reinterpret_cast<const double2 *>(row + k0);
-      x[2 * j] = t.x;
-      x[2 * j + 1] = t.y;
-    }
-  }
-}
-template <int W, int V>
-__device__ __forceinline__ void store_row(double *__restrict__ row, int lw, uint32_t ld,
-                                          const double (&x)[V]) {
-  if constexpr (V == 1) {
-    if ((uint32_t)lw < ld) row[lw] = x[0];
-  } else {
-#pragma unroll
-    for (int j = 0; j < V / 2; ++j) {
-      const uint32_t k0 = 2u * (uint32_t)(j * W + lw);
-      if (k0 < ld) *reinterpret_cast<double2 *>(row + k0) = make_double2(x[2 * j], x[2 * j + 1]);
-    }
-  }
-}
-
-// ----------------------------------------------------------------- digamma
-// psi(x), x > 0: upward recurrence to x >= 10, then the asymptotic series
-// (double-accurate; stands where the reference calls gsl_sf_psi,
-// src/linksampling.hh:181,184).
-__device__ __forceinline__ double digamma(double x) {
-  double acc = 0.0;
-  while (x < 10.0) {
-    acc -= 1.0 / x;
-    x += 1.0;
-  }
-  const double xi = 1.0 / x, xi2 = xi * xi;
-  const double ser =
-      xi2 * (1.0 / 12.0 -
-             xi2 * (1.0 / 120.0 -
-                    xi2 * (1.0 / 252.0 -
-                           xi2 * (1.0 / 240.0 -
-                                  xi2 * (1.0 / 132.0 - xi2 * (691.0 / 32760.0 - xi2 * (1.0 / 12.0)))))));
-  return acc + log(x) - 0.5 * xi - ser;
-}
 
 // block-level reduction of per-lane K-vector partials into one row of `out`:
 // out[k] = sum over the block's 4 wavefronts and 64/W groups, fixed order.
@@ -232,7 +146,7 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
           double s = 0.0;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            e[v] = inset[v] ? exp(x[v] - m) : 0.0;
+            e[v] = inset[v] ? exp_neg(x[v] - m) : 0.0;
             s += e[v];
           }
           s = group_sum<W>(s);
@@ -293,38 +207,38 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
   // per-block partial of `sum` (src/linksampling.cc:625,630,663,700 summed per node)
   block_reduce_store<W, V, 1>(csum, d.part_a + (size_t)blockIdx.x * K, K, lds);
   // link statistics (integers: order-free)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n_dense += __shfl_xor((long long)n_dense, o, 64);
-    n_sparse += __shfl_xor((long long)n_sparse, o, 64);
-    n_short += __shfl_xor((long long)n_short, o, 64);
-  }
-  if (lane == 0) {
-    if (n_dense) atomicAdd(&ctrl->cur_dense, n_dense);
-    if (n_sparse) atomicAdd(&ctrl->cur_sparse, n_sparse);
-    if (n_short) atomicAdd(&ctrl->cur_shortcut, n_short);
-  }
+  __shared__ unsigned long long lcnt[3 * 4];
+  block_store_link_counts(n_dense, n_sparse, n_short, d.part_links, lcnt, 4);
 }
 
 // ===================================================== column reduce of partials
-// out[c] = sum_b part[b][c], c in [0, ncols): 16 columns x 16 row-segments per block.
-__global__ __launch_bounds__(256) void k_colreduce(const double *__restrict__ part, uint32_t nb,
-                                                   uint32_t ncols, double *__restrict__ out,
+// out[c] = sum_b part[b][c] in a fixed order: 4 columns x 64 row-segments per block.
+// Up to two jobs per launch (blockIdx.x < nblk0 -> job 0).
+struct ReduceJob {
+  const double *part;
+  double *out;
+  uint32_t nb, ncols;
+};
+__global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, uint32_t nblk0,
                                                    const DevCtrl *ctrl) {
   if (ctrl->stopped) return;
-  __shared__ double lds[16][17];
-  const int cl = threadIdx.x & 15, seg = threadIdx.x >> 4;
-  const uint32_t c = blockIdx.x * 16 + cl;
+  __shared__ double lds[64][5];
+  const ReduceJob j = blockIdx.x < nblk0 ? j0 : j1;
+  const uint32_t blk = blockIdx.x < nblk0 ? blockIdx.x : blockIdx.x - nblk0;
+  const int cl = threadIdx.x & 3, seg = threadIdx.x >> 2;
+  const uint32_t c = blk * 4 + cl;
   double s = 0.0;
-  if (c < ncols)
-    for (uint32_t b = seg; b < nb; b += 16) s += part[(size_t)b * ncols + c];
+  if (c < j.ncols) {
+#pragma unroll 8
+    for (uint32_t b = seg; b < j.nb; b += 64) s += j.part[(size_t)b * j.ncols + c];
+  }
   lds[seg][cl] = s;
   __syncthreads();
-  if (seg == 0 && c < ncols) {
+  if (seg == 0 && c < j.ncols) {
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += lds[i][cl];
-    out[c] = t;
+    for (int i = 0; i < 64; ++i) t += lds[i][cl];
+    j.out[c] = t;
   }
 }
 
@@ -365,8 +279,43 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
     const uint32_t p = geo.node_begin + i;
     const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
     double acc[V];
-    const int32_t sf = d.split_first[p];
-    if (sf < 0) {
+    const int32_t sf = d.lpl ? -1 : d.split_first[p];
+    if (d.lpl) {
+      // pieces left by k_phi_lpl: interior run -> gamma[p]; run starting at lane 0 of a
+      // wave-item -> slot_f[item]; run ending at lane 63 -> slot_l[item]; added in item order
+      const uint64_t r0 = d.rowptr[p], r1 = d.rowptr[p + 1];
+      double s = 0.0;
+      if (r1 > r0 && (uint32_t)lw < ld) {
+        const uint64_t w0 = r0 >> 6, w1 = (r1 - 1) >> 6;
+        if (w0 == w1) {
+          const double *src = ((r0 & 63) == 0) ? d.slot_f + (size_t)(w0 - d.lpl_w0) * ld
+                              : (((r1 - 1) & 63) == 63) ? d.slot_l + (size_t)(w0 - d.lpl_w0) * ld
+                                                        : d.gamma + (size_t)p * ld;
+          s = src[lw];
+        } else {
+          for (uint64_t w = w0; w <= w1; ++w) {
+            const double *src = (w == w0 && (r0 & 63) != 0) ? d.slot_l : d.slot_f;
+            s += src[(size_t)(w - d.lpl_w0) * ld + lw];
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = (v == 0) ? s : 0.0;
+      if (write_comm) {
+        unsigned long long b;
+        if (d.fcnt) {
+          uint32_t c = 0;
+          if (kval[0]) { c = d.fcnt[(size_t)p * ld + kidx[0]]; d.fcnt[(size_t)p * ld + kidx[0]] = 0; }
+          b = (__ballot(kval[0] && c > prm.lt_min_deg) >> (g * W)) & (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull));
+        } else {
+          b = d.member_acc[p];
+        }
+        if (lw == 0) {
+          d.member[(size_t)p * geo.kw] = b;
+          if (!d.fcnt) d.member_acc[p] = 0ull;
+        }
+      }
+    } else if (sf < 0) {
       load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
     } else {
 #pragma unroll
@@ -412,10 +361,18 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
 #pragma unroll
     for (int v = 0; v < V; ++v) rs += gn[v];
     rs = group_sum<W>(rs);
-    const double psi_rs = digamma(rs);
     double el[V];
+    if (V == 1 && K < (uint32_t)W) {
+      // lane K of the group is idle: let it evaluate psi(row sum) in the same digamma call
+      const double arg = ((uint32_t)lw == K) ? rs : (kval[0] ? gn[0] : 1.0);
+      const double ps = digamma(arg);
+      const double psi_rs = __shfl(ps, g * W + (int)K, 64);
+      el[0] = kval[0] ? ps - psi_rs : 0.0;
+    } else {
+      const double psi_rs = digamma(rs);
 #pragma unroll
-    for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v]) - psi_rs : 0.0;
+      for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v]) - psi_rs : 0.0;
+    }
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     // prune / check_and_set_converged, src/linksampling.cc:455-475
     uint32_t active = 0;
@@ -597,6 +554,27 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     d.elogbeta[2 * k] = digamma(l0) - ps;
     d.elogbeta[2 * k + 1] = digamma(l1) - ps;
   }
+  // link statistics of this sweep: per-block partials of the phi pass
+  __shared__ unsigned long long lsum[3];
+  __shared__ unsigned long long lred[3][256];
+  {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {
+      t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+    }
+    lred[0][threadIdx.x] = t0; lred[1][threadIdx.x] = t1; lred[2][threadIdx.x] = t2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        lred[0][threadIdx.x] += lred[0][threadIdx.x + o];
+        lred[1][threadIdx.x] += lred[1][threadIdx.x + o];
+        lred[2][threadIdx.x] += lred[2][threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 3) lsum[threadIdx.x] = lred[threadIdx.x][0];
+    __syncthreads();
+  }
   const uint32_t iter = ctrl->iter;
   const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
   double sz = 0.0, so = 0.0;
@@ -624,9 +602,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   }
   if (threadIdx.x == 0) {
     ctrl->parity ^= 1u;  // prune()'s flags become current
-    ctrl->links_dense = ctrl->cur_dense; ctrl->links_sparse = ctrl->cur_sparse;
-    ctrl->links_shortcut = ctrl->cur_shortcut;
-    ctrl->cur_dense = ctrl->cur_sparse = ctrl->cur_shortcut = 0;
+    ctrl->links_dense = lsum[0]; ctrl->links_sparse = lsum[1]; ctrl->links_shortcut = lsum[2];
     ctrl->sweeps_done++;
     ctrl->write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
     bool exit_now = false;
@@ -735,13 +711,15 @@ bool pick_layout(uint32_t K, int *W, int *V) {
   } while (0)
 
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  if (d.lpl) { launch_phi_lpl(g, d, p, s); return; }
 #define CALL(W_, V_) hipLaunchKernelGGL((k_phi<W_, V_>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
   SVILS_DISPATCH(g, CALL);
 #undef CALL
 }
 void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_colreduce, dim3((g.K + 15) / 16), dim3(256), 0, s, d.part_a, d.nb_a, g.K,
-                     d.kvec_a, d.ctrl);
+  const ReduceJob j0{d.part_a, d.kvec_a, d.nb_a, g.K};
+  const uint32_t nblk0 = (g.K + 3) / 4;
+  hipLaunchKernelGGL(k_colreduce, dim3(nblk0), dim3(256), 0, s, j0, j0, nblk0, d.ctrl);
 }
 void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define CALL(W_, V_) hipLaunchKernelGGL((k_finalize<W_, V_>), dim3(d.nb_b), dim3(256), 0, s, g, d, p)
@@ -749,15 +727,16 @@ void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, h
 #undef CALL
 }
 void launch_s3(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  if (d.lpl) { launch_s3_lpl(g, d, s); return; }
 #define CALL(W_, V_) hipLaunchKernelGGL((k_s3<W_, V_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
   SVILS_DISPATCH(g, CALL);
 #undef CALL
 }
 void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_colreduce, dim3((2 * g.K + 15) / 16), dim3(256), 0, s, d.part_b, d.nb_b,
-                     2 * g.K, d.kvec_c, d.ctrl);
-  hipLaunchKernelGGL(k_colreduce, dim3((g.K + 15) / 16), dim3(256), 0, s, d.part_c, d.nb_c, g.K,
-                     d.kvec_c + 2 * (size_t)g.K, d.ctrl);
+  const ReduceJob j0{d.part_b, d.kvec_c, d.nb_b, 2 * g.K};
+  const ReduceJob j1{d.part_c, d.kvec_c + 2 * (size_t)g.K, d.nb_c, g.K};
+  const uint32_t nblk0 = (2 * g.K + 3) / 4, nblk1 = (g.K + 3) / 4;
+  hipLaunchKernelGGL(k_colreduce, dim3(nblk0 + nblk1), dim3(256), 0, s, j0, j1, nblk0, d.ctrl);
 }
 void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
                        hipStream_t s) {

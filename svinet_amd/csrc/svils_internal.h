@@ -57,6 +57,19 @@ struct DeviceState {
   uint32_t nslots;
   double *parts;        // [nslots][ld] partial accumulators of split rows
   uint32_t *part_cnt;   // [nslots][ld] partial fmap counts of split rows
+  // lane-per-link layout (K <= 32): wave-item w = CSR entries [64w, 64w+64)
+  int lpl;              // 1: k_phi_lpl / k_s3_lpl are used
+  uint32_t *erow;       // [2L] row (node) of every CSR entry
+  uint32_t *links;      // [L][2] the training-link list itself (p<q), for the s3 pass
+  uint64_t nlinks;
+  uint64_t ent_begin, ent_end;   // owned CSR entries = [rowptr[node_begin], rowptr[node_end])
+  uint64_t link_begin, link_end; // owned links (first endpoint in the node block)
+  uint64_t lpl_w0;      // first wave-item (ent_begin / 64)
+  uint32_t lpl_nitems;
+  double *slot_f;       // [lpl_nitems][ld] segment that starts at lane 0 of an item
+  double *slot_l;       // [lpl_nitems][ld] segment that ends at lane 63 (and does not start at 0)
+  unsigned long long *member_acc; // [n_alloc] tag bits OR-ed during the phi pass (lt_min_deg == 0)
+  uint32_t *fcnt;       // [n_alloc][ld] tag counts (lt_min_deg > 0), else null
   // state
   double *gamma;        // [n_alloc][ld]; doubles as gammanext-accumulator inside a sweep
   double *elogpi;       // [n_alloc][ld]
@@ -74,6 +87,7 @@ struct DeviceState {
   double *kvec_a;       // [K]            sum
   double *kvec_c;       // [3K+4]         s1,s2,s3
   uint32_t nb_a, nb_b, nb_c;
+  unsigned long long *part_links;  // [nb_a][3] per-block dense/sparse/shortcut link counts
   // validation
   uint32_t *vpairs;     // [nv][3]
   double *uval;         // [nv]
@@ -81,6 +95,7 @@ struct DeviceState {
   double *rows;         // [rows_cap][10]
   uint32_t rows_cap;
   DevCtrl *ctrl;
+  unsigned long long *prof;  // [16] cycle counters of instrumented builds (-DSVILS_PROF)
 };
 
 struct Params {
@@ -92,6 +107,10 @@ struct Params {
 };
 
 // launchers (svils_device.hip); all asynchronous on `s`
+bool use_lpl(uint32_t K);
+int lpl_phi_waves(uint32_t K);
+void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_s3_lpl(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
