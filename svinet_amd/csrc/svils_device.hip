@@ -54,16 +54,19 @@ __device__ __forceinline__ void block_reduce_store(double (&part)[NV][V], double
 }
 
 // ============================================================== phi pass (A6)
-// src/linksampling.cc:605-725, pull-style.  One wavefront per Item; its 64/W
-// groups take the chunk's neighbours round-robin.
-template <int W, int V>
-__global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params prm) {
+// src/linksampling.cc:605-725, pull-style, K > 32 (K <= 32 uses k_phi_lpl).  One
+// wavefront per Item (a chunk of <= 32 neighbours of one node), all 64 lanes on one
+// row, V doubles per lane.  The chunk's column indices and converged flags are
+// fetched with one coalesced load each, and the next neighbour's Elogpi row is in
+// flight while the current one is reduced (two rows per wave in flight).
+template <int V>
+__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
+  constexpr int W = 64;
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
-  constexpr int G = 64 / W;
   __shared__ double lds[V * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / W, lw = lane % W;
+  const int lw = lane;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
   const bool sparse_iter = ctrl->iter > 1000;  // src/linksampling.cc:634
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
   for (int v = 0; v < V; ++v) {
     kidx[v] = kmap<W, V>(lw, v);
     kval[v] = (uint32_t)kidx[v] < K;
-    eb[v] = kval[v] ? d.elogbeta[2 * kidx[v]] : 0.0;
+    eb[v] = kval[v] ? d.elogbeta[2 * kidx[v]] : NEG_INF;   // -inf masks the padding columns
   }
   double csum[1][V];
 #pragma unroll
@@ -88,6 +91,13 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
     const Item item = d.items_phi[it];
     const uint32_t p = item.node;
     const uint64_t base = d.rowptr[p] + item.off;
+    const uint32_t len = item.len;   // <= 64 (chunk limit 32)
+    // one coalesced load of the chunk's neighbours and one gather of their flags
+    uint32_t mycol = 0, myconv = 0;
+    if ((uint32_t)lane < len) {
+      mycol = d.col[base + lane];
+      myconv = conv[mycol];
+    }
     const uint32_t pc = conv[p];
     double ap[V];
     load_row<W, V>(elogpi + (size_t)p * ld, lw, ld, ap);
@@ -96,16 +106,23 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
 #pragma unroll
     for (int v = 0; v < V; ++v) { acc[v] = 0.0; cnt[v] = 0; }
     uint32_t p_active = 0;
-    uint64_t pmask[V];
-    if (sparse_iter) {
-      p_active = d.active_cnt[p];
-#pragma unroll
-      for (int v = 0; v < V; ++v) pmask[v] = d.amask[(size_t)p * geo.kw + v];
-    }
+    if (sparse_iter) p_active = d.active_cnt[p];
 
-    for (uint32_t j = g; j < item.len; j += G) {
-      const uint32_t q = d.col[base + j];
-      const uint32_t qc = conv[q];
+    double rcur[V], rnext[V];
+    {
+      const uint32_t q0 = __builtin_amdgcn_readlane(mycol, 0);
+      const uint32_t qc0 = __builtin_amdgcn_readlane(myconv, 0);
+      if (len > 0 && ((pc != 0) == (qc0 != 0))) load_row<W, V>(elogpi + (size_t)q0 * ld, lw, ld, rcur);
+    }
+    for (uint32_t j = 0; j < len; ++j) {
+      const uint32_t q = __builtin_amdgcn_readlane(mycol, j);
+      const uint32_t qc = __builtin_amdgcn_readlane(myconv, j);
+      // prefetch the next neighbour's row (skipped when that link takes the O(1) shortcut)
+      if (j + 1 < len) {
+        const uint32_t q1 = __builtin_amdgcn_readlane(mycol, j + 1);
+        const uint32_t qc1 = __builtin_amdgcn_readlane(myconv, j + 1);
+        if ((pc != 0) == (qc1 != 0)) load_row<W, V>(elogpi + (size_t)q1 * ld, lw, ld, rnext);
+      }
       const bool count_me = q > p;  // count each undirected link once
       if ((pc != 0) != (qc != 0)) {
         // exactly one endpoint converged: src/linksampling.cc:622-631
@@ -113,53 +130,42 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
 #pragma unroll
         for (int v = 0; v < V; ++v)
           if (kidx[v] == c) acc[v] += 1.0;
-        if (count_me && lw == 0) n_short++;
+        if (count_me && lane == 0) n_short++;
       } else {
-        double aq[V];
-        load_row<W, V>(elogpi + (size_t)q * ld, lw, ld, aq);
-        bool inset[V];
         bool sparse = false;
-        if (sparse_iter) {
-          const uint32_t q_active = d.active_cnt[q];
-          sparse = p_active < geo.k10 && q_active < geo.k10;
-        }
-        if (sparse) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) {
-            const uint64_t um = pmask[v] | d.amask[(size_t)q * geo.kw + v];
-            inset[v] = kval[v] && ((um >> lw) & 1ull);
-          }
-        } else {
-#pragma unroll
-          for (int v = 0; v < V; ++v) inset[v] = kval[v];
-        }
+        if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
         double x[V];
         double m = NEG_INF;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          x[v] = inset[v] ? (ap[v] + aq[v]) + eb[v] : NEG_INF;
+          x[v] = (ap[v] + rcur[v]) + eb[v];   // the reference's order (:686); padding -> -inf
+          if (sparse) {
+            const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
+            x[v] = ((um >> lw) & 1ull) ? x[v] : NEG_INF;
+          }
           m = fmax(m, x[v]);
         }
         m = group_max<W>(m);
         if (m != NEG_INF) {  // an empty active-set union contributes nothing (:642-664)
-          double e[V];
           double s = 0.0;
+          bool ismax[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            e[v] = inset[v] ? exp_neg(x[v] - m) : 0.0;
-            s += e[v];
+            ismax[v] = (x[v] == m);
+            x[v] = exp_neg(x[v] - m);   // exp_neg(-inf) == 0
+            s += x[v];
           }
           s = group_sum<W>(s);
           const double inv = 1.0 / s;
 #pragma unroll
-          for (int v = 0; v < V; ++v) acc[v] += e[v] * inv;
+          for (int v = 0; v < V; ++v) acc[v] = fma(x[v], inv, acc[v]);
           // community tagging, src/linksampling.cc:668-681,704-717: the first
           // strict maximum of phi is the first k with x_k == max; its phi is 1/s.
           if (write_comm && inv > prm.link_thresh) {
             int best = 0x7fffffff;
 #pragma unroll
             for (int v = 0; v < V; ++v)
-              if (inset[v] && x[v] == m) best = min(best, kidx[v]);
+              if (ismax[v]) best = min(best, kidx[v]);
 #pragma unroll
             for (int o = 1; o < W; o <<= 1) best = min(best, __shfl_xor(best, o, 64));
 #pragma unroll
@@ -167,39 +173,29 @@ __global__ __launch_bounds__(256) void k_phi(Geometry geo, DeviceState d, Params
               if (kidx[v] == best) cnt[v]++;
           }
         }
-        if (count_me && lw == 0) { if (sparse) n_sparse++; else n_dense++; }
+        if (count_me && lane == 0) { if (sparse) n_sparse++; else n_dense++; }
       }
+#pragma unroll
+      for (int v = 0; v < V; ++v) rcur[v] = rnext[v];
     }
 
-    // combine the groups' partial accumulators (fixed order)
-    if constexpr (G > 1) {
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        acc[v] = cross_group_sum<W>(acc[v]);
-        cnt[v] = cross_group_sum_u32<W>(cnt[v]);
-      }
-    }
-    if (g == 0) {
-#pragma unroll
-      for (int v = 0; v < V; ++v) csum[0][v] += acc[v];
-    }
+    for (int v = 0; v < V; ++v) csum[0][v] += acc[v];
     if (item.slot < 0) {
-      if (g == 0) store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
+      store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
       if (write_comm) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          const unsigned long long b = __ballot(g == 0 && kval[v] && cnt[v] > prm.lt_min_deg);
+          const unsigned long long b = __ballot(kval[v] && cnt[v] > prm.lt_min_deg);
           if (lane == 0) d.member[(size_t)p * geo.kw + v] = b;
         }
       }
     } else {
-      if (g == 0) {
-        store_row<W, V>(d.parts + (size_t)item.slot * ld, lw, ld, acc);
-        if (write_comm) {
+      store_row<W, V>(d.parts + (size_t)item.slot * ld, lw, ld, acc);
+      if (write_comm) {
 #pragma unroll
-          for (int v = 0; v < V; ++v)
-            if (kval[v]) d.part_cnt[(size_t)item.slot * ld + kidx[v]] = cnt[v];
-        }
+        for (int v = 0; v < V; ++v)
+          if (kval[v]) d.part_cnt[(size_t)item.slot * ld + kidx[v]] = cnt[v];
       }
     }
   }
@@ -712,9 +708,14 @@ bool pick_layout(uint32_t K, int *W, int *V) {
 
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   if (d.lpl) { launch_phi_lpl(g, d, p, s); return; }
-#define CALL(W_, V_) hipLaunchKernelGGL((k_phi<W_, V_>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
-  SVILS_DISPATCH(g, CALL);
-#undef CALL
+  switch (g.V) {   // K > 32 => W == 64
+    case 1: hipLaunchKernelGGL((k_phi<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+    case 2: hipLaunchKernelGGL((k_phi<2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+    case 4: hipLaunchKernelGGL((k_phi<4>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+    case 8: hipLaunchKernelGGL((k_phi<8>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+    case 16: hipLaunchKernelGGL((k_phi<16>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+    default: hipLaunchKernelGGL((k_phi<32>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+  }
 }
 void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const ReduceJob j0{d.part_a, d.kvec_a, d.nb_a, g.K};

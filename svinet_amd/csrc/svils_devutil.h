@@ -16,18 +16,39 @@ __device__ __forceinline__ int kmap(int lw, int v) {
 }
 
 // ------------------------------------------------------- group reductions
-template <int W>
-__device__ __forceinline__ double group_sum(double x) {
-#pragma unroll
-  for (int o = 1; o < W; o <<= 1) x += __shfl_xor(x, o, 64);
-  return x;
+// All-reduce over the W lanes of a group.  Steps 1,2,4,8 are DPP moves inside a
+// 16-lane row (quad_perm / row_half_mirror / row_mirror: ~8 cycles each instead of a
+// ~100-cycle ds_bpermute round trip); steps 16 and 32 go through ds_swizzle /
+// ds_bpermute.  The mirrors work as xor-4 / xor-8 because after the previous steps
+// every lane of a quad (8-group) already holds the same partial.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-template <int W>
-__device__ __forceinline__ double group_max(double x) {
-#pragma unroll
-  for (int o = 1; o < W; o <<= 1) x = fmax(x, __shfl_xor(x, o, 64));
-  return x;
+__device__ __forceinline__ double swz16_f64(double x) {   // lane i <-> i ^ 16
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  return __hiloint2double(hi, lo);
 }
+#define SVILS_GROUP_REDUCE(NAME, OP)                                            \
+  template <int W>                                                              \
+  __device__ __forceinline__ double NAME(double x) {                            \
+    if (W >= 2) { const double t = dpp_f64<0xB1>(x); x = OP(x, t); }            \
+    if (W >= 4) { const double t = dpp_f64<0x4E>(x); x = OP(x, t); }            \
+    if (W >= 8) { const double t = dpp_f64<0x141>(x); x = OP(x, t); }           \
+    if (W >= 16) { const double t = dpp_f64<0x140>(x); x = OP(x, t); }          \
+    if (W >= 32) { const double t = swz16_f64(x); x = OP(x, t); }               \
+    if (W >= 64) { const double t = __shfl_xor(x, 32, 64); x = OP(x, t); }      \
+    return x;                                                                   \
+  }
+__device__ __forceinline__ double svils_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double svils_max(double a, double b) { return fmax(a, b); }
+SVILS_GROUP_REDUCE(group_sum, svils_add)
+SVILS_GROUP_REDUCE(group_max, svils_max)
 // sum across the 64/W groups of a wavefront (lane lw of every group ends with the total)
 template <int W>
 __device__ __forceinline__ double cross_group_sum(double x) {
