@@ -97,6 +97,9 @@ def main():
                     help="|".join(WORKLOADS) + "|synthetic:<n>:<k>:<mean_deg>")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU driver even at N=1")
+    ap.add_argument("--shard", choices=["auto", "always", "never"], default="auto",
+                    help="N>1: node-block sharding with RCCL exchanges, or replicate the sweep on every "
+                         "rank (auto: shard only when K*L/N is large enough to amortise 3 collectives/sweep)")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,7 +140,13 @@ def main():
     L = int(setup.nlinks)
     V = int(setup.validation_sorted.shape[0])
 
-    if dist is None:
+    # A sweep has three exchange points; below ~5e7 (link,k) pairs per GPU the sweep is tens of
+    # microseconds and sharding it only adds collective latency, so small problems are replicated.
+    work_per_gpu = float(k) * L / max(world, 1)
+    shard = world > 1 and (args.shard == "always" or (args.shard == "auto" and work_per_gpu >= 5e7))
+    if args.force_sharded:
+        shard = True
+    if not shard:
         eng = setup.engine(use_validation_stop=False, device=local_rank)
         runner = eng
         sync = eng.synchronize
@@ -175,7 +184,7 @@ def main():
         phi_ms, phi_n = timing["phi"]
         phi_avg_s = phi_ms / max(phi_n, 1) * 1e-3
         # algorithmic bytes of the phi pass: 32*K per link x links this rank processes
-        links_per_launch = L / world
+        links_per_launch = L / world if shard else L
         alg_bytes = 32.0 * k * links_per_launch
         achieved = alg_bytes / phi_avg_s / 1e9 if phi_avg_s > 0 else 0.0
         out = {
@@ -193,7 +202,9 @@ def main():
             "data": data,
             "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run, dense path"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
-                       "parallelism": "node-block x%d" % world if world > 1 else "single GPU",
+                       "parallelism": ("node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world) if shard
+                                      else ("replicated on %d GPUs (problem too small to shard: K*L/N = %.1e)" % (world, work_per_gpu)
+                                            if world > 1 else "single GPU"),
                        "converged_nodes_at_end": None},
             "roofline": {"bound": "hbm", "kernel": "k_phi", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -208,12 +219,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
     if path:
         os.unlink(path)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)   # the one JSON line, after any RCCL banner
 
 
 if __name__ == "__main__":

@@ -537,9 +537,29 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
 __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
+  // one combined block reduction: {szeros, sones} doubles and {kzeros, dense, sparse, shortcut} counts
   __shared__ double red[2][256];
-  __shared__ unsigned int cntz[256];
+  __shared__ unsigned long long cred[4][256];
   const uint32_t K = geo.K;
+  const uint32_t iter = ctrl->iter;
+  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
+  double sz = 0.0, so = 0.0;
+  unsigned long long kz = 0, t0 = 0, t1 = 0, t2 = 0;
+  if (do_val) {
+    // contiguous slices per thread, then a fixed-order tree
+    const uint32_t per = (d.nv + blockDim.x - 1) / blockDim.x;
+    const uint32_t b = threadIdx.x * per, e = min(d.nv, b + per);
+    for (uint32_t i = b; i < e; ++i) {
+      const double u = d.uval[i];
+      if (d.vpairs[3 * (size_t)i + 2]) so += u; else { sz += u; kz++; }
+    }
+  }
+  for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {   // link statistics of the phi pass
+    t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+  }
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so;
+  cred[0][threadIdx.x] = kz; cred[1][threadIdx.x] = t0; cred[2][threadIdx.x] = t1; cred[3][threadIdx.x] = t2;
+  // lambda update + set_dir_exp(lambda), src/linksampling.cc:748-759
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
     const double l0 = prm.eta0 + d.kvec_a[k];
     const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
@@ -550,61 +570,25 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     d.elogbeta[2 * k] = digamma(l0) - ps;
     d.elogbeta[2 * k + 1] = digamma(l1) - ps;
   }
-  // link statistics of this sweep: per-block partials of the phi pass
-  __shared__ unsigned long long lsum[3];
-  __shared__ unsigned long long lred[3][256];
-  {
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {
-      t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
-    }
-    lred[0][threadIdx.x] = t0; lred[1][threadIdx.x] = t1; lred[2][threadIdx.x] = t2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) {
-        lred[0][threadIdx.x] += lred[0][threadIdx.x + o];
-        lred[1][threadIdx.x] += lred[1][threadIdx.x + o];
-        lred[2][threadIdx.x] += lred[2][threadIdx.x + o];
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x < 3) lsum[threadIdx.x] = lred[threadIdx.x][0];
-    __syncthreads();
-  }
-  const uint32_t iter = ctrl->iter;
-  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
-  double sz = 0.0, so = 0.0;
-  unsigned int kz = 0;
-  if (do_val) {
-    // contiguous slices per thread, then a fixed-order tree
-    const uint32_t per = (d.nv + blockDim.x - 1) / blockDim.x;
-    const uint32_t b = threadIdx.x * per, e = min(d.nv, b + per);
-    for (uint32_t i = b; i < e; ++i) {
-      const double u = d.uval[i];
-      if (d.vpairs[3 * (size_t)i + 2]) so += u; else { sz += u; kz++; }
-    }
-  }
-  red[0][threadIdx.x] = sz;
-  red[1][threadIdx.x] = so;
-  cntz[threadIdx.x] = kz;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
       red[0][threadIdx.x] += red[0][threadIdx.x + o];
       red[1][threadIdx.x] += red[1][threadIdx.x + o];
-      cntz[threadIdx.x] += cntz[threadIdx.x + o];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cred[c][threadIdx.x] += cred[c][threadIdx.x + o];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     ctrl->parity ^= 1u;  // prune()'s flags become current
-    ctrl->links_dense = lsum[0]; ctrl->links_sparse = lsum[1]; ctrl->links_shortcut = lsum[2];
+    ctrl->links_dense = cred[1][0]; ctrl->links_sparse = cred[2][0]; ctrl->links_shortcut = cred[3][0];
     ctrl->sweeps_done++;
     ctrl->write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
     bool exit_now = false;
     if (do_val) {
       const double szeros = red[0][0], sones = red[1][0];
-      const uint32_t kzeros = cntz[0], kones = d.nv - cntz[0];
+      const uint32_t kzeros = (uint32_t)cred[0][0], kones = d.nv - kzeros;
       const double mean0 = szeros / kzeros, mean1 = sones / kones;
       const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
       double *row = d.rows + (size_t)(ctrl->rows % d.rows_cap) * 10;
