@@ -122,7 +122,8 @@ def main():
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=rank, world_size=world)
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
 
     # ---- inputs: product host side (C++), resident in HBM before timing ----
     path, pairs = None, None
@@ -219,6 +220,29 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+    # N>1 and the main run was replicated: also time the node-block sharded path (RCCL
+    # exchanges) on the same problem, reported next to `value`, never instead of it.
+    if world > 1 and not shard and dist is not None:
+        sh = {}
+        try:
+            from svinet_amd.sharded import HipShard, ShardedSweep
+            shard2 = HipShard(setup, rank, world, local_rank, use_validation_stop=False)
+            run2 = ShardedSweep(shard2, dist)
+            nst = min(args.steps, 50)
+            run2.sweep(args.warmup)
+            shard2.engine.synchronize(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run2.sweep(nst)
+            shard2.engine.synchronize(); torch.cuda.synchronize()
+            el2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+            sh = {"value": L * nst / float(el2.item()), "unit": "edge-updates/s", "steps": nst,
+                  "ms_per_step": float(el2.item()) / nst * 1e3,
+                  "parallelism": "node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world}
+        except Exception as exc:  # the main measurement must survive a failure here
+            sh = {"error": repr(exc)[:300]}
+        if rank == 0:
+            out["sharded_path"] = sh
     if path:
         os.unlink(path)
     if dist is not None:
