@@ -1,0 +1,92 @@
+"""-m gpu: size-independent properties of the sweep at sizes the CPU oracle cannot
+follow (BASELINE config-4/5 shapes), checked through the C ABI.
+
+* phi rows are probability vectors, so per sweep  sum_k (lambda[k][0] - eta0) == 2 L
+  (every link adds 2 to `_sum`, src/linksampling.cc:625,630,663,700);
+* mean indicators: sum_k mphi[p][k] == 1/2 for every node with a training link
+  (tl = 2 deg, quirk Q3) -- including split hub rows and run-straddling wave-items;
+* link-branch counters partition the training links;
+* two engines fed the same inputs produce bit-identical states (no fp atomics);
+* a held-out pair list in a different order gives the same likelihood row values
+  up to summation order (<= 1e-12).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic(n, mean_deg, seed):
+    rng = np.random.default_rng(seed)
+    m = n * mean_deg // 2 - n
+    a = rng.integers(0, n, size=m, dtype=np.int64)
+    b = rng.integers(0, n, size=m, dtype=np.int64)
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    # a few hubs so that rows are split / straddle many wave-items
+    hub = np.stack([np.zeros(3000, dtype=np.int64), rng.integers(1, n, size=3000)], 1)
+    return np.concatenate([ring, np.stack([a, b], 1), hub]).astype(np.int32)
+
+
+@pytest.mark.parametrize("n,k", [(60000, 20), (30000, 200), (20000, 512), (40000, 33)])
+def test_invariants_at_scale(n, k):
+    from svinet_amd.host_api import Setup
+    s = Setup(n=n, k=k, pairs=_synthetic(n, 20, 7))
+    L = int(s.nlinks)
+    e1 = s.engine(use_validation_stop=False)
+    e2 = s.engine(use_validation_stop=False)
+    for sweeps in (1, 3):
+        e1.sweep(sweeps)
+        e2.sweep(sweeps)
+        g1, l1, c1 = e1.state()
+        g2, l2, c2 = e2.state()
+        assert np.array_equal(g1, g2) and np.array_equal(l1, l2) and np.array_equal(c1, c2)
+        assert np.isfinite(g1).all() and (g1 > 0).all()
+        tot = float((l1[:, 0] - s.eta[0]).sum())
+        assert abs(tot - 2.0 * L) < 1e-6 * L, (tot, 2 * L)
+        mphi = e1.aux(2)
+        tl = e1.aux(4)
+        rs = mphi.sum(1)
+        assert np.allclose(rs[tl > 0], 0.5, rtol=0, atol=1e-12)
+        c = e1.control()
+        assert c.links_dense + c.links_sparse + c.links_shortcut == L
+        assert np.array_equal(e1.communities(), e2.communities())
+    # training_links derived on the device side == 2 * training degree
+    deg = np.bincount(s.links.ravel(), minlength=s.n)
+    assert np.array_equal(e1.aux(4), 2.0 * deg)
+
+
+def test_validation_order_independence(graph_files):
+    from svinet_amd.host_api import Setup
+    s = Setup(graph_files["lfr"], 1000, 28)
+    e1 = s.engine(use_validation_stop=False)
+    perm = np.random.default_rng(0).permutation(s.validation_sorted.shape[0])
+    from svinet_amd._svils import Engine
+    e2 = Engine(s.n, s.k, ones=s.ones, ones_prob=s.ones_prob, eta=s.eta, use_validation_stop=False)
+    e2.set_graph(s.links)
+    e2.set_validation(s.validation_sorted[perm])
+    e2.set_state(s.gamma, s.lam)
+    np.testing.assert_allclose(e1.validation_row(), e2.validation_row(), rtol=1e-12)
+    e1.sweep(5)
+    e2.sweep(5)
+    np.testing.assert_allclose(e1.rows(), e2.rows(), rtol=1e-12)
+
+
+def test_edge_cases_small_graphs():
+    """ragged inputs: isolated declared nodes, a star (one hub), k=1..3, no held-out pairs"""
+    from svinet_amd.host_api import Setup
+    from oracle import oracle as O
+    star = np.array([[0, i] for i in range(1, 200)] + [[5, 6], [7, 8]], dtype=np.int32)
+    for k in (2, 3, 9):
+        s = Setup(n=260, k=k, pairs=star, heldout_ratio=0.0)
+        assert s.singles == 60 and s.validation_sorted.shape[0] == 0
+        e = s.engine(use_validation_stop=False)
+        e.sweep(6)
+        ref = O.LinkSampling(O.Network(n=260, pairs=star), k, heldout_ratio=0.0, use_validation_stop=False)
+        ref.set_skip_validation(True)
+        for _ in range(6):
+            ref.sweep()
+        g, lam, conv = e.state()
+        assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-9
+        assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+        assert np.array_equal(conv, ref.converged)
+        assert e.control().iter == 6 and e.control().rows == 0
