@@ -445,7 +445,7 @@ static void assign_training_links(orc_ls *m) {
     for (uint32_t r = 0; r < e->n; ++r) {
       uint32_t q = e->v[r];
       uint32_t lo = p < q ? p : q, hi = p < q ? q : p;
-      if (!edge_ok(m, lo, hi)) continue;
+      if (!m->cfg.accuracy && !edge_ok(m, lo, hi)) continue;   /* :503-510 */
       m->training_links[p]++;
       m->training_links[q]++;
       if (p >= q) continue;
@@ -496,6 +496,7 @@ static void push_row(orc_ls *m, const double *row) {
 /* validation_likelihood, src/linksampling.cc:966-1050.  Returns 1 if the
  * reference would do_on_stop()+exit(0) here. */
 static int validation_likelihood(orc_ls *m) {
+  if (m->cfg.accuracy) return 0;   /* :969-970 */
   uint32_t K = m->k;
   double *pi_p = (double *)malloc(sizeof(double) * K), *pi_q = (double *)malloc(sizeof(double) * K);
   uint32_t k = 0, kzeros = 0, kones = 0;

@@ -64,6 +64,7 @@ typedef struct {
   uint32_t max_iterations;  /* -max-iterations, 0 = none                    */
   int use_validation_stop;  /* 0 with -no-stop                              */
   int skip_init;            /* 1: caller provides gamma via orc_ls_set_state */
+  int accuracy;             /* -accuracy: train on every link, no likelihood/stop rule */
 } orc_config;
 
 void orc_config_default(orc_config *c, uint32_t k);

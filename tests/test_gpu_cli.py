@@ -75,3 +75,35 @@ def test_cli_validation_stop_and_resume(graph_files, tmp_path):
     g0 = np.loadtxt(d / "gamma.txt")
     g1 = np.loadtxt(tmp_path / "n75-k4-resumed-linksampling" / "gamma.txt")
     assert g0.shape == g1.shape and np.isfinite(g1).all()
+
+
+def test_cli_accuracy_and_load_validation(graph_files, tmp_path):
+    # -accuracy: all links train, validation_likelihood() is a no-op => validation.txt stays empty
+    r = _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling", "-accuracy",
+              "-max-iterations", "5", "-label", "acc"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n75-k4-acc-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4, accuracy=True, max_iterations=5)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref_acc"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    assert (d / "validation.txt").read_text() == ""
+    # -load-validation: pairs given as external ids, one "id<TAB>id" per line
+    net = O.Network(graph_files["assort"], 75)
+    s2i = net.seq2id()
+    e = net.edges()
+    pairs = [(int(s2i[a]), int(s2i[b])) for a, b in e[::97]] + [(int(s2i[0]), int(s2i[70])), (int(s2i[3]), int(s2i[66]))]
+    vf = tmp_path / "val.txt"
+    vf.write_text("".join("%d\t%d\n" % p for p in pairs))
+    r = _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling", "-load-validation", str(vf),
+              "-no-stop", "-max-iterations", "3", "-label", "lv"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n75-k4-lv-linksampling"
+    ve = [l.split("\t") for l in (d / "validation-edges.txt").read_text().split("\n") if l]
+    assert len(ve) == len(pairs)
+    v = np.loadtxt(d / "validation.txt")
+    assert v.shape == (5, 11) and int(v[0, 3]) == len(pairs)

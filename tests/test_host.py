@@ -103,3 +103,12 @@ def test_cli_host_outputs_and_loud_failure_without_gpu(graph_files, tmp_path):
 def test_output_dir_naming(graph_files, tmp_path):
     _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling", "-label", "run1", "-seed", "3"], str(tmp_path))
     assert (tmp_path / "n75-k4-run1-seed3-linksampling").is_dir()
+
+
+def test_accuracy_mode_trains_on_all_links(graph_files):
+    """-accuracy: held-out pairs are still drawn (RNG stream unchanged) but no link is held out"""
+    s = Setup(graph_files["assort"], 75, 4, accuracy=True)
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4, accuracy=True)
+    assert s.nlinks == s.ones == ref.nlinks
+    assert np.array_equal(s.links, ref.links) and np.array_equal(s.gamma, ref.gamma)
+    assert np.array_equal(s.validation_accept, ref.validation_accept)
