@@ -27,7 +27,8 @@ class _Config(C.Structure):
     _fields_ = [("k", C.c_uint32), ("seed", C.c_double), ("heldout_ratio", C.c_double),
                 ("link_thresh", C.c_double), ("lt_min_deg", C.c_uint32), ("eta_type", C.c_int),
                 ("reportfreq", C.c_uint32), ("max_iterations", C.c_uint32),
-                ("use_validation_stop", C.c_int), ("skip_init", C.c_int), ("accuracy", C.c_int)]
+                ("use_validation_stop", C.c_int), ("skip_init", C.c_int), ("accuracy", C.c_int),
+                ("eta_override0", C.c_double), ("eta_override1", C.c_double), ("train_on_heldout", C.c_int)]
 
 
 _lib = None
@@ -170,7 +171,7 @@ class LinkSampling:
 
     def __init__(self, net, k, seed=0, heldout_ratio=0.01, link_thresh=0.5, lt_min_deg=0,
                  eta_type="uniform", reportfreq=1, max_iterations=0, use_validation_stop=True,
-                 skip_init=False, accuracy=False):
+                 skip_init=False, accuracy=False, eta_override=None, train_on_heldout=False):
         L = lib()
         cfg = _Config()
         L.orc_config_default(C.byref(cfg), k)
@@ -184,6 +185,9 @@ class LinkSampling:
         cfg.use_validation_stop = int(use_validation_stop)
         cfg.skip_init = int(skip_init)
         cfg.accuracy = int(accuracy)
+        if eta_override is not None:
+            cfg.eta_override0, cfg.eta_override1 = eta_override
+        cfg.train_on_heldout = int(train_on_heldout)
         self.net = net
         self._h = L.orc_ls_create(net._h, C.byref(cfg))
         self.n = L.orc_ls_n(self._h)

@@ -445,7 +445,7 @@ static void assign_training_links(orc_ls *m) {
     for (uint32_t r = 0; r < e->n; ++r) {
       uint32_t q = e->v[r];
       uint32_t lo = p < q ? p : q, hi = p < q ? q : p;
-      if (!m->cfg.accuracy && !edge_ok(m, lo, hi)) continue;   /* :503-510 */
+      if (!m->cfg.accuracy && !m->cfg.train_on_heldout && !edge_ok(m, lo, hi)) continue;   /* :503-510 */
       m->training_links[p]++;
       m->training_links[q]++;
       if (p >= q) continue;
@@ -564,6 +564,8 @@ orc_ls *orc_ls_create(const orc_net *g, const orc_config *cfg) {
     case 3: m->eta0 = 4700.59; m->eta1 = 0.77; break;    /* src/env.hh:371-372 */
     default: m->eta0 = 1; m->eta1 = 1; break;
   }
+  if (cfg->eta_override0 > 0) m->eta0 = cfg->eta_override0;
+  if (cfg->eta_override1 > 0) m->eta1 = cfg->eta_override1;
   size_t nk = (size_t)n * K;
   m->gamma = (double *)calloc(nk, sizeof(double));
   m->gammanext = (double *)calloc(nk, sizeof(double));

@@ -170,3 +170,40 @@ def test_no_device_is_loud():
     from svinet_amd import _svils
     with pytest.raises(_svils.SvilsError):
         _svils.Engine(10, 4, ones=1, ones_prob=0.1, device=4096)
+
+
+# ---------------------------------------------------------------------------
+# HIP path directly against the reference authors' shipped runs (real GSL; older
+# revision: eta = 0.001, held-out links kept in training -- tests/golden/README.md)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("key,d,n,k,hr,stop_iter", [("lfr", "ref_lfr_k28", 1000, 28, 0.01, 43),
+                                                    ("astroph", "ref_astroph_k20", 17903, 20, 0.02, 99)])
+def test_against_shipped_reference_runs(graph_files, key, d, n, k, hr, stop_iter):
+    import os
+    from conftest import GOLDEN
+    from svinet_amd._svils import Engine
+    from svinet_amd.host_api import Setup
+    s = Setup(graph_files[key], n, k, heldout_ratio=hr)
+    all_links = Setup(graph_files[key], n, k, heldout_ratio=hr, accuracy=True).links   # nothing held out
+    assert all_links.shape[0] == s.ones
+    eng = Engine(s.n, s.k, ones=s.ones, ones_prob=s.ones_prob, eta=(0.001, 0.001))
+    eng.set_graph(all_links)
+    eng.set_validation(s.validation_sorted)
+    eng.set_state(s.gamma, np.full((k, 2), 0.001))
+    gold = np.array([[float(x) for x in l.split("\t")] for l in
+                     open(os.path.join(GOLDEN, d, "heldout.txt")).read().split("\n") if l])
+    np.testing.assert_allclose(eng.validation_row()[1:], np.delete(gold[0], 1)[1:], rtol=0, atol=6e-10)
+    eng.sweep(gold.shape[0] + 10)            # the device-side stop rule must fire where the authors' run did
+    c = eng.control()
+    assert c.stopped == 1 and c.iter == stop_iter and c.sweeps_done == gold.shape[0] - 1
+    rows = eng.rows()
+    np.testing.assert_allclose(rows[:, 1:], np.delete(gold[1:], 1, axis=1)[:, 1:], rtol=0, atol=6e-9)
+    assert np.array_equal(rows[:, 0], gold[1:, 0])
+    g, lam, _ = eng.state()
+    np.testing.assert_allclose(lam, np.loadtxt(os.path.join(GOLDEN, d, "lambda.txt"))[:, 1:], rtol=0, atol=1.1e-5)
+    if key == "lfr":
+        np.testing.assert_allclose(g, np.loadtxt(os.path.join(GOLDEN, d, "gamma.txt.gz"))[:, 2:], rtol=0, atol=1.1e-5)
+    else:
+        gg = np.loadtxt(os.path.join(GOLDEN, d, "gamma_rows_mod16.txt.gz"))
+        np.testing.assert_allclose(g[gg[:, 0].astype(np.int64)], gg[:, 2:], rtol=0, atol=1.1e-5)
+        np.testing.assert_allclose(g.sum(0), np.loadtxt(os.path.join(GOLDEN, d, "gamma_colsums.txt")), rtol=1e-8)

@@ -150,3 +150,62 @@ def test_writers_round_trip(graph_files, tmp_path):
     lines = [l for l in (tmp_path / "communities.txt").read_text().split("\n") if l]
     want = [sorted(int(s2i[p]) for p in np.nonzero(member[:, k])[0]) for k in range(4) if member[:, k].any()]
     assert [[int(x) for x in l.split()] for l in lines] == want
+
+
+# ---------------------------------------------------------------------------
+# The sweep itself, pinned on the reference authors' own shipped runs (real GSL).
+# Those runs used an older revision: eta = (0.001, 0.001) and held-out links kept
+# in the training list (tests/golden/README.md); the arithmetic is today's.
+# ---------------------------------------------------------------------------
+LEGACY = dict(eta_override=(0.001, 0.001), train_on_heldout=True)
+SHIPPED = {"lfr": ("ref_lfr_k28", 1000, 28, 0.01, 20, 43), "astroph": ("ref_astroph_k20", 17903, 20, 0.02, 26, 99)}
+
+
+def _gold_rows(d):
+    return [l.split("\t") for l in open(os.path.join(GOLDEN, d, "heldout.txt")).read().split("\n") if l]
+
+
+@pytest.mark.parametrize("key", ["lfr", "astroph"])
+def test_shipped_trajectory_stop_and_model(graph_files, key):
+    d, n, k, hr, exact_rows, stop_iter = SHIPPED[key]
+    net = O.Network(graph_files[key], n)
+    ls = O.LinkSampling(net, k, heldout_ratio=hr, **LEGACY)          # validation stop ON, as shipped
+    gold = _gold_rows(d)
+    sweeps = 0
+    while True:
+        rc = ls.sweep()
+        sweeps += 1
+        assert sweeps <= len(gold)
+        if rc == 2:
+            break
+    # same stopping sweep as the authors' run (max.txt: "<iter> <secs> ... 1")
+    assert ls.iter == stop_iter == int(open(os.path.join(GOLDEN, d, "max.txt")).read().split()[0])
+    assert sweeps == len(gold) - 1
+    rows = ls.rows
+    # every printed digit of every column for the first sweeps ...
+    for i in range(exact_rows + 1):
+        assert _fmt_row(rows[i]) == [gold[i][0]] + gold[i][2:], "row %d" % i
+    # ... and the last printed digit afterwards (through the annealing switch, up to the stop)
+    g = np.array([[float(x) for x in r] for r in gold])
+    np.testing.assert_allclose(rows[:, 1:], np.delete(g, 1, axis=1)[:, 1:], rtol=0, atol=6e-9)
+    # final model against the shipped gamma.txt / lambda.txt (printed with 5 decimals)
+    lam = np.loadtxt(os.path.join(GOLDEN, d, "lambda.txt"))
+    np.testing.assert_allclose(ls.lam, lam[:, 1:], rtol=0, atol=1.1e-5)
+    G = ls.gamma
+    if key == "lfr":
+        gg = np.loadtxt(os.path.join(GOLDEN, d, "gamma.txt.gz"))
+        assert np.array_equal(gg[:, 1].astype(np.int64), net.seq2id())
+        np.testing.assert_allclose(G, gg[:, 2:], rtol=0, atol=1.1e-5)
+        shipped = [set(map(int, l.split())) for l in open(os.path.join(GOLDEN, d, "communities.txt")).read().split("\n") if l.strip()]
+        mem, s2i = ls.communities(), net.seq2id()
+        mine = [set(int(s2i[p]) for p in np.nonzero(mem[:, c])[0]) for c in range(k) if mem[:, c].any()]
+        assert len(mine) == len(shipped) == 28
+        for a, b in zip(mine, shipped):        # older revision tagged a few more members per community
+            assert a <= b and len(a) >= 0.85 * len(b)
+    else:
+        gg = np.loadtxt(os.path.join(GOLDEN, d, "gamma_rows_mod16.txt.gz"))
+        idx = gg[:, 0].astype(np.int64)
+        assert np.array_equal(idx, np.arange(0, n, 16))
+        np.testing.assert_allclose(G[idx], gg[:, 2:], rtol=0, atol=1.1e-5)
+        cs = np.loadtxt(os.path.join(GOLDEN, d, "gamma_colsums.txt"))
+        np.testing.assert_allclose(G.sum(0), cs, rtol=1e-8)
