@@ -145,6 +145,10 @@ int svils_get_communities(svils_handle *h, uint8_t *member);
  *         3 active_comms [n] (uint32), 4 training_links [n] (double). */
 int svils_get_aux(svils_handle *h, int which, void *out);
 
+/* Evaluate the kernels' own special functions on a plain array (unit tests):
+ * which = 0 digamma(x) [stands for gsl_sf_psi], 1 exp(x) for x <= 0, 2 1/x, 3 ln(x) for x >= 1. */
+int svils_debug_eval(svils_handle *h, int which, const double *in, double *out, uint32_t n);
+
 /* ---- measurement --------------------------------------------------------- */
 enum {
   SVILS_KERNEL_PHI = 0, SVILS_KERNEL_REDUCE_SUM, SVILS_KERNEL_FINALIZE, SVILS_KERNEL_S3,

@@ -22,7 +22,7 @@ EXPORTS = (
     "svils_validation_row", "svils_sweep", "svils_synchronize", "svils_get_rows",
     "svils_get_state", "svils_get_communities", "svils_get_aux", "svils_enable_timing",
     "svils_get_timing", "svils_kernel_name", "svils_sweep_phase", "svils_device_buffer",
-    "svils_stream", "svils_last_error", "svils_abi_version",
+    "svils_stream", "svils_last_error", "svils_abi_version", "svils_debug_eval",
 )
 
 
@@ -93,6 +93,7 @@ def load():
     L.svils_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_size_t)]
     L.svils_stream.argtypes = [vp, C.POINTER(vp)]
+    L.svils_debug_eval.argtypes = [vp, C.c_int, vp, vp, C.c_uint32]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version"):
@@ -215,6 +216,12 @@ class Engine:
         shape, dt = shapes[which]
         out = np.zeros(shape, dtype=dt)
         _chk(load().svils_get_aux(self._h, which, out.ctypes.data))
+        return out
+
+    def debug_eval(self, which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        _chk(load().svils_debug_eval(self._h, which, x.ctypes.data, out.ctypes.data, x.size))
         return out
 
     def enable_timing(self, mask):

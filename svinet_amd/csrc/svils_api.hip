@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -261,6 +262,21 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.rows, (size_t)d.rows_cap * 10));
   guard(dalloc(h, &d.ctrl, 1));
   guard(dalloc(h, &d.prof, 16));
+  {
+    double *lt = nullptr;
+    guard(dalloc(h, &lt, 256, false));
+    if (!rc) {
+      // {1/c_i, ln c_i} at the centres of 128 equal sub-intervals of [1,2) (log_tab in svils_devutil.h)
+      double tab[256];
+      for (int i = 0; i < 128; ++i) {
+        const double c = 1.0 + (i + 0.5) / 128.0;
+        tab[2 * i] = 1.0 / c;
+        tab[2 * i + 1] = std::log(c);
+      }
+      if (hipMemcpy(lt, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SVILS_ERR_DEVICE, "log table upload failed");
+      d.logtab = lt;
+    }
+  }
   guard(dalloc(h, &h->row_scratch, 10));
   if (rc) { svils_destroy(h); return rc; }
   DevCtrl c;
@@ -597,6 +613,24 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
     default:
       return fail(SVILS_ERR_ARG, "svils_get_aux: unknown selector %d", which);
   }
+}
+
+int svils_debug_eval(svils_handle *h, int which, const double *in, double *out, uint32_t n) {
+  if (!h || !in || !out || which < 0 || which > 3) return fail(SVILS_ERR_ARG, "svils_debug_eval: bad argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  double *din = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc((void **)&din, (size_t)std::max(n, 1u) * sizeof(double)));
+  if (hipMalloc((void **)&dout, (size_t)std::max(n, 1u) * sizeof(double)) != hipSuccess) { (void)hipFree(din); return fail(SVILS_ERR_NOMEM, "hipMalloc failed"); }
+  int rc = 0;
+  if (hipMemcpy(din, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SVILS_ERR_DEVICE, "upload failed");
+  if (!rc) {
+    launch_debug_eval(h->d, which, din, dout, n, h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(SVILS_ERR_DEVICE, "debug eval failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  return rc;
 }
 
 int svils_enable_timing(svils_handle *h, uint32_t kernel_mask) {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
             s += x[v];
           }
           s = group_sum<W>(s);
-          const double inv = 1.0 / s;
+          const double inv = fast_rcp(s);
 #pragma unroll
           for (int v = 0; v < V; ++v) acc[v] = fma(x[v], inv, acc[v]);
           // community tagging, src/linksampling.cc:668-681,704-717: the first
@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
   __shared__ double lds[2 * V * 64];
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
@@ -361,13 +364,13 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
     if (V == 1 && K < (uint32_t)W) {
       // lane K of the group is idle: let it evaluate psi(row sum) in the same digamma call
       const double arg = ((uint32_t)lw == K) ? rs : (kval[0] ? gn[0] : 1.0);
-      const double ps = digamma(arg);
+      const double ps = digamma(arg, logtab);
       const double psi_rs = __shfl(ps, g * W + (int)K, 64);
       el[0] = kval[0] ? ps - psi_rs : 0.0;
     } else {
-      const double psi_rs = digamma(rs);
+      const double psi_rs = digamma(rs, logtab);
 #pragma unroll
-      for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v]) - psi_rs : 0.0;
+      for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
     }
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     // prune / check_and_set_converged, src/linksampling.cc:455-475
@@ -399,6 +402,9 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
 template <int W, int V>
 __global__ __launch_bounds__(256) void k_dir_exp(Geometry geo, DeviceState d) {
   constexpr int G = 64 / W;
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
@@ -412,10 +418,10 @@ __global__ __launch_bounds__(256) void k_dir_exp(Geometry geo, DeviceState d) {
       rs += gn[v];
     }
     rs = group_sum<W>(rs);
-    const double psi_rs = digamma(rs);
+    const double psi_rs = digamma(rs, logtab);
     double el[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v]) - psi_rs : 0.0;
+    for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
   }
 }
@@ -540,6 +546,9 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   // one combined block reduction: {szeros, sones} doubles and {kzeros, dense, sparse, shortcut} counts
   __shared__ double red[2][256];
   __shared__ unsigned long long cred[4][256];
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
   const uint32_t K = geo.K;
   const uint32_t iter = ctrl->iter;
   const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
@@ -566,9 +575,9 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     const double l1 = prm.eta1 + (s1 * s1 - s2 - s3);
     d.lambda[2 * k] = l0;
     d.lambda[2 * k + 1] = l1;
-    const double ps = digamma(l0 + l1);
-    d.elogbeta[2 * k] = digamma(l0) - ps;
-    d.elogbeta[2 * k + 1] = digamma(l1) - ps;
+    const double ps = digamma(l0 + l1, logtab);
+    d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
+    d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
   }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -654,11 +663,27 @@ __global__ __launch_bounds__(256) void k_row_only(DeviceState d, Params prm, dou
 
 // Elogbeta from lambda (set_dir_exp(_lambda, _Elogbeta), src/linksampling.cc:124,563)
 __global__ __launch_bounds__(256) void k_lambda_exp(Geometry geo, DeviceState d) {
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < geo.K; k += gridDim.x * blockDim.x) {
     const double l0 = d.lambda[2 * k], l1 = d.lambda[2 * k + 1];
-    const double ps = digamma(l0 + l1);
-    d.elogbeta[2 * k] = digamma(l0) - ps;
-    d.elogbeta[2 * k + 1] = digamma(l1) - ps;
+    const double ps = digamma(l0 + l1, logtab);
+    d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
+    d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
+  }
+}
+
+// device special functions on plain arrays, for the unit tests (which: 0 digamma, 1 exp_neg,
+// 2 fast_rcp, 3 log_tab)
+__global__ __launch_bounds__(256) void k_debug_eval(DeviceState d, int which, const double *in, double *out,
+                                                    uint32_t n) {
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double x = in[i];
+    out[i] = which == 0 ? digamma(x, logtab) : which == 1 ? exp_neg(x) : which == 2 ? fast_rcp(x) : log_tab(x, logtab);
   }
 }
 
@@ -747,6 +772,9 @@ void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
 }
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
   hipLaunchKernelGGL(k_lambda_exp, dim3((g.K + 255) / 256), dim3(256), 0, s, g, d);
+}
+void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_eval, dim3((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), dim3(256), 0, s, d, which, in, out, n);
 }
 void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
                      hipStream_t s) {

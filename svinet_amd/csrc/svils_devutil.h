@@ -94,6 +94,13 @@ __device__ __forceinline__ void store_row(double *__restrict__ row, int lw, uint
   }
 }
 
+// one v_max_f64 (fmax() adds two canonicalising v_max per call; the inputs here are never NaN)
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ------------------------------------------------------------------- exp(t), t <= 0
 // The softmax only ever needs exp(x - max) with a non-positive argument.  18
 // instructions instead of libm's ~40: clamp, n = rint(t*log2e), two-step Cody-Waite
@@ -120,12 +127,78 @@ __device__ __forceinline__ double exp_neg(double t) {
   return ldexp(p, (int)n);
 }
 
+// N independent exp_neg chains written step-by-step so the Horner recurrences interleave
+// (a single chain is 15 dependent fp64 ops; hipcc schedules separate calls back to back)
+template <int N>
+__device__ __forceinline__ void exp_neg_n(double (&x)[N]) {
+  double n[N], r[N], p[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i] = fmax(x[i], -750.0); n[i] = rint(x[i] * 1.4426950408889634); }
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = fma(n[i], -6.93147180369123816490e-01, x[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = fma(n[i], -1.90821492927058770002e-10, r[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) p[i] = fma(2.51100376059637769e-08, r[i], 2.76326396390410286e-07);
+#define SVILS_EXP_STEP(C)              \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = fma(p[i], r[i], C);
+  SVILS_EXP_STEP(2.75572409185789696e-06)
+  SVILS_EXP_STEP(2.48014854823284939e-05)
+  SVILS_EXP_STEP(1.98412698900471131e-04)
+  SVILS_EXP_STEP(1.38888889523147751e-03)
+  SVILS_EXP_STEP(8.33333333331960115e-03)
+  SVILS_EXP_STEP(4.16666666664880989e-02)
+  SVILS_EXP_STEP(1.66666666666666796e-01)
+  SVILS_EXP_STEP(5.00000000000001887e-01)
+  SVILS_EXP_STEP(1.0)
+  SVILS_EXP_STEP(1.0)
+#undef SVILS_EXP_STEP
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = ldexp(p[i], (int)n[i]);
+}
+
+// ----------------------------------------------------------------- 1/x and ln(y)
+// v_rcp_f64 seed + two Newton steps (5 instructions, <= 1-2 ulp) instead of the IEEE
+// division sequence (~25 instructions: div_scale x2, rcp, 5 fma, div_fmas, div_fixup)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// ln(y) for normal y > 0 (digamma only calls it with y >= 10): split y = 2^e * m, m in [1,2);
+// 128-entry table {1/c_i, ln c_i} at the interval centres, r = m/c_i - 1 (|r| < 2^-8), degree-7
+// log1p series.  ~20 instructions against ~150 for libm's extended-precision log; 1 ulp
+// (2.2e-16 max relative error vs mpmath on [10, 1e12]).  `tab` lives in LDS (load_logtab).
+__device__ __forceinline__ double log_tab(double y, const double2 *tab) {
+  const int hi = __double2hiint(y), lo = __double2loint(y);
+  const int e = (hi >> 20) - 1023;
+  const int i = (hi >> 13) & 127;
+  const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
+  const double2 t = tab[i];
+  const double r = fma(m, t.x, -1.0);
+  double p = 1.0 / 7.0;
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p, r, 1.0);
+  const double ed = (double)e;
+  return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, fma(p, r, t.y)));
+}
+// copy the 2 KiB table from global memory into LDS (call once per block, then __syncthreads())
+__device__ __forceinline__ void load_logtab(double2 *lds_tab, const double *gtab) {
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) lds_tab[i] = make_double2(gtab[2 * i], gtab[2 * i + 1]);
+}
+
 // ----------------------------------------------------------------- digamma
 // psi(x), x > 0, double-accurate (stands where the reference calls gsl_sf_psi,
-// src/linksampling.hh:181,184).  x < 10 is shifted by 10 with ONE division:
+// src/linksampling.hh:181,184).  x < 10 is shifted by 10 with ONE reciprocal:
 // sum_{i<10} 1/(x+i) = Q'(x)/Q(x), Q = prod (x+i); then the asymptotic series at
-// y = x+10 >= 10 (error < 4e-17).  Max error vs mpmath 1.5e-15 relative.
-__device__ __forceinline__ double digamma(double x) {
+// y = x+10 >= 10 (error < 4e-17).  ~65 instructions; max error vs mpmath 2e-15 relative.
+__device__ __forceinline__ double digamma(double x, const double2 *tab) {
   double shift = 0.0, y = x, xi;
   if (x < 10.0) {
     double Q = x, Qd = 1.0;
@@ -136,11 +209,11 @@ __device__ __forceinline__ double digamma(double x) {
       Q *= t;
     }
     y = x + 10.0;
-    const double r = 1.0 / (Q * y);
+    const double r = fast_rcp(Q * y);
     shift = Qd * y * r;
     xi = Q * r;
   } else {
-    xi = 1.0 / y;
+    xi = fast_rcp(y);
   }
   const double xi2 = xi * xi;
   const double ser =
@@ -149,7 +222,7 @@ __device__ __forceinline__ double digamma(double x) {
                     xi2 * (1.0 / 252.0 -
                            xi2 * (1.0 / 240.0 -
                                   xi2 * (1.0 / 132.0 - xi2 * (691.0 / 32760.0 - xi2 * (1.0 / 12.0)))))));
-  return log(y) - 0.5 * xi - ser - shift;
+  return log_tab(y, tab) - 0.5 * xi - ser - shift;
 }
 
 // per-block link statistics without atomics: every wave's counts go through LDS,

@@ -95,6 +95,7 @@ struct DeviceState {
   double *rows;         // [rows_cap][10]
   uint32_t rows_cap;
   DevCtrl *ctrl;
+  const double *logtab;      // [128][2] {1/c_i, ln c_i} for log_tab()
   unsigned long long *prof;  // [16] cycle counters of instrumented builds (-DSVILS_PROF)
 };
 
@@ -121,6 +122,7 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s);
 void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
                      hipStream_t s);
 bool pick_layout(uint32_t K, int *W, int *V);

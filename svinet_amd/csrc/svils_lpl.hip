@@ -47,14 +47,18 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
   const bool sparse_iter = ctrl->iter > 1000;  // src/linksampling.cc:634
-  const bool full_k = (K == (uint32_t)KR);      // no padding columns (e.g. K = 20, 28)
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
   const double *__restrict__ elogpi = d.elogpi;
   double *mylds = lds[wave];
 
+  // Elogbeta[.][0], wave-uniform but kept in VGPRs on purpose: as KR scalar pairs it made the
+  // SGPR file spill through v_writelane/v_readlane inside the hot loop.  Padding columns
+  // (k >= K) get -inf, which masks them in the softmax without any select.
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   double eb[KR];
 #pragma unroll
-  for (int k = 0; k < KR; ++k) eb[k] = d.elogbeta[2 * (k < (int)K ? k : 0)];
+  for (int k = 0; k < KR; ++k) eb[k] = (k < (int)K) ? d.elogbeta[2 * k + vzero] : NEG_INF;
   double csum = 0.0;  // lane k: partial of sum[k]
   unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
 #ifdef SVILS_PROF
@@ -113,25 +117,27 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
         // branch-free from here so the KR independent exp chains interleave
         double m = NEG_INF;
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-          if (!full_k) phi[k] = (k < (int)K) ? phi[k] : NEG_INF;   // padding columns
-          m = fmax(m, phi[k]);
-        }
+        for (int k = 0; k < KR; ++k) m = max_f64(m, phi[k]);   // padding columns are -inf via eb[]
         if (m != NEG_INF) {
           int best = 0;
 #pragma unroll
           for (int k = KR - 1; k >= 0; --k) best = (phi[k] == m) ? k : best;   // first strict maximum
           double s = 0.0;
+          // KR is even: exps in interleaved groups of 4 (or 2 for the tail)
 #pragma unroll
-          for (int k = 0; k < KR; ++k) {
-#ifdef ABL_NO_EXP
-            phi[k] = (phi[k] - m) * 0.001 + 1.0;
-#else
-            phi[k] = exp_neg(phi[k] - m);   // exp_neg(-inf) == 0 for masked / padding columns
-#endif
-            s += phi[k];
+          for (int k0 = 0; k0 + 4 <= KR; k0 += 4) {
+            double t[4] = {phi[k0] - m, phi[k0 + 1] - m, phi[k0 + 2] - m, phi[k0 + 3] - m};
+            exp_neg_n<4>(t);   // exp_neg(-inf) == 0 for masked / padding columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { phi[k0 + j] = t[j]; s += t[j]; }
           }
-          const double inv = 1.0 / s;
+          if constexpr (KR % 4 != 0) {
+            double t[2] = {phi[KR - 2] - m, phi[KR - 1] - m};
+            exp_neg_n<2>(t);
+            phi[KR - 2] = t[0]; phi[KR - 1] = t[1];
+            s += t[0]; s += t[1];
+          }
+          const double inv = fast_rcp(s);
 #pragma unroll
           for (int k = 0; k < KR; ++k) phi[k] *= inv;
           // community tagging: the first strict maximum of phi is 1/s
