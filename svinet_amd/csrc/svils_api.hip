@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -381,6 +382,10 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
 
   int rc = 0;
   auto guard = [&](int r) { if (r && !rc) rc = r; };
+  // tuning overrides (experiments only): SVILS_NB_A / SVILS_NB_B / SVILS_NB_C = grid sizes
+  if (const char *e = getenv("SVILS_NB_A")) d.nb_a = cap(strtoul(e, nullptr, 10), 65535);
+  if (const char *e = getenv("SVILS_NB_B")) d.nb_b = cap(strtoul(e, nullptr, 10), 65535);
+  if (const char *e = getenv("SVILS_NB_C")) d.nb_c = cap(strtoul(e, nullptr, 10), 65535);
   guard(dalloc(h, &d.rowptr, (size_t)n + 1, false));
   guard(dalloc(h, &d.col, col.size(), false));
   guard(dalloc(h, &d.upper, n, false));

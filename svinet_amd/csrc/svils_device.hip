@@ -230,12 +230,13 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
   }
   lds[seg][cl] = s;
   __syncthreads();
-  if (seg == 0 && c < j.ncols) {
-    double t = 0.0;
+  // fixed-order tree over the 64 row segments
 #pragma unroll
-    for (int i = 0; i < 64; ++i) t += lds[i][cl];
-    j.out[c] = t;
+  for (int o = 32; o > 0; o >>= 1) {
+    if (seg < o) lds[seg][cl] += lds[seg + o][cl];
+    __syncthreads();
   }
+  if (seg == 0 && c < j.ncols) j.out[c] = lds[0][cl];
 }
 
 // ======================================= node finalise (A7 + swap + A5 + A9)
@@ -541,8 +542,9 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
 // likelihood row, stop rule and annealing switch of validation_likelihood
 // (:994-1049), write_comm for the next sweep (:768-774) and _iter++ (:787).
 __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Params prm) {
-  DevCtrl *ctrl = d.ctrl;
-  if (ctrl->stopped) return;
+  // the control block is read once, updated in registers by thread 0 and written back once
+  DevCtrl c = *d.ctrl;
+  if (c.stopped) return;
   // one combined block reduction: {szeros, sones} doubles and {kzeros, dense, sparse, shortcut} counts
   __shared__ double red[2][256];
   __shared__ unsigned long long cred[4][256];
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   load_logtab(logtab, d.logtab);
   __syncthreads();
   const uint32_t K = geo.K;
-  const uint32_t iter = ctrl->iter;
+  const uint32_t iter = c.iter;
   const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
   double sz = 0.0, so = 0.0;
   unsigned long long kz = 0, t0 = 0, t1 = 0, t2 = 0;
@@ -590,41 +592,42 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    ctrl->parity ^= 1u;  // prune()'s flags become current
-    ctrl->links_dense = cred[1][0]; ctrl->links_sparse = cred[2][0]; ctrl->links_shortcut = cred[3][0];
-    ctrl->sweeps_done++;
-    ctrl->write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+    c.parity ^= 1u;  // prune()'s flags become current
+    c.links_dense = cred[1][0]; c.links_sparse = cred[2][0]; c.links_shortcut = cred[3][0];
+    c.sweeps_done++;
+    c.write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
     bool exit_now = false;
     if (do_val) {
       const double szeros = red[0][0], sones = red[1][0];
       const uint32_t kzeros = (uint32_t)cred[0][0], kones = d.nv - kzeros;
       const double mean0 = szeros / kzeros, mean1 = sones / kones;
       const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
-      double *row = d.rows + (size_t)(ctrl->rows % d.rows_cap) * 10;
+      double *row = d.rows + (size_t)(c.rows % d.rows_cap) * 10;
       row[0] = (double)iter; row[1] = (szeros + sones) / d.nv; row[2] = (double)d.nv;
       row[3] = mean0; row[4] = (double)kzeros; row[5] = mean1; row[6] = (double)kones;
       row[7] = prm.zeros_prob * mean0; row[8] = prm.ones_prob * mean1; row[9] = a;
-      ctrl->rows++;
+      c.rows++;
       bool stop = false;
       int why = -1;
       if (iter > 10) {
-        const double prev = ctrl->prev_h;
+        const double prev = c.prev_h;
         if (a > prev && prev != 0 && fabs((a - prev) / prev) < 0.00001) { stop = true; why = 100; }
-        else if (a < prev) ctrl->nh++;
-        else if (a > prev) ctrl->nh = 0;
-        if (a > ctrl->max_h) ctrl->max_h = a;
-        if (ctrl->nh > 2) { why = 1; stop = true; }
+        else if (a < prev) c.nh++;
+        else if (a > prev) c.nh = 0;
+        if (a > c.max_h) c.max_h = a;
+        if (c.nh > 2) { why = 1; stop = true; }
       }
-      ctrl->prev_h = a;
-      if (ctrl->annealing && stop) {
-        ctrl->annealing = 0; ctrl->nh = 0; ctrl->prev_h = 0;  // max.txt keeps the pre-switch `why`
-      } else if (!ctrl->annealing && stop) {
+      c.prev_h = a;
+      if (c.annealing && stop) {
+        c.annealing = 0; c.nh = 0; c.prev_h = 0;  // max.txt keeps the pre-switch `why`
+      } else if (!c.annealing && stop) {
         if (prm.use_validation_stop) exit_now = true;
       }
-      ctrl->why = why;
+      c.why = why;
     }
-    if (exit_now) ctrl->stopped = 1;  // do_on_stop(); exit(0): _iter is not advanced
-    else ctrl->iter = iter + 1;
+    if (exit_now) c.stopped = 1;  // do_on_stop(); exit(0): _iter is not advanced
+    else c.iter = iter + 1;
+    *d.ctrl = c;
   }
 }
 

@@ -1,0 +1,71 @@
+"""-m gpu: randomized small graphs / community counts against the oracle (both
+kernel layouts: lane-per-link for K <= 32, row-per-wavefront above), including
+declared-but-absent nodes, duplicate and reversed input lines, hubs, tiny K, the
+converged shortcuts (forced by seeding converged flags) and the active-set path."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_graph(rng, n, m):
+    a = rng.integers(0, n, size=m)
+    b = rng.integers(0, n, size=m)
+    pairs = np.stack([a, b], 1)
+    pairs = np.concatenate([pairs, pairs[: m // 7, ::-1], pairs[: m // 11]])      # reversed + duplicate lines
+    hub = np.stack([np.full(n // 3, int(rng.integers(0, n))), rng.integers(0, n, size=n // 3)], 1)
+    return (np.concatenate([pairs, hub]) * 3 + 5).astype(np.int32)                # non-contiguous external ids
+
+
+CASES = [(seed, n, k) for seed, (n, k) in enumerate([(12, 1), (30, 2), (40, 3), (64, 5), (100, 8), (130, 9), (150, 16),
+                                                    (200, 17), (257, 24), (300, 31), (300, 32), (120, 33), (90, 40),
+                                                    (80, 63), (70, 64), (60, 65), (50, 70), (45, 129)])]
+
+
+@pytest.mark.parametrize("seed,n,k", CASES)
+def test_random_graph(seed, n, k):
+    from svinet_amd.host_api import Setup
+    rng = np.random.default_rng(1000 + seed)
+    pairs = _random_graph(rng, n, 6 * n)
+    declared = n + int(rng.integers(0, 5))
+    hr = float(rng.choice([0.0, 0.02, 0.05]))
+    s = Setup(n=declared, k=k, pairs=pairs, heldout_ratio=hr, seed=seed)
+    ref = O.LinkSampling(O.Network(n=declared, pairs=pairs), k, heldout_ratio=hr, seed=seed, use_validation_stop=False)
+    if s.validation_sorted.shape[0] == 0:
+        ref.set_skip_validation(True)
+    assert np.array_equal(s.links, ref.links) and np.array_equal(s.gamma, ref.gamma)
+    eng = s.engine(use_validation_stop=False)
+
+    def both(nsw):
+        for _ in range(nsw):
+            ref.sweep()
+        eng.sweep(nsw)
+
+    def check(tag):
+        g, lam, conv = eng.state()
+        assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-7, tag
+        assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-7, tag
+        assert np.array_equal(conv, ref.converged), tag
+        assert np.array_equal(eng.communities(), ref.communities()), tag
+        c = eng.control()
+        assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts(), tag
+
+    both(4)
+    check("dense")
+    # force the one-converged shortcuts: mark a third of the nodes converged on both sides
+    conv = np.zeros(s.n, dtype=np.uint32)
+    idx = rng.choice(s.n, size=s.n // 3, replace=False)
+    conv[idx] = rng.integers(1, k + 1, size=idx.size)      # includes k itself => quirk Q2 (pc == K)
+    g, lam, _ = eng.state()
+    ref.set_converged(conv)
+    eng.set_state(g, lam, conv)
+    ref.set_gamma(g); ref.set_lambda(lam); ref.refresh()
+    both(3)
+    check("shortcuts")
+    # active-set path
+    ref.iter = 1500
+    eng.set_control(iter=1500)
+    both(3)
+    check("sparse")
