@@ -262,7 +262,6 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   d.rows_cap = 1u << 16;
   guard(dalloc(h, &d.rows, (size_t)d.rows_cap * 10));
   guard(dalloc(h, &d.ctrl, 1));
-  guard(dalloc(h, &d.prof, 16));
   {
     double *lt = nullptr;
     guard(dalloc(h, &lt, 256, false));
@@ -382,10 +381,6 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
 
   int rc = 0;
   auto guard = [&](int r) { if (r && !rc) rc = r; };
-  // tuning overrides (experiments only): SVILS_NB_A / SVILS_NB_B / SVILS_NB_C = grid sizes
-  if (const char *e = getenv("SVILS_NB_A")) d.nb_a = cap(strtoul(e, nullptr, 10), 65535);
-  if (const char *e = getenv("SVILS_NB_B")) d.nb_b = cap(strtoul(e, nullptr, 10), 65535);
-  if (const char *e = getenv("SVILS_NB_C")) d.nb_c = cap(strtoul(e, nullptr, 10), 65535);
   guard(dalloc(h, &d.rowptr, (size_t)n + 1, false));
   guard(dalloc(h, &d.col, col.size(), false));
   guard(dalloc(h, &d.upper, n, false));
@@ -604,10 +599,6 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
       return 0;
     case 3:
       HIPCHK(hipMemcpy(out, h->d.active_cnt, g.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      return 0;
-    case 5:
-      HIPCHK(hipMemcpy(out, h->d.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemset(h->d.prof, 0, 16 * sizeof(unsigned long long)));
       return 0;
     case 4: {
       if (!h->have_graph) return fail(SVILS_ERR_ARG, "svils_get_aux: graph not set");

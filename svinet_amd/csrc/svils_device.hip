@@ -741,9 +741,14 @@ void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, h
 }
 void launch_s3(const Geometry &g, const DeviceState &d, hipStream_t s) {
   if (d.lpl) { launch_s3_lpl(g, d, s); return; }
-#define CALL(W_, V_) hipLaunchKernelGGL((k_s3<W_, V_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
-  SVILS_DISPATCH(g, CALL);
-#undef CALL
+  switch (g.V) {   // K > 32 => W == 64
+    case 1: hipLaunchKernelGGL((k_s3<64, 1>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+    case 2: hipLaunchKernelGGL((k_s3<64, 2>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+    case 4: hipLaunchKernelGGL((k_s3<64, 4>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+    case 8: hipLaunchKernelGGL((k_s3<64, 8>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+    case 16: hipLaunchKernelGGL((k_s3<64, 16>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+    default: hipLaunchKernelGGL((k_s3<64, 32>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+  }
 }
 void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const ReduceJob j0{d.part_b, d.kvec_c, d.nb_b, 2 * g.K};

@@ -31,8 +31,7 @@ struct DevCtrl {
   int32_t why;
   uint32_t sweeps_done;
   uint32_t rows;
-  unsigned long long links_dense, links_sparse, links_shortcut;       // published (last sweep)
-  unsigned long long cur_dense, cur_sparse, cur_shortcut;             // being counted
+  unsigned long long links_dense, links_sparse, links_shortcut;       // of the last sweep
   uint32_t parity;  // conv[parity] is the current _converged, conv[parity^1] receives prune()'s
   uint32_t pad;
 };
@@ -96,7 +95,6 @@ struct DeviceState {
   uint32_t rows_cap;
   DevCtrl *ctrl;
   const double *logtab;      // [128][2] {1/c_i, ln c_i} for log_tab()
-  unsigned long long *prof;  // [16] cycle counters of instrumented builds (-DSVILS_PROF)
 };
 
 struct Params {

@@ -61,18 +61,8 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
   for (int k = 0; k < KR; ++k) eb[k] = (k < (int)K) ? d.elogbeta[2 * k + vzero] : NEG_INF;
   double csum = 0.0;  // lane k: partial of sum[k]
   unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
-#ifdef SVILS_PROF
-  long long pt[6] = {0, 0, 0, 0, 0, 0};
-  const long long pstart = clock64();
-#define PROF_MARK(i) do { const long long now_ = clock64(); pt[i] += now_ - plast; plast = now_; } while (0)
-#else
-#define PROF_MARK(i)
-#endif
 
   for (uint32_t it = blockIdx.x * NW + wave; it < d.lpl_nitems; it += gridDim.x * NW) {
-#ifdef SVILS_PROF
-    long long plast = clock64();
-#endif
     const uint64_t e = (d.lpl_w0 + it) * 64 + lane;
     const bool valid = e >= d.ent_begin && e < d.ent_end;
     uint32_t p = 0xffffffffu, q = 0;
@@ -81,19 +71,19 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
       q = d.col[e];
     }
     double phi[KR];
-#pragma unroll
-    for (int k = 0; k < KR; ++k) phi[k] = 0.0;
+    double *mine = mylds + lane * SROW;   // this lane's staged phi row
     int tagk = -1;   // community this link tags (src/linksampling.cc:668-681,704-717), -1: none
+    int one_at = -1; // >= 0: the row is the unit vector e_c (converged shortcut), stored straight to LDS
+    bool dense_row = false;
     if (valid) {
       const uint32_t pc = conv[p], qc = conv[q];
       const bool count_me = q > p;
       if ((pc != 0) != (qc != 0)) {
         // exactly one endpoint converged: src/linksampling.cc:622-631
-        const int c = (int)(pc ? pc : qc) - 1;
-#pragma unroll
-        for (int k = 0; k < KR; ++k) phi[k] = (k == c) ? 1.0 : 0.0;
+        one_at = (int)(pc ? pc : qc) - 1;
         n_short += count_me;
       } else {
+        dense_row = true;
         // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686)
         {
           const double *rp = elogpi + (size_t)p * ld, *rq = elogpi + (size_t)q * ld;
@@ -141,27 +131,27 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
 #pragma unroll
           for (int k = 0; k < KR; ++k) phi[k] *= inv;
           // community tagging: the first strict maximum of phi is 1/s
-#ifndef ABL_NO_TAG
           if (write_comm && inv > prm.link_thresh) tagk = best;
-#endif
         } else {
-#pragma unroll
-          for (int k = 0; k < KR; ++k) phi[k] = 0.0;  // empty active-set union (:642-664)
+          dense_row = false;  // empty active-set union (:642-664): the row is zero
         }
         if (count_me) { if (sparse) n_sparse++; else n_dense++; }
       }
     }
-    PROF_MARK(0);
-    // stage the 64 phi rows
-    double *mine = mylds + lane * SROW;
+    // stage the 64 phi rows: dense rows from registers; shortcut / invalid / empty rows as
+    // zeros (+ a single 1.0) without ever materialising them in registers
+    if (dense_row) {
 #pragma unroll
-    for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(phi[2 * c], phi[2 * c + 1]);
+      for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(phi[2 * c], phi[2 * c + 1]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(0.0, 0.0);
+      if (one_at >= 0) mine[one_at] = 1.0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    PROF_MARK(1);
     // lane k sums column k over the rows in entry order, flushing at node boundaries
-#ifndef ABL_NO_COL
     {
       // heads of the node runs: bit r set <=> row r starts a new node
       const uint32_t pprev = __shfl_up((int)p, 1, 64);
@@ -221,21 +211,9 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
 #undef LPL_FLUSH
       }
     }
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    PROF_MARK(2);
   }
-#ifdef SVILS_PROF
-  if (lane == 0) {
-    atomicAdd(&d.prof[0], (unsigned long long)pt[0]);
-    atomicAdd(&d.prof[1], (unsigned long long)pt[1]);
-    atomicAdd(&d.prof[2], (unsigned long long)pt[2]);
-    atomicAdd(&d.prof[3], (unsigned long long)(clock64() - pstart));
-    atomicAdd(&d.prof[4], 1ull);
-    atomicMax(&d.prof[5], (unsigned long long)(clock64() - pstart));
-  }
-#endif
 
   // per-block partial of `sum`: waves in order
   red[wave][lane] = csum;

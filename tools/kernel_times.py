@@ -19,11 +19,3 @@ eng.sweep(steps); eng.synchronize()
 t = eng.timing()
 tot = sum(v[0] for v in t.values())
 print(os.environ.get("SVILS_LIB", "default"), wl, " ".join("%s=%.1fus" % (k, v[0] / max(v[1], 1) * 1e3) for k, v in t.items()), "sum=%.1fus" % (tot / steps * 1e3))
-if "prof" in os.environ.get("SVILS_LIB", ""):
-    import numpy as np, ctypes
-    from svinet_amd import _svils
-    out = np.zeros(16, dtype=np.uint64)
-    _svils._chk(_svils.load().svils_get_aux(eng._h, 5, out.ctypes.data))
-    nw = max(int(out[4]), 1)
-    print("prof: waves=%d per-wave cycles: compute=%.0f stage=%.0f col=%.0f total=%.0f max_total=%d (sweeps=%d)" % (
-        nw, out[0] / nw, out[1] / nw, out[2] / nw, out[3] / nw, out[5], steps + 5))
