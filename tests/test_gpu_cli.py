@@ -107,3 +107,20 @@ def test_cli_accuracy_and_load_validation(graph_files, tmp_path):
     assert len(ve) == len(pairs)
     v = np.loadtxt(d / "validation.txt")
     assert v.shape == (5, 11) and int(v[0, 3]) == len(pairs)
+
+
+def test_cli_max_iterations_one(graph_files, tmp_path):
+    """-max-iterations 1 forces write_comm from the first sweep (src/linksampling.cc:581-582)"""
+    r = _run(["-file", graph_files["assort"], "-n", "75", "-k", "4", "-link-sampling", "-no-stop",
+              "-max-iterations", "1", "-label", "one"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n75-k4-one-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4, use_validation_stop=False, max_iterations=1)
+    n = 0
+    while ref.sweep() == 0:
+        n += 1
+    assert n == 2
+    rd = tmp_path / "ref_one"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()

@@ -69,3 +69,45 @@ def test_random_graph(seed, n, k):
     eng.set_control(iter=1500)
     both(3)
     check("sparse")
+
+
+@pytest.mark.parametrize("k,n", [(600, 40), (1100, 30), (2048, 64)])
+def test_large_k_layouts(k, n):
+    """V = 16 and V = 32 register layouts (K up to SVILS_MAX_K)"""
+    from svinet_amd.host_api import Setup
+    rng = np.random.default_rng(k)
+    pairs = _random_graph(rng, n, 5 * n)
+    s = Setup(n=n, k=k, pairs=pairs, heldout_ratio=0.05)
+    ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, heldout_ratio=0.05, use_validation_stop=False)
+    eng = s.engine(use_validation_stop=False)
+    for _ in range(3):
+        ref.sweep()
+    eng.sweep(3)
+    g, lam, conv = eng.state()
+    assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-7
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-7
+    assert np.array_equal(eng.communities(), ref.communities())
+    np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("rfreq", [2, 3, 5])
+def test_reportfreq(graph_files, rfreq):
+    """-rfreq after -link-sampling: likelihood every rfreq sweeps, tagging only on the sweep
+    before a report (src/linksampling.cc:768-787)"""
+    from svinet_amd.host_api import Setup
+    s = Setup(graph_files["assort"], 75, 4)
+    ref = O.LinkSampling(O.Network(graph_files["assort"], 75), 4, reportfreq=rfreq)
+    eng = s.engine(reportfreq=rfreq)
+    n = 0
+    while ref.sweep() != 2:
+        n += 1
+        assert n < 3000
+    eng.sweep(n + 1 + 4)
+    c = eng.control()
+    assert c.stopped == 1 and c.iter == ref.iter and c.sweeps_done == n + 1
+    g, lam, conv = eng.state()
+    assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-7
+    assert np.array_equal(eng.communities(), ref.communities())
+    rows = eng.rows()
+    assert np.array_equal(rows[:, 0], ref.rows[1:, 0]) and np.all(rows[:, 0] % rfreq == 0)
+    np.testing.assert_allclose(rows[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
