@@ -164,19 +164,23 @@ const char *svils_kernel_name(int kernel);
 /* ---- multi-GPU hooks (one process per GPU; collectives stay with the caller) */
 /* The sweep split at its two exchange points.  With node-block ownership each
  * handle runs phase A on its rows, the caller all-reduces the K-vector partial
- * buffer, phase B finalises the owned rows, the caller all-gathers the row
- * blocks, phase C does the s3 pass on owned rows, the caller all-reduces the
- * second K-vector buffer, and phase D (replicated) closes the sweep.
- * svils_sweep() == A,B,C,D with no exchange. */
-typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D } svils_phase;
+ * buffer, phase B finalises the owned rows, the caller all-gathers the gamma row
+ * blocks (+ the converged / active flags), phase EXPAND re-derives Elogpi (digamma)
+ * and the mean indicators m = (gamma/scale - alpha)/(n-1) of the rows it does NOT
+ * own from the gathered gamma -- so only ONE n-by-k array crosses the links per
+ * sweep instead of three --, phase C does the s3 pass on owned rows, the caller
+ * all-reduces the second K-vector buffer, and phase D (replicated) closes the
+ * sweep.  svils_sweep() == A,B,C,D with no exchange (EXPAND is a no-op when the
+ * handle owns every row). */
+typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D, SVILS_PHASE_EXPAND } svils_phase;
 int svils_sweep_phase(svils_handle *h, svils_phase phase);
 
 typedef enum {
   SVILS_BUF_KVEC_A = 0,   /* double[k]   : sum (phase A -> all-reduce SUM)          */
   SVILS_BUF_KVEC_C,       /* double[3k+4]: s1,s2,s3, validation partials (C -> SUM) */
   SVILS_BUF_GAMMA,        /* double[n_pad][ld] rows, all-gather by node block      */
-  SVILS_BUF_ELOGPI,       /* double[n_pad][ld]                                      */
-  SVILS_BUF_MPHI,         /* double[n_pad][ld]                                      */
+  SVILS_BUF_ELOGPI,       /* double[n_pad][ld]  (re-derived by EXPAND; exchange optional) */
+  SVILS_BUF_MPHI,         /* double[n_pad][ld]  (re-derived by EXPAND; exchange optional) */
   SVILS_BUF_CONV,         /* uint32[n_pad] new converged flags                      */
   SVILS_BUF_ACTIVE,       /* uint32[n_pad] active_comms                             */
   SVILS_BUF_AMASK,        /* uint64[n_pad][kw] active-set bitmask                   */

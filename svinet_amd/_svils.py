@@ -109,7 +109,7 @@ def _chk(rc):
 
 BUF_KVEC_A, BUF_KVEC_C, BUF_GAMMA, BUF_ELOGPI, BUF_MPHI, BUF_CONV, BUF_ACTIVE, BUF_AMASK, \
     BUF_MEMBER = range(9)
-PHASE_A, PHASE_B, PHASE_C, PHASE_D = range(4)
+PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND = range(5)
 
 
 class Engine:

@@ -132,6 +132,9 @@ int run_phase(svils_handle *h, svils_phase ph) {
       { Timed t(h, SVILS_KERNEL_S3); launch_s3(g, d, s); }
       { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
     } break;
+    case SVILS_PHASE_EXPAND: {
+      launch_expand(g, d, h->prm, s);
+    } break;
     case SVILS_PHASE_D: {
       { Timed t(h, SVILS_KERNEL_VALIDATION); launch_validation(g, d, h->prm, 1, s); }
       { Timed t(h, SVILS_KERNEL_TAIL); launch_tail(g, d, h->prm, s); }

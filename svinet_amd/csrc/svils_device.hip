@@ -427,6 +427,52 @@ __global__ __launch_bounds__(256) void k_dir_exp(Geometry geo, DeviceState d) {
   }
 }
 
+// Multi-GPU: Elogpi and mphi of the rows this handle does not own, re-derived from the
+// all-gathered gamma instead of being exchanged.  gamma_new = (alpha + acc (n-1)/tl) * scale with
+// m = acc/tl (compute_mean_indicators, src/linksampling.cc:536-542)  =>  m = (gamma/scale - alpha)/(n-1).
+// Rows without a training link (gamma == alpha) never enter the s3 pass; their mphi is set to 0.
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Params prm) {
+  const DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  constexpr int G = 64 / W;
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool annealing = ctrl->annealing != 0;
+  bool kval[V];
+  double iscale[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int k = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)k < K;
+    iscale[v] = (annealing && kval[v]) ? d.kvec_a[k] / (double)prm.ones : 1.0;   // 1 / (ones / sum[k])
+  }
+  const double inv_nm1 = 1.0 / ((double)geo.n - 1.0);
+  const uint32_t nown = geo.node_end - geo.node_begin, nother = geo.n - nown;
+  for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < nother; i += gridDim.x * 4 * G) {
+    const uint32_t p = i < geo.node_begin ? i : i + nown;
+    double gn[V];
+    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    double rs = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { if (!kval[v]) gn[v] = 0.0; rs += gn[v]; }
+    rs = group_sum<W>(rs);
+    const double psi_rs = digamma(rs, logtab);
+    double el[V], m[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
+      m[v] = kval[v] ? (gn[v] * iscale[v] - prm.alpha) * inv_nm1 : 0.0;
+    }
+    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+  }
+}
+
 // ================================================================ s3 pass (A8)
 // src/linksampling.cc:731-746 over the upper half (q > p) of each owned row,
 // including quirk Q2 (mphi[q][pc], one past the converged community).
@@ -769,6 +815,16 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
 }
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, g, d, p);
+}
+void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  const uint32_t nother = g.n - (g.node_end - g.node_begin);
+  if (nother == 0) return;
+  const int G = 64 / g.W;
+  uint32_t nb = (nother + 4 * G - 1) / (4 * G);
+  if (nb > 2048) nb = 2048;
+#define CALL(W_, V_) hipLaunchKernelGGL((k_expand<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, p)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
 }
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const int G = 64 / g.W;

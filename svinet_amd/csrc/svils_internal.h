@@ -118,6 +118,7 @@ void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
                        hipStream_t s);
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s);

@@ -8,8 +8,10 @@ multi-GPU form of the sums inside LinkSampling::infer()
 (src/linksampling.cc:605-761):
 
   phase A  phi pass over owned rows      -> all-reduce(SUM)  `sum[k]`           (K doubles)
-  phase B  mean indicators, new gamma,   -> all-gather by node block of gamma,
-           Elogpi, prune over owned rows    Elogpi, mphi rows + converged / active flags
+  phase B  mean indicators, new gamma,   -> all-gather by node block of the gamma rows
+           Elogpi, prune over owned rows    + converged / active flags (ONE n-by-k array)
+  EXPAND   Elogpi = psi(gamma)-psi(sum) and m = (gamma/scale - alpha)/(n-1) of the rows owned
+           by other ranks, re-derived locally from the gathered gamma (no exchange)
   phase C  s3 pass over owned upper rows -> all-reduce(SUM)  s1,s2,s3          (3K doubles)
   phase D  lambda, likelihood, stop rule    (replicated, identical on every rank)
 
@@ -70,7 +72,7 @@ class HipShard:
         self.kvec_a, _ = t(_svils.BUF_KVEC_A, "<f8")
         self.kvec_c, _ = t(_svils.BUF_KVEC_C, "<f8")
         self.rows = []
-        for which in (_svils.BUF_GAMMA, _svils.BUF_ELOGPI, _svils.BUF_MPHI):
+        for which in (_svils.BUF_GAMMA,):     # Elogpi / mphi are re-derived by PHASE_EXPAND
             ten, rb = t(which, "<f8")
             self.rows.append(ten.view(self.n_alloc, rb // 8))
         conv, _ = t(_svils.BUF_CONV, "<i4")
@@ -132,6 +134,7 @@ class ShardedSweep:
                 s.phase(_svils.PHASE_B)
                 for t in s.gather_list():
                     self._allgather_rows(t)
+                s.phase(_svils.PHASE_EXPAND)
                 s.phase(_svils.PHASE_C)
                 self._allreduce(s.kvec_c)
                 s.phase(_svils.PHASE_D)

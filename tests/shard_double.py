@@ -51,13 +51,23 @@ class NumpyShard:
     # ---- surface shared with HipShard ----
     def gather_list(self):
         new = (self.sweeps & 1) ^ 1
-        return [self.t_gamma, self.t_elogpi, self.t_mphi, self.conv[new].view(self.n_alloc, 1), self.active, self.amask]
+        return [self.t_gamma, self.conv[new].view(self.n_alloc, 1), self.active, self.amask]
 
     def end_sweep(self):
         self.sweeps += 1
 
     def phase(self, ph):
-        (self._a, self._b, self._c, self._d)[ph]()
+        (self._a, self._b, self._c, self._d, self._expand)[ph]()
+
+    def _expand(self):
+        # rows of the other ranks: Elogpi and mphi from the gathered gamma
+        n, lo, hi = self.n, self.lo, self.hi
+        oth = np.ones(n, dtype=bool)
+        oth[lo:hi] = False
+        g = self.t_gamma.numpy()[:n][oth]
+        self.t_elogpi.numpy()[:n][oth] = digamma(g) - digamma(g.sum(1, keepdims=True))
+        isc = (self.kvec_a.numpy() / self.ones) if self.annealing else 1.0
+        self.t_mphi.numpy()[:n][oth] = (g * isc - self.alpha) / (n - 1.0)
 
     # ---- phases ----
     def _a(self):

@@ -52,6 +52,7 @@ def test_virtual_ranks_equal_oracle(graph_files, world, k, sweeps):
                         lists[dst][i][src * B:(src + 1) * B].copy_(lists[src][i][src * B:(src + 1) * B])
         sync()
         for s in shards:
+            s.phase(_svils.PHASE_EXPAND)
             s.phase(_svils.PHASE_C)
         sync()
         _exchange_sum([s.kvec_c for s in shards])
