@@ -111,3 +111,34 @@ def test_reportfreq(graph_files, rfreq):
     rows = eng.rows()
     assert np.array_equal(rows[:, 0], ref.rows[1:, 0]) and np.all(rows[:, 0] % rfreq == 0)
     np.testing.assert_allclose(rows[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+
+
+def test_empty_and_tiny_graphs():
+    """degenerate inputs through the C ABI: no training link at all, and an 8-node ring"""
+    from svinet_amd._svils import Engine
+    rng = np.random.default_rng(5)
+    for k in (4, 40):
+        n = 6
+        eng = Engine(n, k, ones=0, ones_prob=0.0, use_validation_stop=False)
+        eng.set_graph(np.zeros((0, 2), dtype=np.uint32))
+        eng.set_validation(np.zeros((0, 3), dtype=np.uint32))
+        eng.set_state(rng.uniform(0.5, 2.0, size=(n, k)), np.ones((k, 2)))
+        eng.sweep(2)
+        g, lam, conv = eng.state()
+        assert np.all(g == 1.0 / k)                      # gammanext stays alpha without links (:532-533)
+        assert np.all(lam[:, 0] == 1.0) and np.all(lam[:, 1] == 1.0)
+        assert eng.control().iter == 2 and eng.control().links_dense == 0
+        # the smallest non-degenerate graph: a ring of 8 nodes (with fewer nodes than 2*degree+1 the
+        # reference's own non-link correction n - tl - 1 goes negative and it produces NaN)
+        pairs = np.array([[i, (i + 1) % 8] for i in range(8)], dtype=np.int32)
+        ref = O.LinkSampling(O.Network(n=8, pairs=pairs), k, heldout_ratio=0.0, use_validation_stop=False)
+        ref.set_skip_validation(True)
+        e2 = Engine(8, k, ones=8, ones_prob=ref.ones_prob, use_validation_stop=False)
+        e2.set_graph(ref.links)
+        e2.set_validation(np.zeros((0, 3), dtype=np.uint32))
+        e2.set_state(ref.gamma, ref.lam)
+        for _ in range(3):
+            ref.sweep()
+        e2.sweep(3)
+        g, lam, conv = e2.state()
+        assert np.allclose(g, ref.gamma, rtol=1e-10) and np.allclose(lam, ref.lam, rtol=1e-10)
