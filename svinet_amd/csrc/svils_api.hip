@@ -53,6 +53,10 @@ struct svils_handle {
   Params prm;
   hipStream_t stream = nullptr;
   bool have_graph = false, have_state = false;
+  // hipGraph replay of whole sweeps (host launch cost: 8 launches x ~7 us per sweep eager)
+  static constexpr uint32_t kGraphSweeps = 8;
+  hipGraphExec_t gexec1 = nullptr, gexecN = nullptr;   // 1 sweep / kGraphSweeps sweeps
+  bool graphs_ok = true;                               // false after a capture failure: stay eager
   std::vector<void *> allocs;
   double *row_scratch = nullptr;  // device [10]
   // timing
@@ -304,6 +308,8 @@ int svils_destroy(svils_handle *h) {
   for (int i = 0; i < SVILS_KERNEL_COUNT; ++i)
     for (auto &ev : h->pending[i]) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   for (auto &ev : h->freelist) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
+  if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -428,6 +434,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
 
 int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) {
   if (!h || (!pairs_y && nv)) return fail(SVILS_ERR_ARG, "svils_set_validation: null argument");
+  if (h->gexec1 || h->gexecN) { (void)hipStreamSynchronize(h->stream); if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1); if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN); h->gexec1 = h->gexecN = nullptr; }
   if (nv > 0xffffffffull) return fail(SVILS_ERR_UNSUPPORTED, "too many validation pairs");
   HIPCHK(hipSetDevice(h->cfg.device));
   for (uint64_t i = 0; i < nv; ++i)
@@ -512,10 +519,9 @@ int svils_sweep_phase(svils_handle *h, svils_phase phase) {
   return run_phase(h, phase);
 }
 
-int svils_sweep(svils_handle *h, uint32_t nsweeps) {
-  if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
-  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
-  HIPCHK(hipSetDevice(h->cfg.device));
+namespace {
+
+int eager_sweeps(svils_handle *h, uint32_t nsweeps) {
   for (uint32_t i = 0; i < nsweeps; ++i) {
     int rc;
     if ((rc = run_phase(h, SVILS_PHASE_A))) return rc;
@@ -523,6 +529,45 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
     if ((rc = run_phase(h, SVILS_PHASE_C))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_D))) return rc;
   }
+  return 0;
+}
+
+void drop_graphs(svils_handle *h) {
+  if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
+  if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
+}
+
+// capture `nsweeps` sweeps of the library's own stream into an executable graph; every kernel
+// argument is a by-value snapshot of pointers/sizes that stay fixed after set_graph/set_state
+// (all loop state lives in device memory), so the graph can be replayed indefinitely
+hipGraphExec_t capture_sweeps(svils_handle *h, uint32_t nsweeps) {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+  const int rc = eager_sweeps(h, nsweeps);
+  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+  (void)hipGraphDestroy(graph);
+  return exec;
+}
+
+}  // namespace
+
+int svils_sweep(svils_handle *h, uint32_t nsweeps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  // per-kernel hipEvent timing needs eager launches; short calls are not worth a capture
+  if (h->tmask != 0 || !h->graphs_ok || nsweeps < 4) return eager_sweeps(h, nsweeps);
+  if (!h->gexec1) {
+    h->gexec1 = capture_sweeps(h, 1);
+    h->gexecN = h->gexec1 ? capture_sweeps(h, svils_handle::kGraphSweeps) : nullptr;
+    if (!h->gexec1 || !h->gexecN) { drop_graphs(h); h->graphs_ok = false; return eager_sweeps(h, nsweeps); }
+  }
+  uint32_t left = nsweeps;
+  for (; left >= svils_handle::kGraphSweeps; left -= svils_handle::kGraphSweeps) HIPCHK(hipGraphLaunch(h->gexecN, h->stream));
+  for (; left > 0; --left) HIPCHK(hipGraphLaunch(h->gexec1, h->stream));
   return 0;
 }
 
