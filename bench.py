@@ -97,6 +97,9 @@ def main():
                     help="|".join(WORKLOADS) + "|synthetic:<n>:<k>:<mean_deg>")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU driver even at N=1")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket k_phi with hipEvents in the timed region (lets svils_sweep replay hipGraphs; "
+                         "roofline then comes from a separate short eager pass)")
     ap.add_argument("--shard", choices=["auto", "always", "never"], default="auto",
                     help="N>1: node-block sharding with RCCL exchanges, or replicate the sweep on every "
                          "rank (auto: shard only when K*L/N is large enough to amortise 3 collectives/sweep)")
@@ -167,7 +170,8 @@ def main():
 
     runner.sweep(args.warmup)
     barrier()
-    eng.enable_timing(1 << _svils.KERNEL_PHI)   # hipEvents around the phi kernel, on its stream
+    if not args.no_kernel_events:
+        eng.enable_timing(1 << _svils.KERNEL_PHI)   # hipEvents around the phi kernel, on its stream
     t0 = time.perf_counter()
     runner.sweep(args.steps)
     sync()
@@ -177,9 +181,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if args.no_kernel_events:        # separate eager pass for the phi timing
+        eng.enable_timing(1 << _svils.KERNEL_PHI)
+        runner.sweep(min(args.steps, 20))
+        sync()
     timing = eng.timing()
     ctrl = eng.control()
-    assert ctrl.sweeps_done == args.warmup + args.steps, "sweeps were skipped"
+    assert ctrl.sweeps_done >= args.warmup + args.steps, "sweeps were skipped"
 
     if rank == 0:
         phi_ms, phi_n = timing["phi"]
@@ -220,6 +228,25 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+    # The hipEvents around k_phi force eager launches (8 per sweep).  Without per-kernel timing
+    # svils_sweep replays whole sweeps as hipGraphs; report that throughput over the SAME sweep
+    # window next to `value` (a fresh engine from the same seeded inputs).
+    if rank == 0 and not shard and not args.no_kernel_events:
+        try:
+            eng2 = setup.engine(use_validation_stop=False, device=local_rank)
+            eng2.sweep(args.warmup)
+            eng2.synchronize(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng2.sweep(args.steps)
+            eng2.synchronize(); torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            out["graph_replay"] = {"value": L * args.steps / el2, "unit": "edge-updates/s",
+                                   "ms_per_step": el2 / args.steps * 1e3,
+                                   "note": "same workload and sweep window, no per-kernel events, "
+                                           "svils_sweep replays 8-sweep hipGraphs"}
+            eng2.close()
+        except Exception as exc:
+            out["graph_replay"] = {"error": repr(exc)[:200]}
     # N>1 and the main run was replicated: also time the node-block sharded path (RCCL
     # exchanges) on the same problem, reported next to `value`, never instead of it.
     if world > 1 and not shard and dist is not None:
