@@ -594,9 +594,13 @@ int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
   if ((uint64_t)first + count > c.rows) return fail(SVILS_ERR_ARG, "rows [%u,%u) not recorded yet (have %u)", first, first + count, c.rows);
   if (c.rows - first > h->d.rows_cap) return fail(SVILS_ERR_ARG, "row %u already overwritten in the ring", first);
-  for (uint32_t i = 0; i < count; ++i) {
-    uint32_t slot = (first + i) % h->d.rows_cap;
-    HIPCHK(hipMemcpy(rows + (size_t)i * 10, h->d.rows + (size_t)slot * 10, 10 * sizeof(double), hipMemcpyDeviceToHost));
+  // the ring wraps at rows_cap: at most two contiguous copies
+  uint32_t done = 0;
+  while (done < count) {
+    const uint32_t slot = (first + done) % h->d.rows_cap;
+    const uint32_t run = std::min(count - done, h->d.rows_cap - slot);
+    HIPCHK(hipMemcpy(rows + (size_t)done * 10, h->d.rows + (size_t)slot * 10, (size_t)run * 10 * sizeof(double), hipMemcpyDeviceToHost));
+    done += run;
   }
   return 0;
 }
