@@ -90,3 +90,23 @@ def test_edge_cases_small_graphs():
         assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
         assert np.array_equal(conv, ref.converged)
         assert e.control().iter == 6 and e.control().rows == 0
+
+
+@pytest.mark.parametrize("n,k,sweeps", [(20000, 64, 6), (8000, 24, 25), (6000, 130, 5)])
+def test_midsize_parity_with_hubs(n, k, sweeps):
+    """mid-size synthetic graphs (hubs => split rows / run-straddling wave-items) against the oracle"""
+    from oracle import oracle as O
+    from svinet_amd.host_api import Setup
+    pairs = _synthetic(n, 16, 11)
+    s = Setup(n=n, k=k, pairs=pairs)
+    ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, use_validation_stop=False)
+    eng = s.engine(use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    eng.sweep(sweeps)
+    g, lam, conv = eng.state()
+    assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-8
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-8
+    assert np.array_equal(conv, ref.converged)
+    assert np.array_equal(eng.communities(), ref.communities())
+    np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-8, atol=1e-13)
