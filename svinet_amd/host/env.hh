@@ -35,6 +35,7 @@ class Env {
     bool nmi = false;
     std::string ground_truth_fname;
     uint32_t nthreads = 0;
+    bool strid = false;
     // extensions of this build (not in the reference)
     int device = 0;
     uint32_t sweep_batch = 1;   // sweeps enqueued between host polls
@@ -69,6 +70,7 @@ class Env {
   std::string ground_truth_fname;
   std::string datfname, label;
   bool batch_mode, link_sampling;
+  bool strid;
   volatile int terminate;
   // set by Network::set_env_variables
   uint64_t total_pairs;

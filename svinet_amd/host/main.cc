@@ -47,6 +47,7 @@ static void usage() {
           "\t-no-stop\tdisable stopping criteria\n\n"
           "\t-seed\t\tset random generator seed\n\n"
           "\t-heldout-ratio, -link-thresh, -lt-min-deg, -eta-type, -accuracy\tas in the reference\n\n"
+          "\t-strid\t\tnode names are strings (writes str2id.txt)\n\n"
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
           "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n");
   fflush(stdout);
@@ -92,6 +93,7 @@ int main(int argc, char **argv) {
     else if (is("-heldout-ratio")) { need(i); a.hol_ratio = atof(argv[++i]); }
     else if (is("-link-thresh")) { need(i); a.link_thresh = atof(argv[++i]); }
     else if (is("-lt-min-deg")) { need(i); a.lt_min_deg = atof(argv[++i]); }
+    else if (is("-strid")) { a.strid = true; }
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
     else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
@@ -102,7 +104,7 @@ int main(int argc, char **argv) {
     }
     else if (is("-gen") || is("-ppc") || is("-lcstats") || is("-gml") || is("-findk") || is("-stratified") ||
              is("-rnode") || is("-rpair") || is("-orig") || is("-infset") || is("-single") ||
-             is("-preprocess") || is("-gp") || is("-adamic-adar") || is("-disjoint") || is("-strid") ||
+             is("-preprocess") || is("-gp") || is("-adamic-adar") || is("-disjoint") ||
              is("-load-test-sets")) {
       unsupported = true;
       unsupported_flag = f;

@@ -52,15 +52,37 @@ int Network::read(const std::string &path) {
   FILE *f = fopen(path.c_str(), "r");
   if (!f) return -1;
   int a, b;
-  // the reference's format string is "%d\t%d\n": any white space separates
-  // fields, so CRLF files (example/assort-75-4.txt) parse as well
-  while (fscanf(f, "%d %d", &a, &b) == 2) {
-    if (add_line((uint32_t)a, (uint32_t)b) && chat && ones() % 10000 == 0) {
-      printf("\r+ %d entries", ones());
-      fflush(stdout);
+  if (env_.strid) {
+    char b1[512], b2[512];
+    while (fscanf(f, "%511s %511s", b1, b2) == 2) {
+      uint32_t id[2];
+      const char *tok[2] = {b1, b2};
+      for (int i = 0; i < 2; ++i) {
+        auto it = str2id_.find(tok[i]);
+        if (it == str2id_.end()) it = str2id_.emplace(tok[i], (uint32_t)str2id_.size()).first;
+        id[i] = it->second;
+      }
+      add_line(id[0], id[1]);
+    }
+  } else {
+    // the reference's format string is "%d\t%d\n": any white space separates
+    // fields, so CRLF files (example/assort-75-4.txt) parse as well
+    while (fscanf(f, "%d %d", &a, &b) == 2) {
+      if (add_line((uint32_t)a, (uint32_t)b) && chat && ones() % 10000 == 0) {
+        printf("\r+ %d entries", ones());
+        fflush(stdout);
+      }
     }
   }
   fclose(f);
+  if (env_.strid && env_.write_files) {
+    FILE *sf = fopen(Env::file_str("/str2id.txt").c_str(), "w");
+    if (sf) {
+      for (const auto &kv : str2id_) fprintf(sf, "%s\t%d\n", kv.first.c_str(), kv.second);
+      fclose(sf);
+    }
+    fprintf(stdout, "+ Total nodes read = %d\n", (int)str2id_.size());
+  }
   if (chat && singles())
     printf("n = %d, curr_seq = %d\n+ Creating ids for %d single nodes\n", declared_n_, nodes_seen(), singles());
   if (chat) fprintf(stdout, "\n+ Done reading network\n");

@@ -4,6 +4,7 @@
 // edges(), y(), deg(), seq2id()/id2seq(), deg_stats().
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -23,6 +24,9 @@ class Network {
   // name a new id are dropped; self loops and repeated pairs are dropped
   // (src/network.cc:22-104).  Returns 0, or -1 if the file cannot be opened.
   int read(const std::string &path);
+  // -strid: node names are arbitrary tokens; they are numbered in order of first appearance and the
+  // table is written to <outdir>/str2id.txt sorted by name (src/network.cc:25-45,131-142)
+  const std::map<std::string, uint32_t> &str2id() const { return str2id_; }
   // same semantics from memory (used for synthetic graphs)
   void read_pairs(const int32_t *pairs, uint64_t nlines);
 
@@ -52,6 +56,7 @@ class Network {
   std::vector<uint32_t> seq2id_;
   std::unordered_map<uint32_t, uint32_t> id2seq_;
   std::unordered_set<uint64_t> pair_set_;
+  std::map<std::string, uint32_t> str2id_;
 };
 
 }  // namespace svinet

@@ -112,3 +112,19 @@ def test_accuracy_mode_trains_on_all_links(graph_files):
     assert s.nlinks == s.ones == ref.nlinks
     assert np.array_equal(s.links, ref.links) and np.array_equal(s.gamma, ref.gamma)
     assert np.array_equal(s.validation_accept, ref.validation_accept)
+
+
+def test_cli_strid(tmp_path):
+    """-strid: arbitrary node names, numbered by first appearance, table in str2id.txt sorted by name"""
+    g = tmp_path / "names.txt"
+    names = ["n%02d" % i for i in range(30)]
+    lines = ["%s\t%s" % (names[i], names[(i + 1) % 30]) for i in range(30)] + ["%s\t%s" % (names[i], names[(i + 5) % 30]) for i in range(30)]
+    g.write_text("\n".join(lines) + "\n")
+    r = _run(["-file", str(g), "-n", "30", "-k", "3", "-link-sampling", "-strid", "-label", "s"], str(tmp_path))
+    d = tmp_path / "n30-k3-s-linksampling"
+    table = [l.split("\t") for l in (d / "str2id.txt").read_text().split("\n") if l]
+    assert [t[0] for t in table] == sorted(names)
+    # first appearance order: n00, n01, n02, ... (n01 appears as second token of line 1)
+    assert dict((a, int(b)) for a, b in table) == {nm: i for i, nm in enumerate(names)}
+    ve = (d / "validation-edges.txt").read_text()
+    assert ve.endswith("\n")
