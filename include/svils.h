@@ -156,6 +156,9 @@ enum {
 };
 /* mask: bit i set = bracket kernel i with hipEvents on the library's stream */
 int svils_enable_timing(svils_handle *h, uint32_t kernel_mask);
+/* sample only every `period`-th sweep of a svils_sweep() call (default 1 = every sweep): the
+ * bracketed sweeps are launched eagerly, the others replay hipGraphs */
+int svils_set_timing_period(svils_handle *h, uint32_t period);
 /* synchronises; ms[i] = summed duration, launches[i] = launches timed since
  * the last svils_enable_timing call.  Arrays of SVILS_KERNEL_COUNT. */
 int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches);

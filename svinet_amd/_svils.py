@@ -23,6 +23,7 @@ EXPORTS = (
     "svils_get_state", "svils_get_communities", "svils_get_aux", "svils_enable_timing",
     "svils_get_timing", "svils_kernel_name", "svils_sweep_phase", "svils_device_buffer",
     "svils_stream", "svils_last_error", "svils_abi_version", "svils_debug_eval",
+    "svils_set_timing_period",
 )
 
 
@@ -94,6 +95,7 @@ def load():
                                       C.POINTER(C.c_size_t)]
     L.svils_stream.argtypes = [vp, C.POINTER(vp)]
     L.svils_debug_eval.argtypes = [vp, C.c_int, vp, vp, C.c_uint32]
+    L.svils_set_timing_period.argtypes = [vp, C.c_uint32]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version"):
@@ -224,8 +226,9 @@ class Engine:
         _chk(load().svils_debug_eval(self._h, which, x.ctypes.data, out.ctypes.data, x.size))
         return out
 
-    def enable_timing(self, mask):
+    def enable_timing(self, mask, period=1):
         _chk(load().svils_enable_timing(self._h, mask))
+        _chk(load().svils_set_timing_period(self._h, period))
 
     def timing(self):
         ms = np.zeros(len(KERNEL_NAMES), dtype=np.float64)

@@ -61,6 +61,7 @@ struct svils_handle {
   double *row_scratch = nullptr;  // device [10]
   // timing
   uint32_t tmask = 0;
+  uint32_t tperiod = 1;   // bracket every tperiod-th sweep only
   std::vector<EvPair> pending[SVILS_KERNEL_COUNT];
   std::vector<EvPair> freelist;
   double t_ms[SVILS_KERNEL_COUNT] = {0};
@@ -559,23 +560,50 @@ hipGraphExec_t capture_sweeps(svils_handle *h, uint32_t nsweeps) {
 
 }  // namespace
 
+namespace {
+
+// replay `n` sweeps from the untimed graphs (captured on first use, with event recording off)
+int graph_sweeps(svils_handle *h, uint32_t n) {
+  if (!h->gexec1) {
+    const uint32_t saved = h->tmask;
+    h->tmask = 0;
+    h->gexec1 = capture_sweeps(h, 1);
+    h->gexecN = h->gexec1 ? capture_sweeps(h, svils_handle::kGraphSweeps) : nullptr;
+    h->tmask = saved;
+    if (!h->gexec1 || !h->gexecN) { drop_graphs(h); h->graphs_ok = false; return eager_sweeps(h, n); }
+  }
+  for (; n >= svils_handle::kGraphSweeps; n -= svils_handle::kGraphSweeps) HIPCHK(hipGraphLaunch(h->gexecN, h->stream));
+  for (; n > 0; --n) HIPCHK(hipGraphLaunch(h->gexec1, h->stream));
+  return 0;
+}
+
+}  // namespace
+
 int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (!h->graphs_ok || nsweeps < 4) return eager_sweeps(h, nsweeps);   // short calls are not worth a capture
-  // per-kernel hipEvent timing needs eager launches (events captured as graph nodes cannot be read
-  // with hipEventElapsedTime on this runtime, and mixing one eager kernel with a graph of the rest
-  // measured slower than plain eager: 86.7 vs 79.7 us per ca-AstroPh sweep)
-  if (h->tmask != 0) return eager_sweeps(h, nsweeps);
-  if (!h->gexec1) {
-    h->gexec1 = capture_sweeps(h, 1);
-    h->gexecN = h->gexec1 ? capture_sweeps(h, svils_handle::kGraphSweeps) : nullptr;
-    if (!h->gexec1 || !h->gexecN) { drop_graphs(h); h->graphs_ok = false; return eager_sweeps(h, nsweeps); }
-  }
+  if (h->tmask == 0) return graph_sweeps(h, nsweeps);
+  // Per-kernel hipEvent timing needs eager launches: events captured as graph nodes cannot be read
+  // with hipEventElapsedTime on this runtime.  With a sampling period P > 1 only every P-th sweep is
+  // launched eagerly between events; the P-1 sweeps in between replay the untimed graphs.
+  if (h->tperiod <= 1) return eager_sweeps(h, nsweeps);
   uint32_t left = nsweeps;
-  for (; left >= svils_handle::kGraphSweeps; left -= svils_handle::kGraphSweeps) HIPCHK(hipGraphLaunch(h->gexecN, h->stream));
-  for (; left > 0; --left) HIPCHK(hipGraphLaunch(h->gexec1, h->stream));
+  while (left > 0) {
+    int rc = eager_sweeps(h, 1);
+    if (rc) return rc;
+    --left;
+    const uint32_t n = std::min(left, h->tperiod - 1);
+    if (n && (rc = graph_sweeps(h, n))) return rc;
+    left -= n;
+  }
+  return 0;
+}
+
+int svils_set_timing_period(svils_handle *h, uint32_t period) {
+  if (!h || period == 0) return fail(SVILS_ERR_ARG, "svils_set_timing_period: bad argument");
+  h->tperiod = period;
   return 0;
 }
 
