@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="astroph-k20",
-                    help="|".join(WORKLOADS) + "|synthetic:<n>:<k>:<mean_deg>")
+                    help="|".join(WORKLOADS) + "|synthetic:<n>:<k>:<mean_deg>|mmsb:<n>:<k>:<mean_deg>")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU driver even at N=1")
     ap.add_argument("--event-period", type=int, default=9,
@@ -139,6 +139,14 @@ def main():
         pairs = _synthetic_pairs(n, int(sd), 20240517)
         setup = Setup(n=n, k=k, pairs=pairs)
         data = "synthetic sparse graph (ring + uniform random pairs, seed 20240517), seeded init"
+    elif args.workload.startswith("mmsb"):
+        from svinet_amd import mmsbgen_sparse
+        _, sn, sk, sd = args.workload.split(":")
+        n, k = int(sn), int(sk)
+        pairs = mmsbgen_sparse.generate(n, k, int(sd))
+        setup = Setup(n=n, k=k, pairs=pairs)
+        data = ("synthetic sparse MMSB graph (svinet_amd/mmsbgen_sparse.py: Dirichlet(0.05) top-4 memberships, "
+                "Beta(4700.59,0.77) rates, Philox seed %d), seeded init" % mmsbgen_sparse.DEFAULT_SEED)
     else:
         fixture, n, k = WORKLOADS[args.workload]
         path = _fixture(fixture)

@@ -110,3 +110,30 @@ def test_midsize_parity_with_hubs(n, k, sweeps):
     assert np.array_equal(conv, ref.converged)
     assert np.array_equal(eng.communities(), ref.communities())
     np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-8, atol=1e-13)
+
+
+@pytest.mark.parametrize("n,k,alpha", [(20000, 32, 0.01), (8000, 100, 0.003)])
+def test_planted_mmsb_recovery(n, k, alpha):
+    """Full run to the device-side stop rule on a planted sparse MMSB graph (the config-5
+    generator at a small size): the strongest planted membership is recovered, the run
+    passes through the annealing switch, converged-node shortcuts and community tagging."""
+    from svinet_amd import mmsbgen_sparse as G
+    from svinet_amd.host_api import Setup
+    from test_mmsbgen import nmi
+    pairs, (comm, w, _) = G.generate(n, k, 24, alpha=alpha, return_truth=True)
+    s = Setup(n=n, k=k, pairs=pairs)
+    eng = s.engine()
+    eng.sweep(400)
+    c = eng.control()
+    assert c.stopped == 1 and 10 < c.sweeps_done < 400 and not c.annealing
+    assert c.links_shortcut > 0 and c.links_dense + c.links_sparse + c.links_shortcut == s.nlinks
+    g, lam, conv = eng.state()
+    strong = w[s.seq2id, 0] > 0.9
+    assert nmi(comm[s.seq2id, 0][strong], g.argmax(1)[strong]) > 0.9
+    # tagged communities: a converged node sits in the community it converged to
+    member = eng.communities()
+    cn = np.nonzero(conv)[0]
+    assert cn.size > n // 20
+    assert member[cn, conv[cn] - 1].mean() > 0.95
+    rows = eng.rows()
+    assert rows[-1, 9] > rows[0, 9]          # held-out likelihood improved

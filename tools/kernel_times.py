@@ -9,6 +9,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 if wl.startswith("synthetic"):
     _, sn, sk, sd = wl.split(":")
     setup = Setup(n=int(sn), k=int(sk), pairs=_synthetic_pairs(int(sn), int(sd), 20240517))
+elif wl.startswith("mmsb"):
+    from svinet_amd import mmsbgen_sparse
+    _, sn, sk, sd = wl.split(":")
+    setup = Setup(n=int(sn), k=int(sk), pairs=mmsbgen_sparse.generate(int(sn), int(sk), int(sd)))
 else:
     f, n, k = WORKLOADS[wl]
     setup = Setup(_fixture(f), n, k)
