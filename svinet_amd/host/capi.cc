@@ -7,6 +7,7 @@
 
 #include "env.hh"
 #include "linksampling.hh"
+#include "mmsbbatch.hh"
 #include "network.hh"
 
 using namespace svinet;
@@ -85,5 +86,49 @@ uint64_t svih_nlinks(svih_setup *s) { return s->ls->training_links().size() / 2;
 const uint32_t *svih_links(svih_setup *s) { return s->ls->training_links().data(); }
 const uint32_t *svih_edges(const svih_setup *s) { return &s->net->edges()[0].first; }
 uint32_t svih_deg(const svih_setup *s, uint32_t p) { return s->net->deg(p); }
+
+// ---- the -batch engine (host CPU), for the tests ----
+struct svih_batch {
+  std::unique_ptr<Env> env;
+  std::unique_ptr<Network> net;
+  std::unique_ptr<MMSBBatch> eng;
+};
+
+svih_batch *svih_batch_from_file(const char *path, const svih_options *o) {
+  static const char *eta_names[] = {"uniform", "fromdata", "sparse", "dense"};
+  Env::Args a;
+  a.n = o->n;
+  a.k = o->k;
+  a.batch = true;
+  a.rand_seed = o->seed;
+  a.hol_ratio = o->heldout_ratio;
+  a.eta_type = eta_names[(o->eta_type >= 0 && o->eta_type < 4) ? o->eta_type : 0];
+  a.write_files = false;
+  svih_batch *b = new svih_batch();
+  b->env.reset(new Env(a));
+  b->net.reset(new Network(*b->env));
+  if (b->net->read(path) < 0) { delete b; return nullptr; }
+  b->env->n = b->net->n() - b->net->singles();
+  b->eng.reset(new MMSBBatch(*b->env, *b->net));
+  return b;
+}
+void svih_batch_free(svih_batch *b) { delete b; }
+uint32_t svih_batch_n(const svih_batch *b) { return b->eng->n(); }
+uint32_t svih_batch_iter(const svih_batch *b) { return b->eng->iter(); }
+double *svih_batch_gamma(svih_batch *b) { return b->eng->gamma().data(); }
+double *svih_batch_lambda(svih_batch *b) { return b->eng->lambda().data(); }
+uint64_t svih_batch_nheldout(const svih_batch *b) { return b->eng->heldout_edges().size() / 2; }
+const uint32_t *svih_batch_heldout(const svih_batch *b) { return b->eng->heldout_edges().data(); }
+uint64_t svih_batch_nvalidation(const svih_batch *b) { return b->eng->validation_edges().size() / 2; }
+const uint32_t *svih_batch_validation(const svih_batch *b) { return b->eng->validation_edges().data(); }
+uint64_t svih_batch_nrows(const svih_batch *b) { return b->eng->heldout_rows().size() / 10; }
+const double *svih_batch_rows(const svih_batch *b) { return b->eng->heldout_rows().data(); }
+void svih_batch_sweep(svih_batch *b) { b->eng->sweep(); }
+int svih_batch_report(svih_batch *b) { return b->eng->report() ? 1 : 0; }
+double svih_batch_eta0(const svih_batch *b) { return b->env->eta0; }
+double svih_batch_eta1(const svih_batch *b) { return b->env->eta1; }
+double svih_batch_ones_prob(const svih_batch *b) { return b->env->ones_prob; }
+const uint32_t *svih_batch_edges(const svih_batch *b) { return &b->net->edges()[0].first; }
+uint32_t svih_batch_ones(const svih_batch *b) { return b->net->ones(); }
 
 }  // extern "C"

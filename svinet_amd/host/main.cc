@@ -2,7 +2,8 @@
 //
 // Accepts the reference's flag set (src/main.cc:114-242, same spelling, same
 // positional/order-sensitive semantics: e.g. -link-sampling resets rfreq to 1,
-// so -rfreq must follow it).  Only the -link-sampling engine is provided; the
+// so -rfreq must follow it).  Engines: -link-sampling (the MI355X path) and the
+// reference's small all-pairs CPU engine -batch (plumbing only); the
 // flags that select the reference's other engines are recognised and rejected
 // with a message instead of being silently ignored.
 #include <csignal>
@@ -13,6 +14,7 @@
 
 #include "env.hh"
 #include "linksampling.hh"
+#include "mmsbbatch.hh"
 #include "network.hh"
 
 using namespace svinet;
@@ -38,7 +40,8 @@ static void usage() {
           "\t-file <name>\tinput tab-separated file with a list of undirected links\n\n"
           "\t-n <N>\t\tnumber of nodes in network\n\n"
           "\t-k <K>\t\tnumber of communities\n\n"
-          "\t-link-sampling\tinference using link sampling (the engine this build provides)\n\n"
+          "\t-link-sampling\tinference using link sampling (the MI355X engine of this build)\n\n"
+          "\t-batch\t\trun batch variational inference over all pairs (host CPU, small graphs)\n\n"
           "\t-load-validation <fname>\tuse the pairs in the file as the validation set for convergence\n\n"
           "\t-load <dir>\tresume from <dir>gamma.txt / <dir>lambda.txt\n\n"
           "\t-label\t\ttag output directory\n\n"
@@ -111,9 +114,9 @@ int main(int argc, char **argv) {
     }
     // unknown flags are ignored, as in the reference
   }
-  if (unsupported || a.batch || !a.link_sampling) {
+  if (unsupported || !(a.batch || a.link_sampling)) {
     fprintf(stderr,
-            "svinet (MI355X build): only the -link-sampling engine is implemented here%s%s.\n"
+            "svinet (MI355X build): only the -link-sampling and -batch engines are implemented here%s%s.\n"
             "Use the reference build for the other engines.\n",
             unsupported ? "; unsupported option " : "", unsupported ? unsupported_flag.c_str() : "");
     return 2;
@@ -133,6 +136,16 @@ int main(int argc, char **argv) {
     return -1;
   }
   env.n = network.n() - network.singles();   // src/main.cc:291
+  if (network.ones() == 0 || env.n < 2) {
+    fprintf(stderr, "error: no links read from %s; quitting\n", a.datfname.c_str());
+    return -1;
+  }
+  if (a.batch) {                             // src/main.cc:354-358
+    printf("+ running mmsb batch inference\n");
+    MMSBBatch mmsb(env, network);
+    mmsb.batch_infer();
+    exit(0);
+  }
   LinkSampling ls(env, network);
   ls.infer();
   exit(0);

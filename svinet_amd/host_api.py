@@ -129,3 +129,65 @@ class Setup:
             self._h = None
 
     __del__ = close
+
+
+class BatchEngine:
+    """The `-batch` engine of the host library (svinet_amd/host/mmsbbatch.cc): the reference's
+    all-pairs CPU engine MMSBInfer::batch_infer (src/mmsbinfer.cc:833-930), plumbing only."""
+
+    def __init__(self, path, n, k, seed=0, heldout_ratio=0.01, eta_type="uniform"):
+        L = load()
+        vp, u32, u64, dbl, P = C.c_void_p, C.c_uint32, C.c_uint64, C.c_double, C.POINTER
+        if not hasattr(L, "_batch_ready"):
+            L.svih_batch_from_file.argtypes = [C.c_char_p, P(Options)]
+            L.svih_batch_from_file.restype = vp
+            for name, res in (("free", None), ("n", u32), ("iter", u32), ("gamma", P(dbl)), ("lambda", P(dbl)),
+                              ("nheldout", u64), ("heldout", P(u32)), ("nvalidation", u64),
+                              ("validation", P(u32)), ("nrows", u64), ("rows", P(dbl)), ("sweep", None),
+                              ("report", C.c_int), ("eta0", dbl), ("eta1", dbl), ("ones_prob", dbl),
+                              ("edges", P(u32)), ("ones", u32)):
+                f = getattr(L, "svih_batch_" + name)
+                f.argtypes = [vp]
+                f.restype = res
+            L._batch_ready = True
+        o = Options()
+        L.svih_options_default(C.byref(o), n, k)
+        o.seed, o.heldout_ratio, o.eta_type = seed, heldout_ratio, ETA_TYPES[eta_type]
+        self._h = L.svih_batch_from_file(os.fsencode(path), C.byref(o))
+        if not self._h:
+            raise IOError("cannot read network %r" % (path,))
+        self.n, self.k = L.svih_batch_n(self._h), k
+        self.eta = (L.svih_batch_eta0(self._h), L.svih_batch_eta1(self._h))
+        self.ones_prob = L.svih_batch_ones_prob(self._h)
+        self.heldout = _arr(L.svih_batch_heldout(self._h), (L.svih_batch_nheldout(self._h), 2), np.uint32)
+        self.validation = _arr(L.svih_batch_validation(self._h), (L.svih_batch_nvalidation(self._h), 2), np.uint32)
+        self.edges = _arr(L.svih_batch_edges(self._h), (L.svih_batch_ones(self._h), 2), np.uint32)
+
+    @property
+    def gamma(self):
+        return _arr(load().svih_batch_gamma(self._h), (self.n, self.k), np.float64)
+
+    @property
+    def lam(self):
+        return _arr(load().svih_batch_lambda(self._h), (self.k, 2), np.float64)
+
+    @property
+    def rows(self):
+        return _arr(load().svih_batch_rows(self._h), (load().svih_batch_nrows(self._h), 10), np.float64)
+
+    @property
+    def iter(self):
+        return load().svih_batch_iter(self._h)
+
+    def sweep(self):
+        load().svih_batch_sweep(self._h)
+
+    def report(self):
+        return bool(load().svih_batch_report(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().svih_batch_free(self._h)
+            self._h = None
+
+    __del__ = close

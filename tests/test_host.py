@@ -69,8 +69,8 @@ def test_cli_usage_and_rejections(tmp_path):
     assert _run([], str(tmp_path)).returncode != 0
     r = _run(["-help"], str(tmp_path))
     assert r.returncode == 0 and "-link-sampling" in r.stdout
-    r = _run(["-file", "x", "-n", "10", "-k", "2", "-batch"], str(tmp_path))
-    assert r.returncode == 2 and "only the -link-sampling engine" in r.stderr
+    r = _run(["-file", "x", "-n", "10", "-k", "2"], str(tmp_path))        # no engine selected
+    assert r.returncode == 2 and "only the -link-sampling and -batch engines" in r.stderr
     r = _run(["-file", "x", "-n", "10", "-k", "2", "-link-sampling", "-rnode"], str(tmp_path))
     assert r.returncode == 2 and "-rnode" in r.stderr
     r = _run(["-file", "/nonexistent", "-n", "10", "-k", "2", "-link-sampling"], str(tmp_path))
