@@ -385,7 +385,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     for (uint32_t p = 0; p < n; ++p)
       for (uint64_t e = rowptr[p]; e < rowptr[p + 1]; ++e) erow[e] = p;
     const int nw = lpl_phi_waves(g.K);
-    d.nb_a = cap((d.lpl_nitems + nw - 1) / nw, 768);   // 3 resident blocks per CU (LDS)
+    d.nb_a = cap((d.lpl_nitems + nw - 1) / nw, lpl_phi_resident_blocks(g.K, h->cfg.device));
     d.nb_c = cap((d.link_end - d.link_begin + 255) / 256, 1024);
   }
 

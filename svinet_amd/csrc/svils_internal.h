@@ -108,6 +108,7 @@ struct Params {
 // launchers (svils_device.hip); all asynchronous on `s`
 bool use_lpl(uint32_t K);
 int lpl_phi_waves(uint32_t K);
+uint32_t lpl_phi_resident_blocks(uint32_t K, int device);
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);

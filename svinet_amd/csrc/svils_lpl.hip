@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
-  __shared__ __attribute__((aligned(16))) double lds[NW][64 * SROW];
+  __shared__ __attribute__((aligned(16))) double lds[NW][32 * SROW];
   __shared__ double red[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
@@ -54,11 +54,9 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
   // Elogbeta[.][0], wave-uniform but kept in VGPRs on purpose: as KR scalar pairs it made the
   // SGPR file spill through v_writelane/v_readlane inside the hot loop.  Padding columns
   // (k >= K) get -inf, which masks them in the softmax without any select.
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  double eb[KR];
-#pragma unroll
-  for (int k = 0; k < KR; ++k) eb[k] = (k < (int)K) ? d.elogbeta[2 * k + vzero] : NEG_INF;
+  __shared__ double eb[KR];
+  if (threadIdx.x < KR) eb[threadIdx.x] = (threadIdx.x < K) ? d.elogbeta[2 * threadIdx.x] : NEG_INF;
+  __syncthreads();
   double csum = 0.0;  // lane k: partial of sum[k]
   unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
 
@@ -71,7 +69,7 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
       q = d.col[e];
     }
     double phi[KR];
-    double *mine = mylds + lane * SROW;   // this lane's staged phi row
+    double *mine = mylds + (lane & 31) * SROW;   // this lane's staged phi row (two passes of 32 rows)
     int tagk = -1;   // community this link tags (src/linksampling.cc:668-681,704-717), -1: none
     int one_at = -1; // >= 0: the row is the unit vector e_c (converged shortcut), stored straight to LDS
     bool dense_row = false;
@@ -138,67 +136,72 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
         if (count_me) { if (sparse) n_sparse++; else n_dense++; }
       }
     }
-    // stage the 64 phi rows: dense rows from registers; shortcut / invalid / empty rows as
-    // zeros (+ a single 1.0) without ever materialising them in registers
-    if (dense_row) {
+    // Stage the phi rows in LDS and let lane k sum column k over them in entry order, flushing at
+    // node boundaries.  The 64 rows go through LDS in two passes of 32 (lanes 0-31, then 32-63):
+    // half the LDS per wavefront, so that the register file, not LDS, sets the occupancy.
+    // Dense rows come from registers; shortcut / invalid / empty rows are zeros (+ a single 1.0)
+    // without ever being materialised in registers.
+    // heads of the node runs: bit r set <=> row r starts a new node
+    const uint32_t pprev = __shfl_up((int)p, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || p != pprev);
+    const unsigned long long vmask = __ballot(p != 0xffffffffu);
+    const bool any_tag = __ballot(tagk >= 0) != 0ull;
+    // lane k: bit r set <=> row r tags community k (KR ballots instead of 64 x 3 VALU ops in the row loop)
+    unsigned long long tmask = 0ull;
+    if (any_tag) {
 #pragma unroll
-      for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(phi[2 * c], phi[2 * c + 1]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(0.0, 0.0);
-      if (one_at >= 0) mine[one_at] = 1.0;
+      for (int k = 0; k < KR; ++k) {
+        const unsigned long long mk = __ballot(tagk == k);
+        tmask = (lane == k) ? mk : tmask;
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // lane k sums column k over the rows in entry order, flushing at node boundaries
-    {
-      // heads of the node runs: bit r set <=> row r starts a new node
-      const uint32_t pprev = __shfl_up((int)p, 1, 64);
-      const unsigned long long heads = __ballot(lane == 0 || p != pprev);
-      const unsigned long long vmask = __ballot(p != 0xffffffffu);
-      const bool any_tag = __ballot(tagk >= 0) != 0ull;
-      // lane k: bit r set <=> row r tags community k (KR ballots instead of 64 x 3 VALU ops in the row loop)
-      unsigned long long tmask = 0ull;
-      if (any_tag) {
+    double acc = 0.0;
+    int a = 0;
+    // one run [a, b] of node `cur` is complete: store its partial gammanext row and its tags.
+    // Tags are pre-reduced per run so that a node costs one atomic per wave-item, not one per link.
+#define LPL_FLUSH(DST, B)                                                                   \
+    do {                                                                                    \
+      if ((vmask >> a) & 1ull) {                                                            \
+        const uint32_t cur = __builtin_amdgcn_readlane(p, a);                               \
+        double *dst = (DST);                                                                \
+        dst[lane] = acc;                                                                    \
+        csum += acc;                                                                        \
+        if (any_tag) {                                                                      \
+          const unsigned long long runmask = (((B) >= 63) ? ~0ull : ((2ull << (B)) - 1ull)) & ~((1ull << a) - 1ull); \
+          const uint32_t cnt = (uint32_t)__popcll(tmask & runmask);                         \
+          if (d.fcnt) { if (cnt) atomicAdd(&d.fcnt[(size_t)cur * ld + lane], cnt); }        \
+          else {                                                                            \
+            const unsigned long long bits = __ballot(cnt > 0);                              \
+            if (bits && lane == 0) atomicOr(&d.member_acc[cur], bits);                      \
+          }                                                                                 \
+        }                                                                                   \
+      }                                                                                     \
+      acc = 0.0;                                                                            \
+    } while (0)
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-          const unsigned long long mk = __ballot(tagk == k);
-          tmask = (lane == k) ? mk : tmask;
+    for (int half = 0; half < 2; ++half) {
+      if ((lane >> 5) == half) {
+        if (dense_row) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(phi[2 * c], phi[2 * c + 1]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(0.0, 0.0);
+          if (one_at >= 0) mine[one_at] = 1.0;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if ((uint32_t)lane < K) {
-        double acc = 0.0;
-        int a = 0;
-        // one run [a, b] of node `cur` is complete: store its partial gammanext row and its tags.
-        // Tags are pre-reduced per run so that a node costs one atomic per wave-item, not one per link.
-#define LPL_FLUSH(DST, B)                                                                   \
-        do {                                                                                \
-          if ((vmask >> a) & 1ull) {                                                        \
-            const uint32_t cur = __builtin_amdgcn_readlane(p, a);                           \
-            double *dst = (DST);                                                            \
-            dst[lane] = acc;                                                                \
-            csum += acc;                                                                    \
-            if (any_tag) {                                                                  \
-              const unsigned long long runmask = (((B) >= 63) ? ~0ull : ((2ull << (B)) - 1ull)) & ~((1ull << a) - 1ull); \
-              const uint32_t cnt = (uint32_t)__popcll(tmask & runmask);                     \
-              if (d.fcnt) { if (cnt) atomicAdd(&d.fcnt[(size_t)cur * ld + lane], cnt); }    \
-              else {                                                                        \
-                const unsigned long long bits = __ballot(cnt > 0);                          \
-                if (bits && lane == 0) atomicOr(&d.member_acc[cur], bits);                  \
-              }                                                                             \
-            }                                                                               \
-          }                                                                                 \
-          acc = 0.0;                                                                        \
-        } while (0)
 #pragma unroll 1
-        for (int rb = 0; rb < 64; rb += 16) {
+        for (int rb = 0; rb < 32; rb += 16) {
           double v[16];
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] = mylds[(rb + j) * SROW + lane];
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const int r = rb + j;
+            const int r = half * 32 + rb + j;
             if (r > 0 && ((heads >> r) & 1ull)) {      // run [a, r-1] ends (wave-uniform branch)
               LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.gamma + (size_t)cur * ld, r - 1);
               a = r;
@@ -207,12 +210,12 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
           }
         }
         // last run ends at lane 63
-        LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.slot_l + (size_t)it * ld, 63);
-#undef LPL_FLUSH
+        if (half == 1) LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.slot_l + (size_t)it * ld, 63);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+#undef LPL_FLUSH
   }
 
   // per-block partial of `sum`: waves in order
@@ -302,6 +305,19 @@ int lpl_phi_waves(uint32_t K) { return K > 28 ? 3 : 4; }
     else if ((K_) <= 28) { CALL(14); }         \
     else { CALL(16); }                         \
   } while (0)
+
+// blocks of k_phi_lpl that fit on the device at once (registers and LDS of the instantiation
+// chosen for K): one grid of this size keeps every wavefront slot busy with no second round
+uint32_t lpl_phi_resident_blocks(uint32_t K, int device) {
+  int per_cu = 0, cus = 0;
+#define CALL(KC_) \
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_phi_lpl<KC_, lpl_waves(KC_)>, 64 * lpl_waves(KC_), 0)
+  LPL_DISPATCH(K, CALL);
+#undef CALL
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (per_cu <= 0 || cus <= 0) return 768;
+  return (uint32_t)per_cu * (uint32_t)cus;
+}
 
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define CALL(KC_)                                                                                   \
