@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_phi with hipEvents in the timed region (lets svils_sweep replay hipGraphs; "
                          "roofline then comes from a separate short eager pass)")
+    ap.add_argument("--no-sharded-extra", action="store_true",
+                    help="N>1, replicated main run: skip the extra timing of the node-block sharded path")
+    ap.add_argument("--extra-timeout", type=int, default=150,
+                    help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
     ap.add_argument("--shard", choices=["auto", "always", "never"], default="auto",
                     help="N>1: node-block sharding with RCCL exchanges, or replicate the sweep on every "
                          "rank (auto: shard only when K*L/N is large enough to amortise 3 collectives/sweep)")
@@ -262,9 +266,36 @@ def main():
             eng2.close()
         except Exception as exc:
             out["graph_replay"] = {"error": repr(exc)[:200]}
+    # The one JSON line is owed to the driver whatever happens below: a watchdog emits it (without the
+    # optional extra) and leaves if the extra measurement or the teardown ever blocks on a collective.
+    import threading
+    emit_lock = threading.Lock()
+    state = {"emitted": False}
+
+    def emit():
+        with emit_lock:
+            if rank == 0 and not state["emitted"]:
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)   # the one JSON line, after any RCCL banner
+            state["emitted"] = True
+
+    finished = threading.Event()
+
+    def watchdog():
+        if not finished.wait(timeout=args.extra_timeout):
+            if rank == 0:
+                out.setdefault("sharded_path", {"error": "timed out after %d s" % args.extra_timeout})
+            emit()
+            sys.stderr.write("bench.py: rank %d left on the watchdog\n" % rank)
+            sys.stderr.flush()
+            os._exit(0)
+
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+
     # N>1 and the main run was replicated: also time the node-block sharded path (RCCL
     # exchanges) on the same problem, reported next to `value`, never instead of it.
-    if world > 1 and not shard and dist is not None:
+    if world > 1 and not shard and dist is not None and not args.no_sharded_extra:
         sh = {}
         try:
             from svinet_amd.sharded import HipShard, ShardedSweep
@@ -289,10 +320,10 @@ def main():
         os.unlink(path)
     if dist is not None:
         dist.barrier()
+    emit()
+    if dist is not None:
         dist.destroy_process_group()
-    if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)   # the one JSON line, after any RCCL banner
+    finished.set()
 
 
 if __name__ == "__main__":
