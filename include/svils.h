@@ -128,6 +128,33 @@ int svils_validation_row(svils_handle *h, double *row10);
 int svils_sweep(svils_handle *h, uint32_t nsweeps);
 int svils_synchronize(svils_handle *h);
 
+/* ---- mini-batch mode (an ADDITION of this build; SURVEY 8f N4, BASELINE north_star) ----
+ * The reference revision's -link-sampling loop is a deterministic full sweep with step size 1
+ * (src/linksampling.cc:556-790); its stochastic engines (MMSBInfer::infer,
+ * src/mmsbinfer.cc:564-641) sample node/pair mini-batches and blend with a Robbins-Monro step
+ * (tau0 + t)^-kappa, per node and for lambda.  svils_step() is that scheme applied to the
+ * link-sampling updates: one step processes the links of a WINDOW of `batch_nodes` consecutive
+ * nodes (windows taken in cyclic order -- relabel the nodes randomly for unbiased batches),
+ * scales the window sums to estimates of the full sums, and blends gamma rows of the window
+ * (per-node step size from the node's own update count) and lambda (step size from the step
+ * number).  With batch_nodes = 0 (all nodes) and kappa = 0 a step equals a full sweep.
+ * Not a parity mode: the reference has no counterpart to compare against. */
+typedef struct {
+  uint32_t batch_nodes;   /* nodes per mini-batch; 0 = all nodes */
+  /* step sizes, the reference's four constants (src/env.hh:399-408: 1024, 0.5, 1024, 0.9):
+   * a node updated c times so far moves by (node_tau0 + c)^-node_kappa, lambda at step t by
+   * (tau0 + t)^-kappa; tau >= 1, kappa in [0, 1], kappa = 0 = no damping */
+  double node_tau0, node_kappa;
+  double tau0, kappa;
+  uint64_t seed;          /* offset of the first window in the cyclic order */
+} svils_stochastic;
+void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes);
+/* Call after svils_create (single-GPU handles only); allocates the extra accumulator. */
+int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg);
+/* Enqueue `nsteps` mini-batch steps; asynchronous; every step advances _iter, writes a
+ * likelihood row when _iter % reportfreq == 0 and runs the stop rule, exactly as a sweep does. */
+int svils_step(svils_handle *h, uint32_t nsteps);
+
 /* rows recorded by the in-loop validation_likelihood(): copies rows
  * [first, first+count) (as numbered since create) into out[count][10]. */
 int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows);

@@ -23,7 +23,7 @@ EXPORTS = (
     "svils_get_state", "svils_get_communities", "svils_get_aux", "svils_enable_timing",
     "svils_get_timing", "svils_kernel_name", "svils_sweep_phase", "svils_device_buffer",
     "svils_stream", "svils_last_error", "svils_abi_version", "svils_debug_eval",
-    "svils_set_timing_period",
+    "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default",
 )
 
 
@@ -31,6 +31,11 @@ class SvilsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("svils error %d: %s" % (code, msg))
         self.code = code
+
+
+class Stochastic(C.Structure):
+    _fields_ = [("batch_nodes", C.c_uint32), ("node_tau0", C.c_double), ("node_kappa", C.c_double),
+                ("tau0", C.c_double), ("kappa", C.c_double), ("seed", C.c_uint64)]
 
 
 class Config(C.Structure):
@@ -83,6 +88,10 @@ def load():
     L.svils_set_control.argtypes = [vp, C.POINTER(Control)]
     L.svils_validation_row.argtypes = [vp, vp]
     L.svils_sweep.argtypes = [vp, C.c_uint32]
+    L.svils_set_stochastic.argtypes = [vp, C.POINTER(Stochastic)]
+    L.svils_step.argtypes = [vp, C.c_uint32]
+    L.svils_stochastic_default.argtypes = [C.POINTER(Stochastic), C.c_uint32]
+    L.svils_stochastic_default.restype = None
     L.svils_synchronize.argtypes = [vp]
     L.svils_get_rows.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.svils_get_state.argtypes = [vp, vp, vp, vp]
@@ -184,6 +193,16 @@ class Engine:
 
     def sweep(self, nsweeps=1):
         _chk(load().svils_sweep(self._h, nsweeps))
+
+    def set_stochastic(self, batch_nodes=0, tau0=1024.0, kappa=0.9, node_tau0=None, node_kappa=None, seed=0):
+        """mini-batch mode (include/svils.h): windows of `batch_nodes` consecutive nodes per step;
+        node step sizes default to the lambda ones when not given"""
+        cfg = Stochastic(batch_nodes, tau0 if node_tau0 is None else node_tau0,
+                         kappa if node_kappa is None else node_kappa, tau0, kappa, seed)
+        _chk(load().svils_set_stochastic(self._h, C.byref(cfg)))
+
+    def step(self, nsteps=1):
+        _chk(load().svils_step(self._h, nsteps))
 
     def sweep_phase(self, phase):
         _chk(load().svils_sweep_phase(self._h, phase))

@@ -67,6 +67,13 @@ struct svils_handle {
   double t_ms[SVILS_KERNEL_COUNT] = {0};
   uint64_t t_n[SVILS_KERNEL_COUNT] = {0};
   std::vector<uint64_t> h_rowptr;  // kept for training_links / aux
+  // mini-batch (Robbins-Monro) mode, svils_set_stochastic / svils_step
+  bool stoch = false;
+  svils_stochastic scfg{};
+  uint64_t steps_done = 0;
+  std::vector<uint64_t> h_linkptr;      // [n+1] first training link whose first endpoint is >= node
+  std::vector<uint32_t> h_item_phi;     // [n+1] first phi item of a node (row-per-wavefront layout)
+  std::vector<uint32_t> h_item_s3;      // [n+1] first s3 item of a node
 };
 
 namespace {
@@ -120,29 +127,28 @@ struct Timed {
   }
 };
 
-int run_phase(svils_handle *h, svils_phase ph) {
-  const Geometry &g = h->geo;
-  const DeviceState &d = h->d;
+int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceState &d, const Params &prm) {
   hipStream_t s = h->stream;
   switch (ph) {
     case SVILS_PHASE_A: {
-      { Timed t(h, SVILS_KERNEL_PHI); launch_phi(g, d, h->prm, s); }
+      { Timed t(h, SVILS_KERNEL_PHI); launch_phi(g, d, prm, s); }
       { Timed t(h, SVILS_KERNEL_REDUCE_SUM); launch_reduce_a(g, d, s); }
     } break;
     case SVILS_PHASE_B: {
       Timed t(h, SVILS_KERNEL_FINALIZE);
-      launch_finalize(g, d, h->prm, s);
+      launch_finalize(g, d, prm, s);
+      if (prm.stoch) launch_carry_flags(g, d, s);
     } break;
     case SVILS_PHASE_C: {
       { Timed t(h, SVILS_KERNEL_S3); launch_s3(g, d, s); }
       { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
     } break;
     case SVILS_PHASE_EXPAND: {
-      launch_expand(g, d, h->prm, s);
+      launch_expand(g, d, prm, s);
     } break;
     case SVILS_PHASE_D: {
-      { Timed t(h, SVILS_KERNEL_VALIDATION); launch_validation(g, d, h->prm, 1, s); }
-      { Timed t(h, SVILS_KERNEL_TAIL); launch_tail(g, d, h->prm, s); }
+      { Timed t(h, SVILS_KERNEL_VALIDATION); launch_validation(g, d, prm, 1, s); }
+      { Timed t(h, SVILS_KERNEL_TAIL); launch_tail(g, d, prm, s); }
     } break;
     default:
       return fail(SVILS_ERR_ARG, "unknown phase %d", (int)ph);
@@ -152,6 +158,13 @@ int run_phase(svils_handle *h, svils_phase ph) {
   for (int i = 0; i < SVILS_KERNEL_COUNT; ++i)
     if (h->pending[i].size() > 8192) return drain_timing(h);
   return 0;
+}
+
+int run_phase(svils_handle *h, svils_phase ph) { return run_phase(h, ph, h->geo, h->d, h->prm); }
+
+void drop_graphs_of(svils_handle *h) {
+  if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
+  if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
 }
 
 // chunk a row segment [off, off+len) of node p into items of <= ch neighbours
@@ -257,6 +270,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   DeviceState &d = h->d;
   const size_t nk = (size_t)g.n_alloc * g.ld;
   guard(dalloc(h, &d.gamma, nk));
+  d.gacc = d.gamma;   // full sweeps accumulate gammanext in place
   guard(dalloc(h, &d.elogpi, nk));
   guard(dalloc(h, &d.mphi, nk));
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
@@ -350,11 +364,20 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   std::vector<int32_t> split_first(n, -1);
   std::vector<uint32_t> split_cnt(n, 0);
   int32_t next_slot = 0;
-  for (uint32_t p = g.node_begin; p < g.node_end; ++p) {
+  h->h_item_phi.assign((size_t)n + 1, 0);
+  h->h_item_s3.assign((size_t)n + 1, 0);
+  h->h_linkptr.assign((size_t)n + 1, 0);
+  for (uint32_t p = 0; p < n; ++p) {
+    h->h_item_phi[p] = (uint32_t)items_phi.size();
+    h->h_item_s3[p] = (uint32_t)items_s3.size();
     const uint32_t deg = (uint32_t)(rowptr[p + 1] - rowptr[p]);
+    h->h_linkptr[p + 1] = h->h_linkptr[p] + (deg - upper[p]);
+    if (p < g.node_begin || p >= g.node_end) continue;
     chunk_row(items_phi, p, 0, deg, ch, &next_slot, &split_first[p], &split_cnt[p]);
     chunk_row(items_s3, p, upper[p], deg - upper[p], ch, nullptr, nullptr, nullptr);
   }
+  h->h_item_phi[n] = (uint32_t)items_phi.size();
+  h->h_item_s3[n] = (uint32_t)items_s3.size();
   DeviceState &d = h->d;
   d.nitems_phi = (uint32_t)items_phi.size();
   d.nitems_s3 = (uint32_t)items_s3.size();
@@ -582,6 +605,7 @@ int graph_sweeps(svils_handle *h, uint32_t n) {
 int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
+  if (h->stoch) return fail(SVILS_ERR_ARG, "svils_sweep: the handle is in mini-batch mode, use svils_step");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (!h->graphs_ok || nsweeps < 4) return eager_sweeps(h, nsweeps);   // short calls are not worth a capture
   if (h->tmask == 0) return graph_sweeps(h, nsweeps);
@@ -604,6 +628,104 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
 int svils_set_timing_period(svils_handle *h, uint32_t period) {
   if (!h || period == 0) return fail(SVILS_ERR_ARG, "svils_set_timing_period: bad argument");
   h->tperiod = period;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mini-batch (Robbins-Monro) steps.  One step = the sweep's four phases restricted to a window of
+// consecutive nodes [b, e): phi pass over the window's CSR rows, finalise of the window's rows
+// blended into the old gamma with the node's own step size, s3 over the links whose first endpoint
+// lies in the window, then lambda blended with rho_lambda, likelihood row and stop rule as in a
+// full sweep.  Window sums are scaled to estimates of the full sums (Params::scale_a/scale_c); with
+// the window = all nodes and kappa = 0 (rho = 1) a step IS a full sweep.
+// ---------------------------------------------------------------------------------------------
+void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes) {
+  if (!cfg) return;
+  cfg->batch_nodes = batch_nodes;
+  cfg->node_tau0 = 1024; cfg->node_kappa = 0.5;   // src/env.hh:405-408
+  cfg->tau0 = 1024; cfg->kappa = 0.9;
+  cfg->seed = 0;
+}
+
+int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
+  if (!h || !cfg) return fail(SVILS_ERR_ARG, "svils_set_stochastic: null argument");
+  if (!(cfg->tau0 >= 1.0) || !(cfg->kappa >= 0.0) || cfg->kappa > 1.0 || !(cfg->node_tau0 >= 1.0) ||
+      !(cfg->node_kappa >= 0.0) || cfg->node_kappa > 1.0)
+    return fail(SVILS_ERR_ARG, "svils_set_stochastic: need tau0 >= 1 and 0 <= kappa <= 1");
+  if (h->geo.node_begin != 0 || h->geo.node_end != h->geo.n)
+    return fail(SVILS_ERR_UNSUPPORTED, "svils_set_stochastic: not available on a node-block shard");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DeviceState &d = h->d;
+  if (!h->stoch) {
+    int rc = 0;
+    double *gacc = nullptr;
+    if ((rc = dalloc(h, &gacc, (size_t)h->geo.n_alloc * h->geo.ld))) return rc;
+    if ((rc = dalloc(h, &d.ncnt, h->geo.n_alloc))) return rc;
+    if ((rc = dalloc(h, &d.s12run, 2 * (size_t)h->geo.K))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    d.gacc = gacc;
+    drop_graphs_of(h);   // captured launches hold gacc == gamma
+  }
+  h->stoch = true;
+  h->scfg = *cfg;
+  return 0;
+}
+
+int svils_step(svils_handle *h, uint32_t nsteps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_step: null handle");
+  if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step: call svils_set_stochastic first");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_step: set graph and state first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const uint32_t n = h->geo.n;
+  const uint32_t bn = (h->scfg.batch_nodes == 0 || h->scfg.batch_nodes > n) ? n : h->scfg.batch_nodes;
+  const uint32_t nblocks = (n + bn - 1) / bn;
+  for (uint32_t s = 0; s < nsteps; ++s, ++h->steps_done) {
+    // windows in a fixed cyclic order; callers randomise the node order
+    const uint32_t blk = (uint32_t)((h->steps_done + h->scfg.seed) % nblocks);
+    const uint32_t b = blk * bn, e = std::min(n, b + bn);
+    Geometry g = h->geo;
+    DeviceState d = h->d;
+    Params p = h->prm;
+    g.node_begin = b;
+    g.node_end = e;
+    d.ent_begin = h->h_rowptr[b];
+    d.ent_end = h->h_rowptr[e];
+    d.lpl_w0 = d.ent_begin >> 6;
+    d.lpl_nitems = d.ent_end > d.ent_begin ? (uint32_t)(((d.ent_end + 63) >> 6) - d.lpl_w0) : 0;
+    d.link_begin = h->h_linkptr[b];
+    d.link_end = h->h_linkptr[e];
+    d.item0_phi = h->h_item_phi[b];
+    d.nitems_phi = h->h_item_phi[e] - h->h_item_phi[b];
+    d.item0_s3 = h->h_item_s3[b];
+    d.nitems_s3 = h->h_item_s3[e] - h->h_item_s3[b];
+    // grids sized for the window (never larger than the allocation made for full sweeps)
+    {
+      auto fit = [](uint64_t want, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, lim)); };
+      const int G = 64 / g.W;
+      d.nb_b = fit(((uint64_t)(e - b) + 4 * G - 1) / (4 * G), h->d.nb_b);
+      if (d.lpl) {
+        const int nw = lpl_phi_waves(g.K);
+        d.nb_a = fit((d.lpl_nitems + nw - 1) / nw, h->d.nb_a);
+        d.nb_c = fit((d.link_end - d.link_begin + 255) / 256, h->d.nb_c);
+      } else {
+        d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);
+        d.nb_c = fit(((uint64_t)d.nitems_s3 + 3) / 4, h->d.nb_c);
+      }
+    }
+    p.stoch = 1;
+    p.tau0 = h->scfg.node_tau0;
+    p.kappa = h->scfg.node_kappa;
+    p.rho_lambda = std::pow(h->scfg.tau0 + (double)h->steps_done, -h->scfg.kappa);
+    const uint64_t ents = d.ent_end - d.ent_begin, ups = d.link_end - d.link_begin;
+    p.scale_a = ents ? (double)(2 * h->d.nlinks) / (double)ents : 0.0;
+    p.scale_c = ups ? (double)h->d.nlinks / (double)ups : 0.0;
+    int rc;
+    if ((rc = run_phase(h, SVILS_PHASE_A, g, d, p))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_B, g, d, p))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_C, g, d, p))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_D, g, d, p))) return rc;
+  }
   return 0;
 }
 

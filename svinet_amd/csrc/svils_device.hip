@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
   unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
 
   for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_phi; it += gridDim.x * 4) {
-    const Item item = d.items_phi[it];
+    const Item item = d.items_phi[d.item0_phi + it];
     const uint32_t p = item.node;
     const uint64_t base = d.rowptr[p] + item.off;
     const uint32_t len = item.len;   // <= 64 (chunk limit 32)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
 #pragma unroll
     for (int v = 0; v < V; ++v) csum[0][v] += acc[v];
     if (item.slot < 0) {
-      store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
+      store_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
       if (write_comm) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -207,6 +207,9 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
   block_store_link_counts(n_dense, n_sparse, n_short, d.part_links, lcnt, 4);
 }
 
+#ifndef SVILS_FIN_WAVES
+#define SVILS_FIN_WAVES(V) 1
+#endif
 // ===================================================== column reduce of partials
 // out[c] = sum_b part[b][c] in a fixed order: 4 columns x 64 row-segments per block.
 // Up to two jobs per launch (blockIdx.x < nblk0 -> job 0).
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
 // compute_mean_indicators (src/linksampling.cc:526-545), the gamma swap/reset
 // (:751-755), set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491),
 // one group per owned node.
-template <int W, int V>
-__global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, Params prm) {
+template <int W, int V, bool STOCH>
+__global__ __launch_bounds__(256, SVILS_FIN_WAVES(V)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
@@ -268,7 +271,10 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
     kidx[v] = kmap<W, V>(lw, v);
     kval[v] = (uint32_t)kidx[v] < K;
     // _network.ones() / _sum[k], src/linksampling.cc:542
-    scale[v] = (annealing && kval[v]) ? (double)prm.ones / d.kvec_a[kidx[v]] : 1.0;
+    // (mini-batch step: kvec_a is the window's sum, scaled to an estimate of the full one)
+    scale[v] = (annealing && kval[v])
+                   ? (double)prm.ones / (STOCH ? d.kvec_a[kidx[v]] * prm.scale_a : d.kvec_a[kidx[v]])
+                   : 1.0;
   }
   double s12[2][V];
 #pragma unroll
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
         if (w0 == w1) {
           const double *src = ((r0 & 63) == 0) ? d.slot_f + (size_t)(w0 - d.lpl_w0) * ld
                               : (((r1 - 1) & 63) == 63) ? d.slot_l + (size_t)(w0 - d.lpl_w0) * ld
-                                                        : d.gamma + (size_t)p * ld;
+                                                        : d.gacc + (size_t)p * ld;
           s = src[lw];
         } else {
           for (uint64_t w = w0; w <= w1; ++w) {
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
         }
       }
     } else if (sf < 0) {
-      load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, acc);
+      load_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
     } else {
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = 0.0;
@@ -349,6 +355,24 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
         if (annealing) gn[v] *= scale[v];
         if (kval[v]) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; }
         else { m[v] = 0.0; gn[v] = 0.0; }
+      }
+      if constexpr (STOCH) {
+        // Robbins-Monro step of this node: gamma <- (1 - rho) gamma + rho gamma_hat with
+        // rho = (tau0 + c)^-kappa, c = updates the node has had; s1/s2 are kept as running sums
+        // over the stored mphi rows, so this row contributes (new - old)
+        const uint32_t c = d.ncnt[p];
+        const double rho = exp_neg(-prm.kappa * log_tab(prm.tau0 + (double)c, logtab));
+        double gold[V], mold[V];
+        load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gold);
+        load_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, mold);
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (kval[v]) {
+            gn[v] = (1.0 - rho) * gold[v] + rho * gn[v];
+            s12[0][v] -= mold[v];
+            s12[1][v] -= mold[v] * mold[v];
+          }
+        if (lw == 0) d.ncnt[p] = c + 1u;
       }
       store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     } else {
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
   for (int v = 0; v < V; ++v) s3[0][v] = 0.0;
 
   for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_s3; it += gridDim.x * 4) {
-    const Item item = d.items_s3[it];
+    const Item item = d.items_s3[d.item0_s3 + it];
     const uint32_t p = item.node;
     const uint64_t base = d.rowptr[p] + item.off;
     const uint32_t pc = conv[p];
@@ -525,6 +549,30 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
   block_reduce_store<W, V, 1>(s3, d.part_c + (size_t)blockIdx.x * K, K, lds);
 }
 
+// lambda of the sweep being finished, from the reduced K-vectors (src/linksampling.cc:748-754).
+// Full sweep: lambda[k] = (eta0 + sum[k], eta1 + s1^2 - s2 - s3).  Mini-batch step: sum and s3 are
+// window sums scaled to estimates of the full ones, s1/s2 are running totals (previous total + this
+// window's change), and the result is blended into the old lambda with the step size rho_lambda.
+// Returns the running s1, s2 through s1r/s2r (what k_tail stores back in mini-batch mode).
+__device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Params &prm, uint32_t K, uint32_t k,
+                                                double &l0, double &l1, double &s1r, double &s2r) {
+  double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
+  if (!prm.stoch) {
+    l0 = prm.eta0 + d.kvec_a[k];
+    l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+  } else {
+    s1 += d.s12run[k];
+    s2 += d.s12run[K + k];
+    s3 *= prm.scale_c;
+    const double h0 = prm.eta0 + d.kvec_a[k] * prm.scale_a;
+    const double h1 = prm.eta1 + (s1 * s1 - s2 - s3);
+    l0 = (1.0 - prm.rho_lambda) * d.lambda[2 * k] + prm.rho_lambda * h0;
+    l1 = (1.0 - prm.rho_lambda) * d.lambda[2 * k + 1] + prm.rho_lambda * h1;
+  }
+  s1r = s1;
+  s2r = s2;
+}
+
 // ================================================== validation likelihood (A10)
 // edge_likelihood (src/linksampling.hh:258-292), one group per held-out pair.
 // The non-link K^2 double loop collapses exactly:
@@ -550,9 +598,8 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
     if ((uint32_t)k < K) {
       double l0, l1;
       if (in_loop) {  // lambda of this sweep, same expression as k_tail
-        l0 = prm.eta0 + d.kvec_a[k];
-        const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
-        l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+        double s1r, s2r;
+        lambda_of_sweep(d, prm, K, (uint32_t)k, l0, l1, s1r, s2r);
       } else {
         l0 = d.lambda[2 * k];
         l1 = d.lambda[2 * k + 1];
@@ -581,6 +628,17 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
     if (s < 1e-30) s = 1e-30;
     if (lw == 0) d.uval[i] = log(s);
   }
+}
+
+// Mini-batch step over a node window: prune() wrote conv[parity^1] for the window's rows only;
+// every other row carries its flag over so that the parity flip in k_tail keeps it.
+__global__ __launch_bounds__(256) void k_carry_flags(Geometry geo, DeviceState d) {
+  const DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < geo.n; p += gridDim.x * blockDim.x)
+    if (p < geo.node_begin || p >= geo.node_end) conv_new[p] = conv_old[p];
 }
 
 // =============================================================== tail (A8/A10/A11)
@@ -618,11 +676,11 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   cred[0][threadIdx.x] = kz; cred[1][threadIdx.x] = t0; cred[2][threadIdx.x] = t1; cred[3][threadIdx.x] = t2;
   // lambda update + set_dir_exp(lambda), src/linksampling.cc:748-759
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-    const double l0 = prm.eta0 + d.kvec_a[k];
-    const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
-    const double l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+    double l0, l1, s1r, s2r;
+    lambda_of_sweep(d, prm, K, k, l0, l1, s1r, s2r);
     d.lambda[2 * k] = l0;
     d.lambda[2 * k + 1] = l1;
+    if (prm.stoch) { d.s12run[k] = s1r; d.s12run[K + k] = s2r; }
     const double ps = digamma(l0 + l1, logtab);
     d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
     d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
@@ -641,7 +699,8 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     c.parity ^= 1u;  // prune()'s flags become current
     c.links_dense = cred[1][0]; c.links_sparse = cred[2][0]; c.links_shortcut = cred[3][0];
     c.sweeps_done++;
-    c.write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+    // (mini-batch steps tag on every step: a window is only visited once per pass over the nodes)
+    c.write_comm = (prm.stoch || iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
     bool exit_now = false;
     if (do_val) {
       const double szeros = red[0][0], sones = red[1][0];
@@ -781,7 +840,11 @@ void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s) {
   hipLaunchKernelGGL(k_colreduce, dim3(nblk0), dim3(256), 0, s, j0, j0, nblk0, d.ctrl);
 }
 void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-#define CALL(W_, V_) hipLaunchKernelGGL((k_finalize<W_, V_>), dim3(d.nb_b), dim3(256), 0, s, g, d, p)
+#define CALL(W_, V_)                                                                                     \
+  do {                                                                                                   \
+    if (p.stoch) hipLaunchKernelGGL((k_finalize<W_, V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p); \
+    else hipLaunchKernelGGL((k_finalize<W_, V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p);        \
+  } while (0)
   SVILS_DISPATCH(g, CALL);
 #undef CALL
 }
@@ -815,6 +878,12 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
 }
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, g, d, p);
+}
+void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  if (g.node_end - g.node_begin >= g.n) return;
+  uint32_t nb = (g.n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_carry_flags, dim3(nb), dim3(256), 0, s, g, d);
 }
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   const uint32_t nother = g.n - (g.node_end - g.node_begin);

@@ -51,6 +51,7 @@ struct DeviceState {
   uint32_t nitems_phi;
   Item *items_s3;       // chunks over the upper part of owned rows
   uint32_t nitems_s3;
+  uint32_t item0_phi, item0_s3;   // first item of the current node window (0 outside mini-batch steps)
   int32_t *split_first; // [n] first slot of a split row or -1
   uint32_t *split_cnt;  // [n]
   uint32_t nslots;
@@ -71,6 +72,10 @@ struct DeviceState {
   uint32_t *fcnt;       // [n_alloc][ld] tag counts (lt_min_deg > 0), else null
   // state
   double *gamma;        // [n_alloc][ld]; doubles as gammanext-accumulator inside a sweep
+  double *gacc;         // where the phi pass accumulates gammanext: == gamma for full sweeps, a separate
+                        // [n_alloc][ld] buffer in mini-batch mode (the old gamma row is blended in)
+  uint32_t *ncnt;       // [n_alloc] mini-batch mode: number of updates each node has received
+  double *s12run;       // [2K]     mini-batch mode: running s1, s2 over the stored mphi rows
   double *elogpi;       // [n_alloc][ld]
   double *mphi;         // [n_alloc][ld]
   uint32_t *conv;       // [2][n_alloc]
@@ -103,6 +108,12 @@ struct Params {
   uint32_t lt_min_deg, reportfreq;
   int32_t use_validation_stop;
   double ones_prob, zeros_prob;
+  // mini-batch (Robbins-Monro) steps, svils_step(); all neutral for full sweeps
+  int32_t stoch;          // 1: this launch is a mini-batch step over the node window [node_begin, node_end)
+  double tau0, kappa;     // step size of a node that has been updated c times: (tau0 + c)^-kappa (node_tau0/node_kappa)
+  double rho_lambda;      // step size of the global lambda update of this step
+  double scale_a;         // 2L / (CSR entries of the window): window `sum` -> estimate of the full `sum`
+  double scale_c;         // L / (links whose first endpoint is in the window): window s3 -> estimate of s3
 };
 
 // launchers (svils_device.hip); all asynchronous on `s`
@@ -119,6 +130,7 @@ void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
                        hipStream_t s);
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d
           for (int j = 0; j < 16; ++j) {
             const int r = half * 32 + rb + j;
             if (r > 0 && ((heads >> r) & 1ull)) {      // run [a, r-1] ends (wave-uniform branch)
-              LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.gamma + (size_t)cur * ld, r - 1);
+              LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.gacc + (size_t)cur * ld, r - 1);
               a = r;
             }
             acc += v[j];

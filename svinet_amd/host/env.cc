@@ -65,7 +65,8 @@ Env::Env(const Args &a)
       datfname(a.datfname), label(a.label),
       batch_mode(a.batch), link_sampling(a.link_sampling), strid(a.strid),
       terminate(0), total_pairs(0), ones_prob(0), zeros_prob(1),
-      device(a.device), sweep_batch(a.sweep_batch ? a.sweep_batch : 1), write_files(a.write_files) {
+      device(a.device), sweep_batch(a.sweep_batch ? a.sweep_batch : 1), write_files(a.write_files),
+      minibatch(a.minibatch), tau0(a.tau0), kappa(a.kappa), nodetau0(a.nodetau0), nodekappa(a.nodekappa) {
   if (!write_files) {
     if (plogf_) { fclose(plogf_); plogf_ = nullptr; }
     prefix.clear();
@@ -142,6 +143,13 @@ Env::Env(const Args &a)
   plog("test_file_location", load_test_fname);
   plog("reportfreq", reportfreq);
   plog("eta_type", eta_type);
+  if (minibatch) {   // keys of this build (mini-batch mode), after the reference's
+    plog("link_sampling_minibatch_nodes", minibatch);
+    plog("tau0", tau0);
+    plog("kappa", kappa);
+    plog("nodetau0", nodetau0);
+    plog("nodekappa", nodekappa);
+  }
   // network.dat symlink, src/env.hh:621-625
   std::string nd = file_str("/network.dat");
   unlink(nd.c_str());

@@ -41,6 +41,9 @@ class Env {
     uint32_t sweep_batch = 1;   // sweeps enqueued between host polls
     std::string outdir_root;    // directory in which the output dir is created ("" = cwd)
     bool write_files = true;    // false: library use (bench / tests), nothing touches the disk
+    // mini-batch mode of -link-sampling (include/svils.h, svils_step): 0 = full sweeps (the reference's loop)
+    uint32_t minibatch = 0;     // nodes per mini-batch
+    double tau0 = 1024, kappa = 0.9, nodetau0 = 1024, nodekappa = 0.5;   // src/env.hh:405-408
   };
 
   explicit Env(const Args &a);
@@ -79,6 +82,8 @@ class Env {
   int device;
   uint32_t sweep_batch;
   bool write_files;
+  uint32_t minibatch;
+  double tau0, kappa, nodetau0, nodekappa;
 
   static std::string prefix;
   static std::string file_str(const std::string &fname) { return prefix + fname; }

@@ -1,5 +1,7 @@
 #include "linksampling.hh"
 
+#include <random>
+
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
@@ -140,10 +142,34 @@ void LinkSampling::attach() {
   cfg.zeros_prob = zeros_prob_;
   cfg.device = env_.device;
   if (svils_create(&cfg, &h_)) die_svils("svils_create");
+  if (env_.minibatch) {
+    // random relabelling (own generator: the GSL stream of the samplers / init is not disturbed)
+    std::mt19937_64 eng(0x5eed5eedull + (uint64_t)env_.seed);
+    dev_of_.resize(n_);
+    for (uint32_t i = 0; i < n_; ++i) dev_of_[i] = i;
+    for (uint32_t i = n_; i > 1; --i) std::swap(dev_of_[i - 1], dev_of_[eng() % i]);
+    seq_of_.resize(n_);
+    for (uint32_t i = 0; i < n_; ++i) seq_of_[dev_of_[i]] = i;
+    svils_stochastic sc;
+    svils_stochastic_default(&sc, env_.minibatch);
+    sc.tau0 = env_.tau0; sc.kappa = env_.kappa; sc.node_tau0 = env_.nodetau0; sc.node_kappa = env_.nodekappa;
+    if (svils_set_stochastic(h_, &sc)) die_svils("svils_set_stochastic");
+  }
   // with -accuracy validation_likelihood() returns at once (:969-970)
-  if (!env_.accuracy && !val_sorted_.empty())
-    if (svils_set_validation(h_, val_sorted_.data(), val_sorted_.size() / 3)) die_svils("svils_set_validation");
-  if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
+  if (!env_.accuracy && !val_sorted_.empty()) {
+    std::vector<uint32_t> v(val_sorted_);
+    if (!dev_of_.empty())
+      for (size_t i = 0; i < v.size(); i += 3) { v[i] = dev_of_[v[i]]; v[i + 1] = dev_of_[v[i + 1]]; }
+    if (svils_set_validation(h_, v.data(), v.size() / 3)) die_svils("svils_set_validation");
+  }
+  if (dev_of_.empty()) {
+    if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
+  } else {
+    std::vector<double> g((size_t)n_ * k_);
+    for (uint32_t i = 0; i < n_; ++i)
+      std::copy(&gamma_[(size_t)i * k_], &gamma_[(size_t)(i + 1) * k_], &g[(size_t)dev_of_[i] * k_]);
+    if (svils_set_state(h_, g.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
+  }
 }
 
 // ---------------------------------------------------------------- validation set
@@ -311,6 +337,12 @@ void LinkSampling::write_max(const double *r, int why, double max_h) const {   /
 void LinkSampling::save_model() {                          // src/linksampling.cc:804-837
   std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
   if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
+  if (!dev_of_.empty()) {   // back to sequence-id order
+    std::vector<double> t((size_t)n_ * k_);
+    for (uint32_t i = 0; i < n_; ++i)
+      std::copy(&g[(size_t)dev_of_[i] * k_], &g[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
+    g.swap(t);
+  }
   FILE *gf = open_or_die(Env::file_str("/gamma.txt"), "gamma");
   const std::vector<uint32_t> &s2i = network_.seq2id();
   for (uint32_t i = 0; i < n_; ++i) {
@@ -343,6 +375,12 @@ void LinkSampling::write_groups() {                        // src/linksampling.c
 void LinkSampling::log_communities() {                     // :839-852, :882-917
   member_.assign((size_t)n_ * k_, 0);
   if (svils_get_communities(h_, member_.data())) die_svils("svils_get_communities");
+  if (!dev_of_.empty()) {
+    std::vector<uint8_t> t((size_t)n_ * k_);
+    for (uint32_t i = 0; i < n_; ++i)
+      std::copy(&member_[(size_t)dev_of_[i] * k_], &member_[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
+    member_.swap(t);
+  }
   FILE *f = open_or_die(Env::file_str("/communities.txt"), "communities");
   const std::vector<uint32_t> &s2i = network_.seq2id();
   std::vector<uint32_t> ids;
@@ -393,7 +431,17 @@ int LinkSampling::infer() {
   }
   if (!graph_sent_) {
     const std::vector<uint32_t> &L = training_links();
-    if (svils_set_graph(h_, L.data(), L.size() / 2)) die_svils("svils_set_graph");
+    if (dev_of_.empty()) {
+      if (svils_set_graph(h_, L.data(), L.size() / 2)) die_svils("svils_set_graph");
+    } else {
+      std::vector<std::pair<uint32_t, uint32_t> > R(L.size() / 2);
+      for (size_t i = 0; i < R.size(); ++i) {
+        const uint32_t a = dev_of_[L[2 * i]], b = dev_of_[L[2 * i + 1]];
+        R[i] = a < b ? std::make_pair(a, b) : std::make_pair(b, a);
+      }
+      std::sort(R.begin(), R.end());
+      if (svils_set_graph(h_, &R[0].first, R.size())) die_svils("svils_set_graph");
+    }
     graph_sent_ = true;
   }
   const uint64_t nlinks = links_.size() / 2;
@@ -415,7 +463,11 @@ int LinkSampling::infer() {
     if (env_.max_iterations) batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - c.iter);
     printf("\riteration %d: processing %d links", c.iter, (int)nlinks);
     fflush(stdout);
-    if (svils_sweep(h_, batch)) die_svils("svils_sweep");
+    if (env_.minibatch) {
+      if (svils_step(h_, batch)) die_svils("svils_step");
+    } else if (svils_sweep(h_, batch)) {
+      die_svils("svils_sweep");
+    }
     fetch_and_log_rows();
     if (svils_get_control(h_, &c)) die_svils("svils_get_control");
     if (env_.write_files && !c.stopped) log_communities();        // :785

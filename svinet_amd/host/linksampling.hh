@@ -81,6 +81,9 @@ class LinkSampling {
   std::vector<uint32_t> links_;
   bool links_done_ = false;
   std::vector<uint8_t> member_;                // last downloaded communities [n][k]
+  // mini-batch mode: nodes are handed to the device under a random relabelling so that a window of
+  // consecutive device ids is a uniform random subset; dev_of_[seq] / seq_of_[dev], empty otherwise
+  std::vector<uint32_t> dev_of_, seq_of_;
   svils_handle *h_ = nullptr;
   bool graph_sent_ = false;
   uint32_t rows_logged_ = 0;

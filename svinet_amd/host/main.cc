@@ -52,7 +52,10 @@ static void usage() {
           "\t-heldout-ratio, -link-thresh, -lt-min-deg, -eta-type, -accuracy\tas in the reference\n\n"
           "\t-strid\t\tnode names are strings (writes str2id.txt)\n\n"
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
-          "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n");
+          "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
+          "\t-minibatch <m>\tmini-batch mode of -link-sampling: one step = the links of m randomly chosen nodes,\n"
+          "\t\t\tRobbins-Monro step sizes (-tau0 -kappa -nodetau0 -nodekappa; defaults 1024 0.9 1024 0.5);\n"
+          "\t\t\tgive -rfreq <steps> after -link-sampling to evaluate the stop rule every <steps> steps\n\n");
   fflush(stdout);
 }
 
@@ -100,6 +103,11 @@ int main(int argc, char **argv) {
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
     else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
+    else if (is("-minibatch")) { need(i); a.minibatch = atoi(argv[++i]); }
+    else if (is("-tau0")) { need(i); a.tau0 = atof(argv[++i]); }
+    else if (is("-kappa")) { need(i); a.kappa = atof(argv[++i]); }
+    else if (is("-nodetau0")) { need(i); a.nodetau0 = atof(argv[++i]); }
+    else if (is("-nodekappa")) { need(i); a.nodekappa = atof(argv[++i]); }
     else if (is("-stopthresh") || is("-inf") || is("-scale") || is("-itype") || is("-groups-file") ||
              is("-init-communities")) {
       need(i); ++i;   // value flags of other engines: consumed, no effect on this path

@@ -124,3 +124,28 @@ def test_cli_max_iterations_one(graph_files, tmp_path):
     ref.write_model(str(rd))
     _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
     assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+
+
+def test_cli_minibatch_mode(graph_files, tmp_path):
+    """-minibatch: mini-batch steps through the CLI (random node relabelling on the host side is
+    undone in every output file)."""
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-rfreq", "5", "-no-stop",
+              "-max-iterations", "199", "-minibatch", "200", "-tau0", "1", "-kappa", "0.5", "-nodetau0", "1",
+              "-nodekappa", "0.5", "-sweep-batch", "5"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    gam = np.loadtxt(d / "gamma.txt")
+    assert gam.shape == (1000, 30) and np.all(gam[:, 2:] > 0)
+    rows = np.loadtxt(d / "validation.txt")
+    assert rows[-1, 10] > rows[0, 10]
+    assert np.array_equal(rows[1:, 0], np.arange(0, 200, 5))
+    assert "link_sampling_minibatch_nodes: 200" in (d / "param.txt").read_text()
+    # gamma rows are in sequence-id order again: a node's strongest community agrees with its neighbours' more
+    # often than with random nodes'
+    edges = np.array([[int(x) for x in l.split()] for l in open(graph_files["lfr"]) if l.strip()])
+    ids = gam[:, 1].astype(int)
+    top = dict(zip(ids, gam[:, 2:].argmax(1)))
+    same = np.mean([top[a] == top[b] for a, b in edges])
+    rng = np.random.default_rng(0)
+    rnd = np.mean([top[a] == top[b] for a, b in zip(rng.permutation(ids), rng.permutation(ids))])
+    assert same > rnd + 0.3
