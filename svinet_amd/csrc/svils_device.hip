@@ -554,10 +554,11 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
 // window sums scaled to estimates of the full ones, s1/s2 are running totals (previous total + this
 // window's change), and the result is blended into the old lambda with the step size rho_lambda.
 // Returns the running s1, s2 through s1r/s2r (what k_tail stores back in mini-batch mode).
+template <bool STOCH>
 __device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Params &prm, uint32_t K, uint32_t k,
                                                 double &l0, double &l1, double &s1r, double &s2r) {
   double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
-  if (!prm.stoch) {
+  if constexpr (!STOCH) {
     l0 = prm.eta0 + d.kvec_a[k];
     l1 = prm.eta1 + (s1 * s1 - s2 - s3);
   } else {
@@ -578,7 +579,7 @@ __device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Para
 // The non-link K^2 double loop collapses exactly:
 //   sum_{z,z'} pi_p[z] pi_q[z'] (1 - [z==z'] beta_z - [z!=z'] eps), 1 - eps == 1.0 in double
 //   = (sum pi_p)(sum pi_q) - sum_z pi_p[z] pi_q[z] beta_z .
-template <int W, int V>
+template <int W, int V, bool STOCH>
 __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d, Params prm,
                                                     int in_loop) {
   const DevCtrl *ctrl = d.ctrl;
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
       double l0, l1;
       if (in_loop) {  // lambda of this sweep, same expression as k_tail
         double s1r, s2r;
-        lambda_of_sweep(d, prm, K, (uint32_t)k, l0, l1, s1r, s2r);
+        lambda_of_sweep<STOCH>(d, prm, K, (uint32_t)k, l0, l1, s1r, s2r);
       } else {
         l0 = d.lambda[2 * k];
         l1 = d.lambda[2 * k + 1];
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(256) void k_carry_flags(Geometry geo, DeviceState d
 // lambda update + set_dir_exp(lambda) (src/linksampling.cc:748-759), the
 // likelihood row, stop rule and annealing switch of validation_likelihood
 // (:994-1049), write_comm for the next sweep (:768-774) and _iter++ (:787).
+template <bool STOCH>
 __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Params prm) {
   // the control block is read once, updated in registers by thread 0 and written back once
   DevCtrl c = *d.ctrl;
@@ -677,10 +679,10 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   // lambda update + set_dir_exp(lambda), src/linksampling.cc:748-759
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
     double l0, l1, s1r, s2r;
-    lambda_of_sweep(d, prm, K, k, l0, l1, s1r, s2r);
+    lambda_of_sweep<STOCH>(d, prm, K, k, l0, l1, s1r, s2r);
     d.lambda[2 * k] = l0;
     d.lambda[2 * k + 1] = l1;
-    if (prm.stoch) { d.s12run[k] = s1r; d.s12run[K + k] = s2r; }
+    if constexpr (STOCH) { d.s12run[k] = s1r; d.s12run[K + k] = s2r; }
     const double ps = digamma(l0 + l1, logtab);
     d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
     d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     c.links_dense = cred[1][0]; c.links_sparse = cred[2][0]; c.links_shortcut = cred[3][0];
     c.sweeps_done++;
     // (mini-batch steps tag on every step: a window is only visited once per pass over the nodes)
-    c.write_comm = (prm.stoch || iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+    c.write_comm = (STOCH || iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
     bool exit_now = false;
     if (do_val) {
       const double szeros = red[0][0], sones = red[1][0];
@@ -872,12 +874,16 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
   uint32_t nb = (d.nv + 4 * G - 1) / (4 * G);
   if (nb > 2048) nb = 2048;
 #define CALL(W_, V_) \
-  hipLaunchKernelGGL((k_validation<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, p, in_loop)
+  do {                                                                                                       \
+    if (p.stoch) hipLaunchKernelGGL((k_validation<W_, V_, true>), dim3(nb), dim3(256), 0, s, g, d, p, in_loop); \
+    else hipLaunchKernelGGL((k_validation<W_, V_, false>), dim3(nb), dim3(256), 0, s, g, d, p, in_loop);        \
+  } while (0)
   SVILS_DISPATCH(g, CALL);
 #undef CALL
 }
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-  hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, g, d, p);
+  if (p.stoch) hipLaunchKernelGGL(k_tail<true>, dim3(1), dim3(256), 0, s, g, d, p);
+  else hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(256), 0, s, g, d, p);
 }
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s) {
   if (g.node_end - g.node_begin >= g.n) return;
