@@ -383,9 +383,10 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   d.nitems_s3 = (uint32_t)items_s3.size();
   d.nslots = (uint32_t)next_slot;
   auto cap = [](uint64_t x, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(x, lim)); };
-  d.nb_a = cap((d.nitems_phi + 3) / 4, 2048);
-  d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), 1024);
-  d.nb_c = cap((d.nitems_s3 + 3) / 4, 2048);
+  // grids of the row-per-wavefront kernels: whole multiples of the resident block count
+  d.nb_a = cap((d.nitems_phi + 3) / 4, 4 * rpw_resident_blocks(g, 0, h->cfg.device));
+  d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), rpw_resident_blocks(g, 2, h->cfg.device));
+  d.nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
   // lane-per-link layout for small K: wave-items of 64 consecutive CSR entries
   d.lpl = use_lpl(g.K) ? 1 : 0;
   d.nlinks = nlinks;

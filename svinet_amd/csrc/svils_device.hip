@@ -836,6 +836,41 @@ void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStr
     default: hipLaunchKernelGGL((k_phi<32>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
   }
 }
+// Blocks of the row-per-wavefront phi / s3 kernels resident on the device at once.  Grids are
+// made a whole multiple of this: with variable-length items more blocks balance better, but a
+// last partial round of blocks idles most of the chip (measured: 2048 blocks at 1536 resident
+// cost +12 % on k_s3<64,8>).
+uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
+  int per_cu = 0, cus = 0;
+#define OCC(KERNEL) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0)
+  if (which == 0) {
+    switch (g.V) {
+      case 1: OCC(k_phi<1>); break;
+      case 2: OCC(k_phi<2>); break;
+      case 4: OCC(k_phi<4>); break;
+      case 8: OCC(k_phi<8>); break;
+      case 16: OCC(k_phi<16>); break;
+      default: OCC(k_phi<32>); break;
+    }
+  } else if (which == 2) {
+#define CALL(W_, V_) OCC((k_finalize<W_, V_, false>))
+    SVILS_DISPATCH(g, CALL);
+#undef CALL
+  } else {
+    switch (g.V) {
+      case 1: OCC((k_s3<64, 1>)); break;
+      case 2: OCC((k_s3<64, 2>)); break;
+      case 4: OCC((k_s3<64, 4>)); break;
+      case 8: OCC((k_s3<64, 8>)); break;
+      case 16: OCC((k_s3<64, 16>)); break;
+      default: OCC((k_s3<64, 32>)); break;
+    }
+  }
+#undef OCC
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (per_cu <= 0 || cus <= 0) return 1024;
+  return (uint32_t)per_cu * (uint32_t)cus;
+}
 void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const ReduceJob j0{d.part_a, d.kvec_a, d.nb_a, g.K};
   const uint32_t nblk0 = (g.K + 3) / 4;

@@ -120,6 +120,7 @@ struct Params {
 bool use_lpl(uint32_t K);
 int lpl_phi_waves(uint32_t K);
 uint32_t lpl_phi_resident_blocks(uint32_t K, int device);
+uint32_t rpw_resident_blocks(const Geometry &g, int which /*0 phi, 1 s3, 2 finalize*/, int device);
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
