@@ -13,6 +13,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a clean checkout has no built artefacts (they are git-ignored): build them once, in-tree
+    need = [os.path.join(ROOT, "svinet_amd", "lib", "libsvils.so"),
+            os.path.join(ROOT, "svinet_amd", "lib", "libsvinet_host.so"),
+            os.path.join(ROOT, "svinet_amd", "bin", "svinet")]
+    if not all(os.path.exists(f) for f in need):
+        from svinet_amd import build
+        build.build_all()
 
 
 @pytest.fixture(scope="session")
