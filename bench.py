@@ -120,6 +120,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SVILS_BENCH_ONE_DEVICE"):   # protocol debugging on a 1-GPU box: every rank on device 0
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
@@ -133,7 +135,9 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             import datetime
-            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+            backend = os.environ.get("SVILS_BENCH_BACKEND", "nccl")
+            kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600), **kw)
 
     # ---- inputs: product host side (C++), resident in HBM before timing ----
     path, pairs = None, None

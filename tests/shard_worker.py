@@ -1,0 +1,39 @@
+"""worker of tests/test_gpu_sharded.py::test_two_processes_one_gpu -- one rank of a ShardedSweep run.
+Launched by torch.distributed.run; every rank uses GPU 0 (the test box has one), so the process
+group is gloo (RCCL refuses two ranks on one device); everything else is the production path:
+HipShard, the aliasing tensors, the engine's own HIP stream, svinet_amd/sharded.py."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    path, n, k, sweeps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    import torch
+    import torch.distributed as dist
+    from svinet_amd.host_api import Setup
+    from svinet_amd.sharded import HipShard, ShardedSweep
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    setup = Setup(path, n, k)
+    shard = HipShard(setup, rank, world, 0, use_validation_stop=False)
+    run = ShardedSweep(shard, dist)
+    run.sweep(sweeps)
+    run.gather_communities()
+    shard.engine.synchronize()
+    torch.cuda.synchronize()
+    g, lam, conv = shard.engine.state()
+    c = shard.engine.control()
+    np.savez(out + ".%d.npz" % rank, gamma=g, lam=lam, conv=conv, member=shard.engine.communities(),
+             iter=c.iter, annealing=c.annealing, rows=shard.engine.rows())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,3 +108,32 @@ def test_sharded_driver_world1(graph_files):
         assert np.allclose(shard.rows[0][:1000, :28].cpu().numpy(), a[0], rtol=0, atol=0)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 40), (3, 64, 6)])
+def test_two_processes_one_gpu(graph_files, tmp_path, world, k, sweeps):
+    """svinet_amd/sharded.py end to end in separate processes (one per rank, as on a multi-GPU node),
+    all on GPU 0 with a gloo group: the exchanged state equals the oracle's on every rank."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py")
+    out = str(tmp_path / "state")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29600 + world), worker,
+                        graph_files["lfr"], "1000", str(k), str(sweeps), out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    states = [np.load(out + ".%d.npz" % rk) for rk in range(world)]
+    for s in states:
+        assert np.max(np.abs(s["gamma"] - ref.gamma) / np.abs(ref.gamma)) < 1e-5
+        assert np.max(np.abs(s["lam"] - ref.lam) / np.abs(ref.lam)) < 1e-5
+        assert np.array_equal(s["conv"], ref.converged)
+        assert int(s["iter"]) == ref.iter and bool(s["annealing"]) == ref.annealing
+        np.testing.assert_allclose(s["rows"][:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+        assert np.array_equal(s["member"], ref.communities())
+    for s in states[1:]:
+        assert np.array_equal(s["gamma"], states[0]["gamma"]) and np.array_equal(s["lam"], states[0]["lam"])
