@@ -59,7 +59,7 @@ __device__ __forceinline__ void block_reduce_store(double (&part)[NV][V], double
 // row, V doubles per lane.  The chunk's column indices and converged flags are
 // fetched with one coalesced load each, and the next neighbour's Elogpi row is in
 // flight while the current one is reduced (two rows per wave in flight).
-template <int V>
+template <int V, bool LOWT>
 __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
   constexpr int W = 64;
   DevCtrl *ctrl = d.ctrl;
@@ -134,43 +134,91 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
       } else {
         bool sparse = false;
         if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
-        double x[V];
-        double m = NEG_INF;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          x[v] = (ap[v] + rcur[v]) + eb[v];   // the reference's order (:686); padding -> -inf
+        // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686);
+        // padding columns and, on the active-set path, columns outside the union -> -inf
+        auto xk = [&](int v) {
+          double t = (ap[v] + rcur[v]) + eb[v];
           if (sparse) {
             const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
-            x[v] = ((um >> lw) & 1ull) ? x[v] : NEG_INF;
+            t = ((um >> lw) & 1ull) ? t : NEG_INF;
           }
-          m = fmax(m, x[v]);
-        }
-        m = group_max<W>(m);
-        if (m != NEG_INF) {  // an empty active-set union contributes nothing (:642-664)
+          return t;
+        };
+        if constexpr (!LOWT) {
+          // Every x_k is <= 0 (Elogpi and Elogbeta are expectations of logs of probabilities), so the
+          // softmax needs no max shift to stay finite: exp(x_k) / sum_j exp(x_j) directly -- one
+          // cross-lane reduction instead of two.  Only when the whole row underflows (sum below
+          // 1e-280; also the empty active-set union) is it redone with the shift.
           double s = 0.0;
-          bool ismax[V];
+          double e[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            ismax[v] = (x[v] == m);
-            x[v] = exp_neg(x[v] - m);   // exp_neg(-inf) == 0
-            s += x[v];
+            e[v] = exp_neg(xk(v));   // exp_neg(-inf) == 0
+            s += e[v];
           }
           s = group_sum<W>(s);
-          const double inv = fast_rcp(s);
+          bool live = true;
+          if (s < 1e-280) {   // wave-uniform
+            double m = NEG_INF;
 #pragma unroll
-          for (int v = 0; v < V; ++v) acc[v] = fma(x[v], inv, acc[v]);
-          // community tagging, src/linksampling.cc:668-681,704-717: the first
-          // strict maximum of phi is the first k with x_k == max; its phi is 1/s.
-          if (write_comm && inv > prm.link_thresh) {
-            int best = 0x7fffffff;
+            for (int v = 0; v < V; ++v) m = fmax(m, xk(v));
+            m = group_max<W>(m);
+            live = (m != NEG_INF);   // an empty active-set union contributes nothing (:642-664)
+            s = 0.0;
+            if (live) {
 #pragma unroll
-            for (int v = 0; v < V; ++v)
-              if (ismax[v]) best = min(best, kidx[v]);
+              for (int v = 0; v < V; ++v) {
+                e[v] = exp_neg(xk(v) - m);
+                s += e[v];
+              }
+              s = group_sum<W>(s);
+            }
+          }
+          if (live) {
+            const double inv = fast_rcp(s);
 #pragma unroll
-            for (int o = 1; o < W; o <<= 1) best = min(best, __shfl_xor(best, o, 64));
+            for (int v = 0; v < V; ++v) acc[v] = fma(e[v], inv, acc[v]);
+            // community tagging, src/linksampling.cc:668-681,704-717: tag the first strict maximum
+            // of phi if it exceeds link_thresh.  With link_thresh >= 1/2 (this instantiation) a phi
+            // above the threshold IS the strict maximum and is unique, so no argmax is needed.
+            if (write_comm) {
+              const double ts = prm.link_thresh * s;
 #pragma unroll
-            for (int v = 0; v < V; ++v)
-              if (kidx[v] == best) cnt[v]++;
+              for (int v = 0; v < V; ++v) cnt[v] += (e[v] > ts) ? 1u : 0u;
+            }
+          }
+        } else {
+          double x[V];
+          double m = NEG_INF;
+#pragma unroll
+          for (int v = 0; v < V; ++v) { x[v] = xk(v); m = fmax(m, x[v]); }
+          m = group_max<W>(m);
+          if (m != NEG_INF) {  // an empty active-set union contributes nothing (:642-664)
+            double s = 0.0;
+            bool ismax[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              ismax[v] = (x[v] == m);
+              x[v] = exp_neg(x[v] - m);   // exp_neg(-inf) == 0
+              s += x[v];
+            }
+            s = group_sum<W>(s);
+            const double inv = fast_rcp(s);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fma(x[v], inv, acc[v]);
+            // link_thresh < 1/2: several phi may exceed it; the first strict maximum of phi is the
+            // first k with x_k == max, and its phi is 1/s
+            if (write_comm && inv > prm.link_thresh) {
+              int best = 0x7fffffff;
+#pragma unroll
+              for (int v = 0; v < V; ++v)
+                if (ismax[v]) best = min(best, kidx[v]);
+#pragma unroll
+              for (int o = 1; o < W; o <<= 1) best = min(best, __shfl_xor(best, o, 64));
+#pragma unroll
+              for (int v = 0; v < V; ++v)
+                if (kidx[v] == best) cnt[v]++;
+            }
           }
         }
         if (count_me && lane == 0) { if (sparse) n_sparse++; else n_dense++; }
@@ -827,14 +875,21 @@ bool pick_layout(uint32_t K, int *W, int *V) {
 
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   if (d.lpl) { launch_phi_lpl(g, d, p, s); return; }
+  // link_thresh < 1/2 needs the argmax form of the tagging rule (k_phi<V, true>)
+#define PHI(V_)                                                                                    \
+  do {                                                                                             \
+    if (p.link_thresh < 0.5) hipLaunchKernelGGL((k_phi<V_, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); \
+    else hipLaunchKernelGGL((k_phi<V_, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);          \
+  } while (0)
   switch (g.V) {   // K > 32 => W == 64
-    case 1: hipLaunchKernelGGL((k_phi<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
-    case 2: hipLaunchKernelGGL((k_phi<2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
-    case 4: hipLaunchKernelGGL((k_phi<4>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
-    case 8: hipLaunchKernelGGL((k_phi<8>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
-    case 16: hipLaunchKernelGGL((k_phi<16>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
-    default: hipLaunchKernelGGL((k_phi<32>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break;
+    case 1: PHI(1); break;
+    case 2: PHI(2); break;
+    case 4: PHI(4); break;
+    case 8: PHI(8); break;
+    case 16: PHI(16); break;
+    default: PHI(32); break;
   }
+#undef PHI
 }
 // Blocks of the row-per-wavefront phi / s3 kernels resident on the device at once.  Grids are
 // made a whole multiple of this: with variable-length items more blocks balance better, but a
@@ -845,12 +900,12 @@ uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
 #define OCC(KERNEL) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0)
   if (which == 0) {
     switch (g.V) {
-      case 1: OCC(k_phi<1>); break;
-      case 2: OCC(k_phi<2>); break;
-      case 4: OCC(k_phi<4>); break;
-      case 8: OCC(k_phi<8>); break;
-      case 16: OCC(k_phi<16>); break;
-      default: OCC(k_phi<32>); break;
+      case 1: OCC((k_phi<1, false>)); break;
+      case 2: OCC((k_phi<2, false>)); break;
+      case 4: OCC((k_phi<4, false>)); break;
+      case 8: OCC((k_phi<8, false>)); break;
+      case 16: OCC((k_phi<16, false>)); break;
+      default: OCC((k_phi<32, false>)); break;
     }
   } else if (which == 2) {
 #define CALL(W_, V_) OCC((k_finalize<W_, V_, false>))
