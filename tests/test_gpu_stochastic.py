@@ -95,3 +95,23 @@ def test_minibatch_run_on_planted_graph():
     # tagging runs on every step, so every window has published memberships
     member = eng.communities()
     assert member.any(axis=1).mean() > 0.5
+
+
+def test_stochastic_api_errors(graph_files):
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    s = Setup(graph_files["assort"], 75, 4)
+    e = s.engine()
+    with pytest.raises(_svils.SvilsError):
+        e.step(1)                                   # not in mini-batch mode
+    with pytest.raises(_svils.SvilsError):
+        e.set_stochastic(batch_nodes=10, tau0=0.5, kappa=0.5)      # tau0 < 1
+    with pytest.raises(_svils.SvilsError):
+        e.set_stochastic(batch_nodes=10, tau0=1.0, kappa=1.5)      # kappa > 1
+    e.set_stochastic(batch_nodes=10, tau0=1.0, kappa=0.5)
+    e.step(8)                                       # 75 nodes / 10 = 8 windows, the last one short
+    g, lam, _ = e.state()
+    assert np.isfinite(g).all() and np.isfinite(lam).all()
+    shard = s.engine(node_block=(0, 40), n_alloc=80)
+    with pytest.raises(_svils.SvilsError):
+        shard.set_stochastic(batch_nodes=10)        # node-block shards have no mini-batch mode
