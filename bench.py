@@ -229,7 +229,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": data,
-            "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run, dense path"
+            "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
                        "parallelism": ("node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world) if shard
                                       else ("replicated on %d GPUs (problem too small to shard: K*L/N = %.1e)" % (world, work_per_gpu)
@@ -248,6 +248,10 @@ def main():
         }
         g, lam, conv = eng.state()
         out["config"]["converged_nodes_at_end"] = int((conv > 0).sum())
+        # how the last sweep's links were evaluated (src/linksampling.cc:622-719): full softmax, active-set
+        # (sparse) path (_iter > 1000 only), O(1) shortcut of links with exactly one converged endpoint
+        out["config"]["links_last_sweep"] = {"dense": int(ctrl.links_dense), "sparse": int(ctrl.links_sparse),
+                                             "shortcut": int(ctrl.links_shortcut)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
