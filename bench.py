@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_phi with hipEvents in the timed region (lets svils_sweep replay hipGraphs; "
                          "roofline then comes from a separate short eager pass)")
+    ap.add_argument("--replicate", action="store_true",
+                    help="N>1, problem too small to shard: run the SAME chain on every rank (value = one chain, "
+                         "'strong') instead of independent restarts (value = all chains, 'weak')")
     ap.add_argument("--no-sharded-extra", action="store_true",
                     help="N>1, replicated main run: skip the extra timing of the node-block sharded path")
     ap.add_argument("--extra-timeout", type=int, default=150,
@@ -160,6 +163,7 @@ def main():
         path = _fixture(fixture)
         setup = Setup(path, n, k)
         data = "reference example graph %s (fixture copy), seeded init (MT19937 4357)" % fixture
+    setup0 = setup          # the seed-0 problem (also what the optional sharded-path timing uses)
     L = int(setup.nlinks)
     V = int(setup.validation_sorted.shape[0])
 
@@ -169,6 +173,15 @@ def main():
     shard = world > 1 and (args.shard == "always" or (args.shard == "auto" and work_per_gpu >= 5e7))
     if args.force_sharded:
         shard = True
+    # N > 1 and too small to shard: every rank runs its own chain -- an independent restart with -seed <rank>
+    # (different held-out sample and initialisation), the way a multi-GPU node is used on a small graph.
+    # `value` is then the aggregate over the N chains ("weak"); the strong-scaling number of ONE chain over
+    # the N GPUs is timed separately below (`sharded_path`).
+    restarts = world > 1 and not shard and not args.replicate
+    if restarts and rank > 0:
+        setup = Setup(path, n, k, seed=rank) if path else Setup(n=n, k=k, pairs=pairs, seed=rank)
+        L = int(setup.nlinks)
+        V = int(setup.validation_sorted.shape[0])
     if not shard:
         eng = setup.engine(use_validation_stop=False, device=local_rank)
         runner = eng
@@ -197,10 +210,15 @@ def main():
     sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    links_all_chains = float(L)
     if dist is not None and world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        if restarts:
+            ll = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ll, op=dist.ReduceOp.SUM)
+            links_all_chains = float(ll.item())
     if args.no_kernel_events:        # separate eager pass for the phi timing
         eng.enable_timing(1 << _svils.KERNEL_PHI)
         runner.sweep(min(args.steps, 20))
@@ -218,22 +236,24 @@ def main():
         achieved = alg_bytes / phi_avg_s / 1e9 if phi_avg_s > 0 else 0.0
         out = {
             "metric": "edge-updates/sec (link-sampling SVI step)",
-            "value": L * args.steps / elapsed,
+            "value": (links_all_chains if restarts else L) * args.steps / elapsed,
             "unit": "edge-updates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if restarts else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": data,
             "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
                        "parallelism": ("node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world) if shard
-                                      else ("replicated on %d GPUs (problem too small to shard: K*L/N = %.1e)" % (world, work_per_gpu)
-                                            if world > 1 else "single GPU"),
+                                      else (("%d independent chains, one per GPU (restarts with -seed 0..%d; no exchange): the "
+                                             "problem is too small to shard (K*L/N = %.1e), see sharded_path for one chain over "
+                                             "%d GPUs" % (world, world - 1, work_per_gpu, world)) if restarts
+                                            else ("the same chain replicated on %d GPUs" % world) if world > 1 else "single GPU"),
                        "converged_nodes_at_end": None},
             "roofline": {"bound": "hbm", "kernel": "k_phi", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -246,6 +266,9 @@ def main():
                          "note": "working set is cache-resident below ~256 MB of state (Infinity Cache): "
                                  "achieved is algorithmic bytes / kernel time, not HBM traffic"},
         }
+        if restarts:
+            out["single_chain"] = {"value": L * args.steps / elapsed, "unit": "edge-updates/s",
+                                   "note": "rank 0's chain alone (the N=1 workload); `value` sums the %d chains" % world}
         g, lam, conv = eng.state()
         out["config"]["converged_nodes_at_end"] = int((conv > 0).sum())
         # how the last sweep's links were evaluated (src/linksampling.cc:622-719): full softmax, active-set
@@ -307,7 +330,7 @@ def main():
         sh = {}
         try:
             from svinet_amd.sharded import HipShard, ShardedSweep
-            shard2 = HipShard(setup, rank, world, local_rank, use_validation_stop=False)
+            shard2 = HipShard(setup0, rank, world, local_rank, use_validation_stop=False)
             run2 = ShardedSweep(shard2, dist)
             nst = min(args.steps, 50)
             run2.sweep(args.warmup)
@@ -317,7 +340,7 @@ def main():
             shard2.engine.synchronize(); torch.cuda.synchronize()
             el2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
             dist.all_reduce(el2, op=dist.ReduceOp.MAX)
-            sh = {"value": L * nst / float(el2.item()), "unit": "edge-updates/s", "steps": nst,
+            sh = {"value": int(setup0.nlinks) * nst / float(el2.item()), "unit": "edge-updates/s", "steps": nst,
                   "ms_per_step": float(el2.item()) / nst * 1e3,
                   "parallelism": "node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world}
         except Exception as exc:  # the main measurement must survive a failure here
