@@ -255,9 +255,6 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
   block_store_link_counts(n_dense, n_sparse, n_short, d.part_links, lcnt, 4);
 }
 
-#ifndef SVILS_FIN_WAVES
-#define SVILS_FIN_WAVES(V) 1
-#endif
 // ===================================================== column reduce of partials
 // out[c] = sum_b part[b][c] in a fixed order: 4 columns x 64 row-segments per block.
 // Up to two jobs per launch (blockIdx.x < nblk0 -> job 0).
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
 // (:751-755), set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491),
 // one group per owned node.
 template <int W, int V, bool STOCH>
-__global__ __launch_bounds__(256, SVILS_FIN_WAVES(V)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
