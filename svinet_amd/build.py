@@ -18,7 +18,7 @@ BINDIR = os.path.join(HERE, "bin")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 CXX = os.environ.get("CXX", "g++")
-CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
+CXX_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread"]
 
 
 def _stale(target, sources):

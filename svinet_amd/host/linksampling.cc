@@ -1,6 +1,7 @@
 #include "linksampling.hh"
 
 #include <random>
+#include <thread>
 
 #include <algorithm>
 #include <cerrno>
@@ -247,19 +248,71 @@ std::string LinkSampling::edgelist_s(const std::vector<uint32_t> &t) const {  //
 }
 
 // ------------------------------------------------------------------ initialisation
-void LinkSampling::init_gamma2() {                        // src/linksampling.cc:374-401
-  std::vector<double> phi(k_);
+// init_gamma2 (src/linksampling.cc:374-401): for every link (held-out ones included), in the order
+// "for p, for q in adj[p] with p < q", draw K uniforms, normalise them to sum 1 and add the vector
+// to gamma[p] and gamma[q].  The uniforms come from ONE sequential stream, so they are drawn by this
+// thread, chunk by chunk; normalising a chunk and adding it into gamma is done by worker threads
+// while the next chunk is being drawn.  Every node's row is owned by one worker and receives its
+// links' vectors in link order, so the result is bit-identical to the sequential loop.
+void LinkSampling::init_gamma2() {
+  std::vector<uint32_t> lp, lq;
+  lp.reserve(network_.ones());
+  lq.reserve(network_.ones());
   for (uint32_t p = 0; p < n_; ++p)
-    for (uint32_t q : network_.get_edges(p)) {
-      if (p >= q) continue;   // all links, held-out ones included
-      double s = .0;
-      for (uint32_t k = 0; k < k_; ++k) { phi[k] = rng_.uniform(); }
-      for (uint32_t k = 0; k < k_; ++k) s += phi[k];
-      double *gp = &gamma_[(size_t)p * k_], *gq = &gamma_[(size_t)q * k_];
-      for (uint32_t k = 0; k < k_; ++k) phi[k] = phi[k] / s;
-      for (uint32_t k = 0; k < k_; ++k) gp[k] += phi[k];
-      for (uint32_t k = 0; k < k_; ++k) gq[k] += phi[k];
+    for (uint32_t q : network_.get_edges(p))
+      if (p < q) { lp.push_back(p); lq.push_back(q); }   // all links, held-out ones included
+  const size_t E = lp.size(), K = k_;
+  unsigned T = std::thread::hardware_concurrency();
+  T = std::max(1u, std::min(T, 32u));
+  if (E * K < (1u << 22)) T = 1;   // small problems: threads cost more than they save
+  const size_t C = std::max<size_t>(256, ((size_t)32 << 20) / (K * sizeof(double)));   // links per chunk
+  std::vector<double> buf[2];
+  buf[0].resize(std::min(C, std::max<size_t>(E, 1)) * K);
+  if (T > 1) buf[1].resize(buf[0].size());
+
+  // normalise rows [b, e) of a chunk in place: sequential sum over k, then the division (:392-396)
+  auto normalise = [&](double *v, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      double *u = v + i * K, s = .0;
+      for (size_t k = 0; k < K; ++k) s += u[k];
+      for (size_t k = 0; k < K; ++k) u[k] = u[k] / s;
     }
+  };
+  // add the chunk's vectors into the rows of the nodes in [nb, ne), in link order
+  auto accumulate = [&](const double *v, size_t l0, size_t cnt, uint32_t nb, uint32_t ne) {
+    for (size_t i = 0; i < cnt; ++i) {
+      const uint32_t p = lp[l0 + i], q = lq[l0 + i];
+      const double *u = v + i * K;
+      if (p >= nb && p < ne) { double *g = &gamma_[(size_t)p * K]; for (size_t k = 0; k < K; ++k) g[k] += u[k]; }
+      if (q >= nb && q < ne) { double *g = &gamma_[(size_t)q * K]; for (size_t k = 0; k < K; ++k) g[k] += u[k]; }
+    }
+  };
+  auto process = [&](double *v, size_t l0, size_t cnt) {
+    if (T == 1) { normalise(v, 0, cnt); accumulate(v, l0, cnt, 0, n_); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back(normalise, v, cnt * t / T, cnt * (t + 1) / T);
+    for (auto &x : th) x.join();
+    th.clear();
+    for (unsigned t = 0; t < T; ++t)
+      th.emplace_back(accumulate, v, l0, cnt, (uint32_t)((uint64_t)n_ * t / T), (uint32_t)((uint64_t)n_ * (t + 1) / T));
+    for (auto &x : th) x.join();
+  };
+
+  std::thread pending;
+  int cur = 0;
+  for (size_t l0 = 0; l0 < E; l0 += C) {
+    const size_t cnt = std::min(C, E - l0);
+    double *v = buf[cur].data();
+    rng_.fill_uniform(v, cnt * K);
+    if (pending.joinable()) pending.join();
+    if (T == 1) {
+      process(v, l0, cnt);
+    } else {
+      pending = std::thread(process, v, l0, cnt);
+      cur ^= 1;
+    }
+  }
+  if (pending.joinable()) pending.join();
 }
 
 int LinkSampling::init_lambda() {                         // src/linksampling.cc:364-372

@@ -92,6 +92,8 @@ int Network::read(const std::string &path) {
 }
 
 void Network::read_pairs(const int32_t *pairs, uint64_t nlines) {
+  pair_set_.reserve(nlines);
+  edges_.reserve(nlines);
   for (uint64_t i = 0; i < nlines; ++i) add_line((uint32_t)pairs[2 * i], (uint32_t)pairs[2 * i + 1]);
   set_env_variables();
 }
