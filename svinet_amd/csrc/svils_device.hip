@@ -99,8 +99,12 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
       myconv = conv[mycol];
     }
     const uint32_t pc = conv[p];
+    // Elogpi[p][k] + Elogbeta[k][0], once per item; x_k = this + Elogpi[q][k] (the reference adds the
+    // two Elogpi terms first, :686 -- a different rounding of the same sum, one add per column saved)
     double ap[V];
     load_row<W, V>(elogpi + (size_t)p * ld, lw, ld, ap);
+#pragma unroll
+    for (int v = 0; v < V; ++v) ap[v] += eb[v];   // padding columns -> -inf
     double acc[V];
     uint32_t cnt[V];
 #pragma unroll
@@ -134,10 +138,10 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
       } else {
         bool sparse = false;
         if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
-        // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686);
-        // padding columns and, on the active-set path, columns outside the union -> -inf
+        // x_k = Elogpi[p][k] + Elogpi[q][k] + Elogbeta[k][0]; padding columns and, on the active-set
+        // path, columns outside the union -> -inf
         auto xk = [&](int v) {
-          double t = (ap[v] + rcur[v]) + eb[v];
+          double t = ap[v] + rcur[v];
           if (sparse) {
             const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
             t = ((um >> lw) & 1ull) ? t : NEG_INF;
