@@ -142,3 +142,36 @@ def test_empty_and_tiny_graphs():
         e2.sweep(3)
         g, lam, conv = e2.state()
         assert np.allclose(g, ref.gamma, rtol=1e-10) and np.allclose(lam, ref.lam, rtol=1e-10)
+
+
+@pytest.mark.parametrize("k", [20, 64, 200])
+def test_softmax_rows_that_underflow(k):
+    """Links whose endpoints have (almost) disjoint supports: every exp(x_k) underflows without a
+    shift (x_k < -745 for all k).  The row-per-wavefront kernel computes its softmax without the max
+    shift and must fall back to the shifted form for such rows; the lane-per-link kernel always shifts.
+    Both must agree with the oracle's sequential log-sum-exp."""
+    from svinet_amd.host_api import Setup
+    n = 2 * k + 20          # every community keeps some mass (an empty one makes E/sum[k] infinite in the reference too)
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    chords = np.stack([np.arange(n), (np.arange(n) + 7) % n], 1)
+    pairs = np.concatenate([ring, chords]).astype(np.int32)
+    s = Setup(n=n, k=k, pairs=pairs, heldout_ratio=0.0)
+    ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, heldout_ratio=0.0, use_validation_stop=False)
+    ref.set_skip_validation(True)
+    # node i is concentrated on community i % k; everything else is tiny, so that psi(tiny) ~ -1/tiny = -2000
+    g = np.full((n, k), 5e-4)
+    g[np.arange(n), np.arange(n) % k] = 50.0
+    lam = np.tile([3.0, 2.0], (k, 1))
+    ref.set_gamma(g); ref.set_lambda(lam); ref.refresh()
+    x = ref.elogpi[0] + ref.elogpi[1] + ref.elogbeta[:, 0]
+    assert x.max() < -745, "the test must exercise the underflow path"
+    eng = s.engine(use_validation_stop=False)
+    eng.set_state(g, lam)
+    for nsw in (1, 2):
+        ref.sweep()
+        eng.sweep(1)
+        gg, ll, conv = eng.state()
+        assert np.isfinite(gg).all() and np.isfinite(ll).all()
+        np.testing.assert_allclose(gg, ref.gamma, rtol=1e-7)
+        np.testing.assert_allclose(ll, ref.lam, rtol=1e-7)
+        assert np.array_equal(conv, ref.converged)
