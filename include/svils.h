@@ -128,6 +128,9 @@ int svils_validation_row(svils_handle *h, double *row10);
 int svils_sweep(svils_handle *h, uint32_t nsweeps);
 int svils_synchronize(svils_handle *h);
 
+/* phases of a sweep / mini-batch step between exchange points (see "multi-GPU hooks" below) */
+typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D, SVILS_PHASE_EXPAND } svils_phase;
+
 /* ---- mini-batch mode (an ADDITION of this build; SURVEY 8f N4, BASELINE north_star) ----
  * The reference revision's -link-sampling loop is a deterministic full sweep with step size 1
  * (src/linksampling.cc:556-790); its stochastic engines (MMSBInfer::infer,
@@ -147,13 +150,25 @@ typedef struct {
   double node_tau0, node_kappa;
   double tau0, kappa;
   uint64_t seed;          /* offset of the first window in the cyclic order */
+  /* node-block shards (svils_config node_begin/node_end): nodes per rank block (= n_alloc / world);
+   * 0 on a single handle.  Every rank then takes the window at the SAME offset inside its own block,
+   * so a global mini-batch is world x batch_nodes nodes; drive it with svils_step_phase(). */
+  uint32_t shard_block;
 } svils_stochastic;
 void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes);
-/* Call after svils_create (single-GPU handles only); allocates the extra accumulator. */
+/* Call after svils_create; allocates the extra accumulator. */
 int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg);
 /* Enqueue `nsteps` mini-batch steps; asynchronous; every step advances _iter, writes a
  * likelihood row when _iter % reportfreq == 0 and runs the stop rule, exactly as a sweep does. */
 int svils_step(svils_handle *h, uint32_t nsteps);
+/* One mini-batch step split at its exchange points, for node-block shards (one process per GPU):
+ * A -> all-reduce SVILS_BUF_KVEC_A -> B -> all-gather, for every rank's window, the rows of
+ * SVILS_BUF_GAMMA and SVILS_BUF_MPHI and the flag buffers -> EXPAND (Elogpi of the other ranks' window
+ * rows from the gathered gamma) -> C -> all-reduce SVILS_BUF_KVEC_C -> D.  Phase A opens the step,
+ * phase D closes it.  svils_step_window gives the window of the open (or next) step relative to a
+ * rank's block: rows [r*shard_block + begin, r*shard_block + end) for every rank r. */
+int svils_step_phase(svils_handle *h, svils_phase phase);
+int svils_step_window(svils_handle *h, uint32_t *begin, uint32_t *end);
 
 /* rows recorded by the in-loop validation_likelihood(): copies rows
  * [first, first+count) (as numbered since create) into out[count][10]. */
@@ -202,7 +217,6 @@ const char *svils_kernel_name(int kernel);
  * all-reduces the second K-vector buffer, and phase D (replicated) closes the
  * sweep.  svils_sweep() == A,B,C,D with no exchange (EXPAND is a no-op when the
  * handle owns every row). */
-typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D, SVILS_PHASE_EXPAND } svils_phase;
 int svils_sweep_phase(svils_handle *h, svils_phase phase);
 
 typedef enum {

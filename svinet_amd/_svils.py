@@ -23,7 +23,7 @@ EXPORTS = (
     "svils_get_state", "svils_get_communities", "svils_get_aux", "svils_enable_timing",
     "svils_get_timing", "svils_kernel_name", "svils_sweep_phase", "svils_device_buffer",
     "svils_stream", "svils_last_error", "svils_abi_version", "svils_debug_eval",
-    "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default",
+    "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default", "svils_step_phase", "svils_step_window",
 )
 
 
@@ -35,7 +35,7 @@ class SvilsError(RuntimeError):
 
 class Stochastic(C.Structure):
     _fields_ = [("batch_nodes", C.c_uint32), ("node_tau0", C.c_double), ("node_kappa", C.c_double),
-                ("tau0", C.c_double), ("kappa", C.c_double), ("seed", C.c_uint64)]
+                ("tau0", C.c_double), ("kappa", C.c_double), ("seed", C.c_uint64), ("shard_block", C.c_uint32)]
 
 
 class Config(C.Structure):
@@ -90,6 +90,8 @@ def load():
     L.svils_sweep.argtypes = [vp, C.c_uint32]
     L.svils_set_stochastic.argtypes = [vp, C.POINTER(Stochastic)]
     L.svils_step.argtypes = [vp, C.c_uint32]
+    L.svils_step_phase.argtypes = [vp, C.c_int]
+    L.svils_step_window.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.svils_stochastic_default.argtypes = [C.POINTER(Stochastic), C.c_uint32]
     L.svils_stochastic_default.restype = None
     L.svils_synchronize.argtypes = [vp]
@@ -194,15 +196,25 @@ class Engine:
     def sweep(self, nsweeps=1):
         _chk(load().svils_sweep(self._h, nsweeps))
 
-    def set_stochastic(self, batch_nodes=0, tau0=1024.0, kappa=0.9, node_tau0=None, node_kappa=None, seed=0):
+    def set_stochastic(self, batch_nodes=0, tau0=1024.0, kappa=0.9, node_tau0=None, node_kappa=None, seed=0,
+                       shard_block=0):
         """mini-batch mode (include/svils.h): windows of `batch_nodes` consecutive nodes per step;
-        node step sizes default to the lambda ones when not given"""
+        node step sizes default to the lambda ones when not given; shard_block = nodes per rank block on
+        a node-block shard (then drive the steps with step_phase)"""
         cfg = Stochastic(batch_nodes, tau0 if node_tau0 is None else node_tau0,
-                         kappa if node_kappa is None else node_kappa, tau0, kappa, seed)
+                         kappa if node_kappa is None else node_kappa, tau0, kappa, seed, shard_block)
         _chk(load().svils_set_stochastic(self._h, C.byref(cfg)))
 
     def step(self, nsteps=1):
         _chk(load().svils_step(self._h, nsteps))
+
+    def step_phase(self, phase):
+        _chk(load().svils_step_phase(self._h, phase))
+
+    def step_window(self):
+        b, e = C.c_uint32(), C.c_uint32()
+        _chk(load().svils_step_window(self._h, C.byref(b), C.byref(e)))
+        return b.value, e.value
 
     def sweep_phase(self, phase):
         _chk(load().svils_sweep_phase(self._h, phase))

@@ -74,6 +74,12 @@ struct svils_handle {
   std::vector<uint64_t> h_linkptr;      // [n+1] first training link whose first endpoint is >= node
   std::vector<uint32_t> h_item_phi;     // [n+1] first phi item of a node (row-per-wavefront layout)
   std::vector<uint32_t> h_item_s3;      // [n+1] first s3 item of a node
+  // the open mini-batch step (between svils_step_phase(A) and (D)): per-launch copies with the window set
+  bool step_open = false;
+  Geometry sg;
+  DeviceState sd;
+  Params sp;
+  uint32_t sw_begin = 0, sw_end = 0;    // window relative to a rank's block
 };
 
 namespace {
@@ -653,8 +659,15 @@ int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
   if (!(cfg->tau0 >= 1.0) || !(cfg->kappa >= 0.0) || cfg->kappa > 1.0 || !(cfg->node_tau0 >= 1.0) ||
       !(cfg->node_kappa >= 0.0) || cfg->node_kappa > 1.0)
     return fail(SVILS_ERR_ARG, "svils_set_stochastic: need tau0 >= 1 and 0 <= kappa <= 1");
-  if (h->geo.node_begin != 0 || h->geo.node_end != h->geo.n)
-    return fail(SVILS_ERR_UNSUPPORTED, "svils_set_stochastic: not available on a node-block shard");
+  const Geometry &g0 = h->geo;
+  const bool whole = g0.node_begin == 0 && g0.node_end == g0.n;
+  if (cfg->shard_block == 0) {
+    if (!whole) return fail(SVILS_ERR_ARG, "svils_set_stochastic: a node-block shard needs shard_block");
+  } else {
+    if (g0.node_begin % cfg->shard_block != 0 || g0.node_end > g0.node_begin + cfg->shard_block ||
+        g0.n_alloc % cfg->shard_block != 0)
+      return fail(SVILS_ERR_ARG, "svils_set_stochastic: shard_block does not match the handle's node block");
+  }
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
   DeviceState &d = h->d;
@@ -673,59 +686,126 @@ int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
   return 0;
 }
 
+namespace {
+
+// window of step `t` relative to a rank's block, and the per-launch state of this handle for it
+void step_window(const svils_handle *h, uint64_t t, uint32_t *b, uint32_t *e) {
+  const uint32_t B = h->scfg.shard_block ? h->scfg.shard_block : h->geo.n;
+  const uint32_t bn = (h->scfg.batch_nodes == 0 || h->scfg.batch_nodes > B) ? B : h->scfg.batch_nodes;
+  const uint32_t nblocks = (B + bn - 1) / bn;
+  const uint32_t blk = (uint32_t)((t + h->scfg.seed) % nblocks);   // fixed cyclic order
+  *b = blk * bn;
+  *e = std::min(B, *b + bn);
+}
+
+int open_step(svils_handle *h) {
+  const uint32_t n = h->geo.n;
+  const uint32_t B = h->scfg.shard_block ? h->scfg.shard_block : n;
+  const uint32_t world = h->scfg.shard_block ? h->geo.n_alloc / B : 1;
+  uint32_t wb, we;
+  step_window(h, h->steps_done, &wb, &we);
+  h->sw_begin = wb;
+  h->sw_end = we;
+  Geometry &g = h->sg;
+  DeviceState &d = h->sd;
+  Params &p = h->sp;
+  g = h->geo;
+  d = h->d;
+  p = h->prm;
+  // this handle's rows of the mini-batch
+  const uint32_t b = std::min(n, h->geo.node_begin + wb), e = std::min(n, h->geo.node_begin + we);
+  g.node_begin = b;
+  g.node_end = e;
+  d.ent_begin = h->h_rowptr[b];
+  d.ent_end = h->h_rowptr[e];
+  d.lpl_w0 = d.ent_begin >> 6;
+  d.lpl_nitems = d.ent_end > d.ent_begin ? (uint32_t)(((d.ent_end + 63) >> 6) - d.lpl_w0) : 0;
+  d.link_begin = h->h_linkptr[b];
+  d.link_end = h->h_linkptr[e];
+  d.item0_phi = h->h_item_phi[b];
+  d.nitems_phi = h->h_item_phi[e] - h->h_item_phi[b];
+  d.item0_s3 = h->h_item_s3[b];
+  d.nitems_s3 = h->h_item_s3[e] - h->h_item_s3[b];
+  // grids sized for the window (never larger than the allocation made for full sweeps)
+  {
+    auto fit = [](uint64_t want, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, lim)); };
+    const int G = 64 / g.W;
+    d.nb_b = fit(((uint64_t)(e - b) + 4 * G - 1) / (4 * G), h->d.nb_b);
+    if (d.lpl) {
+      const int nw = lpl_phi_waves(g.K);
+      d.nb_a = fit((d.lpl_nitems + nw - 1) / nw, h->d.nb_a);
+      d.nb_c = fit((d.link_end - d.link_begin + 255) / 256, h->d.nb_c);
+    } else {
+      d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);
+      d.nb_c = fit(((uint64_t)d.nitems_s3 + 3) / 4, h->d.nb_c);
+    }
+  }
+  p.stoch = 1;
+  p.tau0 = h->scfg.node_tau0;
+  p.kappa = h->scfg.node_kappa;
+  p.rho_lambda = std::pow(h->scfg.tau0 + (double)h->steps_done, -h->scfg.kappa);
+  // window sums -> estimates of the full sums: the mini-batch is the union of every rank's window
+  uint64_t ents = 0, ups = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    const uint32_t rb = std::min(n, r * B + wb), re = std::min(n, std::min((r + 1) * B, r * B + we));
+    ents += h->h_rowptr[re] - h->h_rowptr[rb];
+    ups += h->h_linkptr[re] - h->h_linkptr[rb];
+  }
+  p.scale_a = ents ? (double)(2 * h->d.nlinks) / (double)ents : 0.0;
+  p.scale_c = ups ? (double)h->d.nlinks / (double)ups : 0.0;
+  h->step_open = true;
+  return 0;
+}
+
+}  // namespace
+
+int svils_step_window(svils_handle *h, uint32_t *begin, uint32_t *end) {
+  if (!h || !begin || !end) return fail(SVILS_ERR_ARG, "svils_step_window: null argument");
+  if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_window: call svils_set_stochastic first");
+  if (h->step_open) { *begin = h->sw_begin; *end = h->sw_end; }
+  else step_window(h, h->steps_done, begin, end);
+  return 0;
+}
+
+int svils_step_phase(svils_handle *h, svils_phase phase) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_step_phase: null handle");
+  if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_phase: call svils_set_stochastic first");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_step_phase: set graph and state first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (phase == SVILS_PHASE_A) {
+    if (h->step_open) return fail(SVILS_ERR_ARG, "svils_step_phase: the previous step was not closed with phase D");
+    int rc = open_step(h);
+    if (rc) return rc;
+  } else if (!h->step_open) {
+    return fail(SVILS_ERR_ARG, "svils_step_phase: phase A opens a step");
+  }
+  int rc;
+  if (phase == SVILS_PHASE_EXPAND) {
+    if (h->scfg.shard_block) {
+      launch_expand_window(h->sg, h->sd, h->sp, h->sw_begin, h->sw_end, h->scfg.shard_block,
+                           h->geo.node_begin / h->scfg.shard_block, h->geo.n_alloc / h->scfg.shard_block, h->stream);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
+  if ((rc = run_phase(h, phase, h->sg, h->sd, h->sp))) return rc;
+  if (phase == SVILS_PHASE_D) {
+    h->step_open = false;
+    ++h->steps_done;
+  }
+  return 0;
+}
+
 int svils_step(svils_handle *h, uint32_t nsteps) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_step: null handle");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step: call svils_set_stochastic first");
-  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_step: set graph and state first");
-  HIPCHK(hipSetDevice(h->cfg.device));
-  const uint32_t n = h->geo.n;
-  const uint32_t bn = (h->scfg.batch_nodes == 0 || h->scfg.batch_nodes > n) ? n : h->scfg.batch_nodes;
-  const uint32_t nblocks = (n + bn - 1) / bn;
-  for (uint32_t s = 0; s < nsteps; ++s, ++h->steps_done) {
-    // windows in a fixed cyclic order; callers randomise the node order
-    const uint32_t blk = (uint32_t)((h->steps_done + h->scfg.seed) % nblocks);
-    const uint32_t b = blk * bn, e = std::min(n, b + bn);
-    Geometry g = h->geo;
-    DeviceState d = h->d;
-    Params p = h->prm;
-    g.node_begin = b;
-    g.node_end = e;
-    d.ent_begin = h->h_rowptr[b];
-    d.ent_end = h->h_rowptr[e];
-    d.lpl_w0 = d.ent_begin >> 6;
-    d.lpl_nitems = d.ent_end > d.ent_begin ? (uint32_t)(((d.ent_end + 63) >> 6) - d.lpl_w0) : 0;
-    d.link_begin = h->h_linkptr[b];
-    d.link_end = h->h_linkptr[e];
-    d.item0_phi = h->h_item_phi[b];
-    d.nitems_phi = h->h_item_phi[e] - h->h_item_phi[b];
-    d.item0_s3 = h->h_item_s3[b];
-    d.nitems_s3 = h->h_item_s3[e] - h->h_item_s3[b];
-    // grids sized for the window (never larger than the allocation made for full sweeps)
-    {
-      auto fit = [](uint64_t want, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, lim)); };
-      const int G = 64 / g.W;
-      d.nb_b = fit(((uint64_t)(e - b) + 4 * G - 1) / (4 * G), h->d.nb_b);
-      if (d.lpl) {
-        const int nw = lpl_phi_waves(g.K);
-        d.nb_a = fit((d.lpl_nitems + nw - 1) / nw, h->d.nb_a);
-        d.nb_c = fit((d.link_end - d.link_begin + 255) / 256, h->d.nb_c);
-      } else {
-        d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);
-        d.nb_c = fit(((uint64_t)d.nitems_s3 + 3) / 4, h->d.nb_c);
-      }
-    }
-    p.stoch = 1;
-    p.tau0 = h->scfg.node_tau0;
-    p.kappa = h->scfg.node_kappa;
-    p.rho_lambda = std::pow(h->scfg.tau0 + (double)h->steps_done, -h->scfg.kappa);
-    const uint64_t ents = d.ent_end - d.ent_begin, ups = d.link_end - d.link_begin;
-    p.scale_a = ents ? (double)(2 * h->d.nlinks) / (double)ents : 0.0;
-    p.scale_c = ups ? (double)h->d.nlinks / (double)ups : 0.0;
+  if (h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step: a node-block shard is driven with svils_step_phase");
+  for (uint32_t s = 0; s < nsteps; ++s) {
     int rc;
-    if ((rc = run_phase(h, SVILS_PHASE_A, g, d, p))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_B, g, d, p))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_C, g, d, p))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_D, g, d, p))) return rc;
+    if ((rc = svils_step_phase(h, SVILS_PHASE_A))) return rc;
+    if ((rc = svils_step_phase(h, SVILS_PHASE_B))) return rc;
+    if ((rc = svils_step_phase(h, SVILS_PHASE_C))) return rc;
+    if ((rc = svils_step_phase(h, SVILS_PHASE_D))) return rc;
   }
   return 0;
 }

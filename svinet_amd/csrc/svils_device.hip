@@ -680,6 +680,40 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
   }
 }
 
+// Sharded mini-batch step: Elogpi of the OTHER ranks' window rows, from the gamma rows just gathered
+// (their mphi rows are gathered as they are: a blended gamma no longer determines them).
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_expand_window(Geometry geo, DeviceState d, uint32_t wb, uint32_t we,
+                                                       uint32_t block, uint32_t my_rank, uint32_t world) {
+  const DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  constexpr int G = 64 / W;
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const uint32_t wlen = we - wb, total = wlen * (world - 1);
+  for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < total; i += gridDim.x * 4 * G) {
+    uint32_t r = i / wlen;
+    if (r >= my_rank) ++r;
+    const uint32_t p = r * block + wb + i % wlen;
+    if (p >= geo.n || p >= (r + 1) * block) continue;
+    double gn[V];
+    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    double rs = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { if ((uint32_t)kmap<W, V>(lw, v) >= K) gn[v] = 0.0; rs += gn[v]; }
+    rs = group_sum<W>(rs);
+    const double psi_rs = digamma(rs, logtab);
+    double el[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
+    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+  }
+}
+
 // Mini-batch step over a node window: prune() wrote conv[parity^1] for the window's rows only;
 // every other row carries its flag over so that the parity flip in k_tail keeps it.
 __global__ __launch_bounds__(256) void k_carry_flags(Geometry geo, DeviceState d) {
@@ -981,6 +1015,17 @@ void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s) 
   uint32_t nb = (g.n + 255) / 256;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_carry_flags, dim3(nb), dim3(256), 0, s, g, d);
+}
+void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &, uint32_t wb, uint32_t we,
+                          uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s) {
+  if (world <= 1 || we <= wb) return;
+  const uint32_t total = (we - wb) * (world - 1);
+  const int G = 64 / g.W;
+  uint32_t nb = (total + 4 * G - 1) / (4 * G);
+  if (nb > 2048) nb = 2048;
+#define CALL(W_, V_) hipLaunchKernelGGL((k_expand_window<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, wb, we, block, my_rank, world)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
 }
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   const uint32_t nother = g.n - (g.node_end - g.node_begin);

@@ -132,6 +132,8 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
                        hipStream_t s);
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
+                          uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s);
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);

@@ -75,6 +75,8 @@ class HipShard:
         for which in (_svils.BUF_GAMMA,):     # Elogpi / mphi are re-derived by PHASE_EXPAND
             ten, rb = t(which, "<f8")
             self.rows.append(ten.view(self.n_alloc, rb // 8))
+        ten, rb = t(_svils.BUF_MPHI, "<f8")   # exchanged only by mini-batch steps
+        self.mphi = ten.view(self.n_alloc, rb // 8)
         conv, _ = t(_svils.BUF_CONV, "<i4")
         self.conv = conv.view(2, self.n_alloc)
         act, _ = t(_svils.BUF_ACTIVE, "<i4")
@@ -143,3 +145,37 @@ class ShardedSweep:
     def gather_communities(self):
         with self._ctx():
             self._allgather_rows(self.s.member)
+
+
+class ShardedStep(ShardedSweep):
+    """Mini-batch (Robbins-Monro) steps over node-block shards: every rank takes the window at the same
+    offset inside its own block (svils_step_window), so one step updates world x batch_nodes nodes.
+    Exchanges per step: all-reduce of `sum[k]` (K doubles); all-gather of the WINDOWS' gamma and mphi
+    rows and flags (world x batch_nodes rows, not n); all-reduce of s1,s2,s3 (3K doubles) -- the
+    "K-vector lambda and touched gamma rows" of the global step.  The engines must have been put in
+    mini-batch mode with shard_block = HipShard.B."""
+
+    def _allgather_window(self, t, b, e):
+        if self.world > 1 and e > b:
+            B, r = self.s.B, self.s.rank
+            outs = [t[q * B + b:q * B + e] for q in range(self.world)]
+            mine = outs[r]
+            self.dist.all_gather(outs, mine.clone(), group=self.group)   # the input aliases outs[r]
+
+    def step(self, nsteps=1):
+        s = self.s
+        eng = s.engine
+        with self._ctx():
+            for _ in range(nsteps):
+                eng.step_phase(_svils.PHASE_A)
+                self._allreduce(s.kvec_a)
+                eng.step_phase(_svils.PHASE_B)
+                b, e = eng.step_window()
+                new = (s.sweeps & 1) ^ 1
+                for t in s.rows + [s.mphi, s.conv[new].view(s.n_alloc, 1), s.active, s.amask]:
+                    self._allgather_window(t, b, e)
+                eng.step_phase(_svils.PHASE_EXPAND)
+                eng.step_phase(_svils.PHASE_C)
+                self._allreduce(s.kvec_c)
+                eng.step_phase(_svils.PHASE_D)
+                s.end_sweep()

@@ -137,3 +137,49 @@ def test_two_processes_one_gpu(graph_files, tmp_path, world, k, sweeps):
         assert np.array_equal(s["member"], ref.communities())
     for s in states[1:]:
         assert np.array_equal(s["gamma"], states[0]["gamma"]) and np.array_equal(s["lam"], states[0]["lam"])
+
+
+def _run_workers(graph_files, tmp_path, world, k, steps, mode, port):
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py")
+    out = str(tmp_path / "state")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker,
+                        graph_files["lfr"], "1000", str(k), str(steps), out, mode],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [np.load(out + ".%d.npz" % rk) for rk in range(world)]
+
+
+@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 30), (3, 64, 5)])
+def test_sharded_minibatch_full_window_is_a_sweep(graph_files, tmp_path, world, k, sweeps):
+    """sharded mini-batch steps with one window per block and step size 1 (kappa = 0) are full sweeps:
+    separate processes, gloo group on GPU 0, state equal to the oracle's on every rank"""
+    states = _run_workers(graph_files, tmp_path, world, k, sweeps, "step:1:0", 29610 + world)
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    for s in states:
+        assert np.max(np.abs(s["gamma"] - ref.gamma) / np.abs(ref.gamma)) < 1e-5
+        assert np.max(np.abs(s["lam"] - ref.lam) / np.abs(ref.lam)) < 1e-5
+        assert np.array_equal(s["conv"], ref.converged)
+        assert int(s["iter"]) == ref.iter and bool(s["annealing"]) == ref.annealing
+        np.testing.assert_allclose(s["rows"][:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+    for s in states[1:]:
+        assert np.array_equal(s["gamma"], states[0]["gamma"]) and np.array_equal(s["lam"], states[0]["lam"])
+
+
+def test_sharded_minibatch_windows(graph_files, tmp_path):
+    """3 windows per block, damped steps, 2 ranks: 90 steps = 30 passes over the nodes.  The replicated state
+    is bit-identical on both ranks, every node has been updated (sum_k mphi = 1/2, quirk Q3), the held-out
+    likelihood improves."""
+    states = _run_workers(graph_files, tmp_path, 2, 28, 90, "step:3:0.5", 29620)
+    a, b = states
+    for key in ("gamma", "lam", "conv", "rows", "mphi"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.isfinite(a["gamma"]).all() and (a["gamma"] > 0).all() and (a["lam"] > 0).all()
+    np.testing.assert_allclose(a["mphi"].sum(1), 0.5, rtol=1e-9)
+    assert int(a["iter"]) == 90 and a["rows"].shape[0] == 90
+    assert a["rows"][-1, 9] > a["rows"][0, 9]
