@@ -652,6 +652,7 @@ void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes) {
   cfg->node_tau0 = 1024; cfg->node_kappa = 0.5;   // src/env.hh:405-408
   cfg->tau0 = 1024; cfg->kappa = 0.9;
   cfg->seed = 0;
+  cfg->shard_block = 0;
 }
 
 int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
