@@ -66,3 +66,75 @@ def test_sharded_equals_oracle(graph_files, tmp_path, world, sweeps):
     np.testing.assert_allclose(got["gamma"], ref.gamma, rtol=1e-8)
     np.testing.assert_allclose(got["lam"], ref.lam, rtol=1e-8)
     np.testing.assert_allclose(got["rows"], ref.rows[1:, 9], rtol=1e-9)
+
+
+class _FakeStepEngine:
+    """records the phase order and hands out scripted windows: the exchange logic of ShardedStep is
+    what is under test here, not the kernels (those run in tests/test_gpu_sharded.py)"""
+
+    def __init__(self, windows):
+        self.windows, self.t, self.calls = windows, 0, []
+
+    def step_phase(self, ph):
+        self.calls.append(ph)
+        if ph == 3:          # PHASE_D closes the step
+            self.t += 1
+
+    def step_window(self):
+        return self.windows[self.t % len(self.windows)]
+
+
+class _FakeShard:
+    def __init__(self, rank, world, B, cols, windows):
+        self.rank, self.world, self.B, self.n_alloc = rank, world, B, B * world
+        self.engine = _FakeStepEngine(windows)
+        mk = lambda c, dt: torch.zeros(self.n_alloc, c, dtype=dt)
+        self.rows, self.mphi = [mk(cols, torch.float64)], mk(cols, torch.float64)
+        self.conv = torch.zeros(2, self.n_alloc, dtype=torch.int32)
+        self.active, self.amask = mk(1, torch.int32), mk(1, torch.int64)
+        self.kvec_a, self.kvec_c = torch.zeros(cols, dtype=torch.float64), torch.zeros(3 * cols, dtype=torch.float64)
+        self.sweeps = 0
+
+    def end_sweep(self):
+        self.sweeps += 1
+
+
+def _step_worker(rank, world, port, B, cols, windows, out):
+    from svinet_amd.sharded import ShardedStep
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = _FakeShard(rank, world, B, cols, windows)
+        drv = ShardedStep(sh, dist)
+        for t, (b, e) in enumerate(windows):
+            # what this rank's kernels would have produced in its own window
+            lo, hi = rank * B + b, rank * B + e
+            sh.rows[0][lo:hi] = 100.0 * (t + 1) + rank
+            sh.mphi[lo:hi] = -(100.0 * (t + 1) + rank)
+            sh.conv[(sh.sweeps & 1) ^ 1][lo:hi] = 7 * (t + 1) + rank
+            sh.kvec_a[:] = rank + 1.0
+            sh.kvec_c[:] = 2.0 * (rank + 1)
+            drv.step(1)
+            assert sh.kvec_a[0].item() == world * (world + 1) / 2 and sh.kvec_c[0].item() == world * (world + 1)
+        assert sh.engine.calls == [0, 1, 4, 2, 3] * len(windows)      # A, B, EXPAND, C, D
+        np.savez(out + ".%d.npz" % rank, gamma=sh.rows[0].numpy(), mphi=sh.mphi.numpy(), conv=sh.conv.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_exchanges_only_the_windows(tmp_path, world):
+    B, cols = 10, 4
+    windows = [(0, 4), (4, 8), (8, 10)]
+    out = str(tmp_path / "st")
+    mp.spawn(_step_worker, args=(world, _free_port(), B, cols, windows, out), nprocs=world, join=True)
+    got = [np.load(out + ".%d.npz" % r) for r in range(world)]
+    for g in got[1:]:                                   # replicated after the exchanges
+        for key in ("gamma", "mphi", "conv"):
+            assert np.array_equal(g[key], got[0][key])
+    gam = got[0]["gamma"]
+    for t, (b, e) in enumerate(windows):
+        for r in range(world):
+            assert np.all(gam[r * B + b:r * B + e] == 100.0 * (t + 1) + r)
+            assert np.all(got[0]["mphi"][r * B + b:r * B + e] == -(100.0 * (t + 1) + r))
