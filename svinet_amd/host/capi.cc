@@ -9,6 +9,7 @@
 #include "linksampling.hh"
 #include "mmsbbatch.hh"
 #include "network.hh"
+#include "nmi.hh"
 
 using namespace svinet;
 
@@ -86,6 +87,14 @@ uint64_t svih_nlinks(svih_setup *s) { return s->ls->training_links().size() / 2;
 const uint32_t *svih_links(svih_setup *s) { return s->ls->training_links().data(); }
 const uint32_t *svih_edges(const svih_setup *s) { return &s->net->edges()[0].first; }
 uint32_t svih_deg(const svih_setup *s, uint32_t p) { return s->net->deg(p); }
+
+// normalised mutual information of a communities.txt-style file against a ground-truth file in the
+// "node<TAB>community ..." format of -nmi; < 0 when a file cannot be read
+double svih_nmi(const char *communities_path, const char *ground_truth_path) {
+  Cover x, y;
+  if (!read_cover_lines(communities_path, &x) || !read_cover_memberships(ground_truth_path, &y)) return -1.0;
+  return lfk_nmi(y, x);
+}
 
 // ---- the -batch engine (host CPU), for the tests ----
 struct svih_batch {

@@ -81,6 +81,24 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     exit(-1);
   }
 
+  if (env_.nmi) {   // Network::load_ground_truth / write_gt_communities (src/network.cc:252-307,508-525)
+    if (!read_cover_memberships(env_.ground_truth_fname, &ground_truth_)) {
+      fprintf(stderr, "error: cannot read ground truth file %s; check path; skipping file\n", env_.ground_truth_fname.c_str());
+    } else if (env_.write_files) {
+      printf("+ Done loading ground truth\n+ Writing ground truth communities\n");
+      FILE *f = open_or_die(Env::file_str("/ground_truth.txt"), "ground truth");
+      FILE *g = open_or_die(Env::file_str("/ground_truth_community_sizes.txt"), "ground truth sizes");
+      uint32_t c = 0;
+      for (const auto &v : ground_truth_) {
+        fprintf(g, "%d\t%ld\n", c++, (long)v.size());
+        for (uint32_t id : v) fprintf(f, "%d ", id);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+      fclose(g);
+    }
+  }
+
   gamma_.assign((size_t)n_ * k_, 0.0);
   lambda_.assign(2 * (size_t)k_, 0.0);
   if (env_.model_load) {
@@ -437,6 +455,7 @@ void LinkSampling::log_communities() {                     // :839-852, :882-917
   FILE *f = open_or_die(Env::file_str("/communities.txt"), "communities");
   const std::vector<uint32_t> &s2i = network_.seq2id();
   std::vector<uint32_t> ids;
+  Cover found;
   for (uint32_t c = 0; c < k_; ++c) {
     ids.clear();
     for (uint32_t p = 0; p < n_; ++p)
@@ -445,8 +464,17 @@ void LinkSampling::log_communities() {                     // :839-852, :882-917
     std::sort(ids.begin(), ids.end());
     for (uint32_t id : ids) fprintf(f, "%d ", id);
     fprintf(f, "\n");
+    if (env_.nmi) found.push_back(ids);
   }
   fclose(f);
+  if (env_.nmi && !ground_truth_.empty()) {
+    // the reference runs `/usr/local/bin/mutual ground_truth.txt communities.txt >> mutual.txt` here (:843-851)
+    FILE *mf = fopen(Env::file_str("/mutual.txt").c_str(), "a");
+    if (mf) {
+      fprintf(mf, "mutual3:\t%g\n", lfk_nmi(ground_truth_, found));
+      fclose(mf);
+    }
+  }
 }
 
 void LinkSampling::do_on_stop() {                          // src/linksampling.cc:792-802

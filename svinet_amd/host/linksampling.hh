@@ -17,6 +17,7 @@
 
 #include "env.hh"
 #include "network.hh"
+#include "nmi.hh"
 #include "rng.hh"
 
 struct svils_handle;
@@ -84,6 +85,7 @@ class LinkSampling {
   // mini-batch mode: nodes are handed to the device under a random relabelling so that a window of
   // consecutive device ids is a uniform random subset; dev_of_[seq] / seq_of_[dev], empty otherwise
   std::vector<uint32_t> dev_of_, seq_of_;
+  Cover ground_truth_;                         // -nmi: the reference cover (external ids)
   svils_handle *h_ = nullptr;
   bool graph_sent_ = false;
   uint32_t rows_logged_ = 0;

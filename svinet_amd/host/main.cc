@@ -51,6 +51,8 @@ static void usage() {
           "\t-seed\t\tset random generator seed\n\n"
           "\t-heldout-ratio, -link-thresh, -lt-min-deg, -eta-type, -accuracy\tas in the reference\n\n"
           "\t-strid\t\tnode names are strings (writes str2id.txt)\n\n"
+          "\t-nmi <file>\tground-truth communities (\"node<TAB>community ...\" per line): the normalised mutual\n"
+          "\t\t\tinformation of every communities.txt against it is appended to mutual.txt\n\n"
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
           "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
           "\t-minibatch <m>\tmini-batch mode of -link-sampling: one step = the links of m randomly chosen nodes,\n"
@@ -133,8 +135,6 @@ int main(int argc, char **argv) {
     fprintf(stderr, "error: -n and -k are required\n");
     return -1;
   }
-  if (a.nmi) fprintf(stderr, "warning: -nmi needs the external /usr/local/bin/mutual tool; ignored\n");
-  a.nmi = false;
 
   Env env(a);
   env_global = &env;

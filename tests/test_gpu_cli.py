@@ -149,3 +149,19 @@ def test_cli_minibatch_mode(graph_files, tmp_path):
     rng = np.random.default_rng(0)
     rnd = np.mean([top[a] == top[b] for a, b in zip(rng.permutation(ids), rng.permutation(ids))])
     assert same > rnd + 0.3
+
+
+def test_cli_nmi(graph_files, tmp_path):
+    """-nmi <ground truth>: ground_truth.txt in the reference's layout and one `mutual3:` line per
+    communities.txt written; the LFR communities are recovered (the authors' run ends at 0.897)."""
+    truth = os.path.join(GOLDEN, "graphs", "LFR-ground-truth-n1000-k28.txt")
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-nmi", truth], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    gt = [l.split() for l in (d / "ground_truth.txt").read_text().splitlines() if l.strip()]
+    assert len(gt) == 28 and sum(len(c) for c in gt) >= 1000
+    lines = (d / "mutual.txt").read_text().splitlines()
+    rows = np.loadtxt(d / "validation.txt")
+    assert all(l.startswith("mutual3:\t") for l in lines) and len(lines) == rows.shape[0] - 1   # row 0 is the constructor's
+    vals = np.array([float(l.split("\t")[1]) for l in lines])
+    assert vals[0] < 0.2 and vals[-1] > 0.8

@@ -128,3 +128,22 @@ def test_cli_strid(tmp_path):
     assert dict((a, int(b)) for a, b in table) == {nm: i for i, nm in enumerate(names)}
     ve = (d / "validation-edges.txt").read_text()
     assert ve.endswith("\n")
+
+
+def test_nmi_matches_the_shipped_mutual_txt():
+    """-nmi: the reference appends the external `mutual` program's output to mutual.txt after every
+    communities.txt; the authors' shipped LFR run holds both files, so the last mutual.txt line pins the
+    native implementation (svinet_amd/host/nmi.cc)."""
+    import ctypes as C
+    from svinet_amd import host_api
+    L = host_api.load()
+    L.svih_nmi.argtypes = [C.c_char_p, C.c_char_p]
+    L.svih_nmi.restype = C.c_double
+    d = os.path.join(GOLDEN, "ref_lfr_k28")
+    truth = os.path.join(GOLDEN, "graphs", "LFR-ground-truth-n1000-k28.txt")
+    v = L.svih_nmi(os.fsencode(os.path.join(d, "communities.txt")), os.fsencode(truth))
+    last = open(os.path.join(d, "mutual.txt")).read().split()[-1]
+    assert "%g" % v == last == "0.897372"
+    # a cover against itself is 1; unreadable files are reported
+    own = os.path.join(d, "communities.txt")
+    assert L.svih_nmi(os.fsencode(own), b"/nonexistent") < 0
