@@ -70,6 +70,10 @@ typedef struct {
   /* rows allocated for the replicated n-by-k arrays (>= n; 0 = n).  A caller
    * that all-gathers equal node blocks sets world_size * block_rows.        */
   uint32_t n_alloc;
+  /* the active-set branch is taken when _iter > sparse_after_iter: the constant 1000 of
+   * src/linksampling.cc:634 (svils_config_default).  The revision that produced the runs shipped
+   * under example/ behaved like 0, which is how the tests reproduce them. */
+  int32_t sparse_after_iter;
 } svils_config;
 
 /* fills the reference's defaults for a given n,k (alpha=1/k, eta=1,1, ...) */

@@ -28,7 +28,8 @@ class _Config(C.Structure):
                 ("link_thresh", C.c_double), ("lt_min_deg", C.c_uint32), ("eta_type", C.c_int),
                 ("reportfreq", C.c_uint32), ("max_iterations", C.c_uint32),
                 ("use_validation_stop", C.c_int), ("skip_init", C.c_int), ("accuracy", C.c_int),
-                ("eta_override0", C.c_double), ("eta_override1", C.c_double), ("train_on_heldout", C.c_int)]
+                ("eta_override0", C.c_double), ("eta_override1", C.c_double), ("train_on_heldout", C.c_int),
+                ("sparse_after_iter", C.c_int32)]
 
 
 _lib = None
@@ -171,7 +172,7 @@ class LinkSampling:
 
     def __init__(self, net, k, seed=0, heldout_ratio=0.01, link_thresh=0.5, lt_min_deg=0,
                  eta_type="uniform", reportfreq=1, max_iterations=0, use_validation_stop=True,
-                 skip_init=False, accuracy=False, eta_override=None, train_on_heldout=False):
+                 skip_init=False, accuracy=False, eta_override=None, train_on_heldout=False, sparse_after_iter=1000):
         L = lib()
         cfg = _Config()
         L.orc_config_default(C.byref(cfg), k)
@@ -188,6 +189,7 @@ class LinkSampling:
         if eta_override is not None:
             cfg.eta_override0, cfg.eta_override1 = eta_override
         cfg.train_on_heldout = int(train_on_heldout)
+        cfg.sparse_after_iter = int(sparse_after_iter)
         self.net = net
         self._h = L.orc_ls_create(net._h, C.byref(cfg))
         self.n = L.orc_ls_n(self._h)

@@ -299,6 +299,7 @@ void orc_config_default(orc_config *c, uint32_t k) {
   c->max_iterations = 0;
   c->use_validation_stop = 1;
   c->skip_init = 0;
+  c->sparse_after_iter = 1000;   /* src/linksampling.cc:634 */
 }
 
 static uint64_t hash_u64(uint64_t x) {
@@ -689,7 +690,7 @@ int orc_ls_sweep(orc_ls *m) {
       sc++;
     } else {
       double r = .0;
-      if (m->iter > 1000 && m->active_comms[p] < m->k10 && m->active_comms[q] < m->k10) {
+      if ((int64_t)m->iter > (int64_t)m->cfg.sparse_after_iter && m->active_comms[p] < m->k10 && m->active_comms[q] < m->k10) {
         /* sorted, unique union of the two active lists, :635-640 */
         uint32_t nu = 0;
         for (uint32_t j = 0; j < m->active_k_len[p]; ++j) uni[nu++] = m->active_k[(size_t)p * m->k10 + j];

@@ -11,17 +11,19 @@
  *     example/n1000-k28-LFR-linksampling.tgz and
  *     example/n17903-k20-mmsb-linksampling.tgz (heldout-edges.txt and the
  *     first row of heldout.txt) -- tests/test_oracle_golden.py.
- *   - the sweep itself (phi pass, mean indicators, s3, lambda, expectations,
- *     prune, likelihood, annealing switch, stop rule) is PINNED against the
- *     authors' shipped trajectories and final models in the same tarballs
- *     (heldout.txt, max.txt, gamma.txt, lambda.txt).  Those runs came from an
- *     older revision that used eta = 0.001 and kept held-out links in the
- *     training list; with exactly those two settings (eta_override,
- *     train_on_heldout) this restatement reproduces every printed digit of the
- *     first 20 (LFR) / 26 (ca-AstroPh) likelihood rows, the last printed digit
- *     of all 44 / 100 rows, the stopping sweep (43 / 99) and gamma/lambda to
- *     print resolution.  The reference itself cannot be built here (needs GSL,
- *     absent from the image), so there is no oracle/_ref.
+ *   - the sweep itself (phi pass incl. the converged-node shortcuts and the active-set
+ *     branch, mean indicators, s3, lambda, expectations, prune, likelihood, annealing
+ *     switch, stop rule) is PINNED against the authors' shipped runs in the same
+ *     tarballs (heldout.txt, max.txt, infer.log, gamma.txt, lambda.txt).  Those runs came
+ *     from an older revision that differs on this path in three inputs: eta = 0.001,
+ *     held-out links kept in the training list, and the active-set branch not gated by
+ *     _iter > 1000.  With exactly those settings (eta_override, train_on_heldout,
+ *     sparse_after_iter = 0) this restatement reproduces every printed digit of every
+ *     column of all 45 (LFR) / 101 (ca-AstroPh) likelihood rows, the number of links
+ *     that took the dense and the active-set branch in every sweep (infer.log), the
+ *     sweep of the annealing switch, the stopping sweep (43 / 99) and gamma/lambda to
+ *     print resolution.  The reference itself cannot be built here (needs GSL, absent
+ *     from the image), so there is no oracle/_ref.
  *
  * Every function cites the reference file:line it restates
  * (paths relative to the reference tree, e.g. src/linksampling.cc:605-725).
@@ -76,6 +78,9 @@ typedef struct {
    * arithmetic against those shipped trajectories */
   double eta_override0, eta_override1;   /* > 0: replace eta0/eta1 */
   int train_on_heldout;                  /* 1: keep held-out links in the training list */
+  /* the active-set ("sparse") branch is taken when _iter > sparse_after_iter (src/linksampling.cc:634
+   * has the constant 1000; the revision that made the shipped runs had no such condition: -1) */
+  int32_t sparse_after_iter;
 } orc_config;
 
 void orc_config_default(orc_config *c, uint32_t k);

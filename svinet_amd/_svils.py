@@ -47,7 +47,7 @@ class Config(C.Structure):
         ("use_validation_stop", C.c_int32),
         ("ones_prob", C.c_double), ("zeros_prob", C.c_double),
         ("device", C.c_int32), ("node_begin", C.c_uint32), ("node_end", C.c_uint32),
-        ("n_alloc", C.c_uint32),
+        ("n_alloc", C.c_uint32), ("sparse_after_iter", C.c_int32),
     ]
 
 
@@ -129,7 +129,8 @@ class Engine:
     """One svils_handle: the device-resident body of LinkSampling::infer()."""
 
     def __init__(self, n, k, ones, ones_prob, eta=(1.0, 1.0), link_thresh=0.5, lt_min_deg=0,
-                 reportfreq=1, use_validation_stop=True, device=0, node_block=None, n_alloc=0):
+                 reportfreq=1, use_validation_stop=True, device=0, node_block=None, n_alloc=0,
+                 sparse_after_iter=1000):
         L = load()
         cfg = Config()
         _chk(L.svils_config_default(C.byref(cfg), n, k))
@@ -145,6 +146,7 @@ class Engine:
         if node_block is not None:
             cfg.node_begin, cfg.node_end = node_block
         cfg.n_alloc = n_alloc
+        cfg.sparse_after_iter = sparse_after_iter
         self.n, self.k = n, k
         self._h = C.c_void_p()
         _chk(L.svils_create(C.byref(cfg), C.byref(self._h)))

@@ -228,6 +228,7 @@ int svils_config_default(svils_config *cfg, uint32_t n, uint32_t k) {
   cfg->node_begin = 0;
   cfg->node_end = n;
   cfg->n_alloc = 0;
+  cfg->sparse_after_iter = 1000;   // src/linksampling.cc:634
   return 0;
 }
 
@@ -265,6 +266,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   p.epsilon = cfg->epsilon; p.link_thresh = cfg->link_thresh; p.lt_min_deg = cfg->lt_min_deg;
   p.reportfreq = cfg->reportfreq; p.use_validation_stop = cfg->use_validation_stop;
   p.ones_prob = cfg->ones_prob; p.zeros_prob = cfg->zeros_prob;
+  p.sparse_after = cfg->sparse_after_iter;
   memset(&h->d, 0, sizeof(h->d));
 
   int rc = 0;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
   const int lw = lane;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
-  const bool sparse_iter = ctrl->iter > 1000;  // src/linksampling.cc:634
+  const bool sparse_iter = (long long)ctrl->iter > (long long)prm.sparse_after;  // _iter > 1000, src/linksampling.cc:634
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
   const double *__restrict__ elogpi = d.elogpi;
 

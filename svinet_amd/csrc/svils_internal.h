@@ -108,6 +108,7 @@ struct Params {
   uint32_t lt_min_deg, reportfreq;
   int32_t use_validation_stop;
   double ones_prob, zeros_prob;
+  int32_t sparse_after;   // active-set branch when _iter > sparse_after (1000, src/linksampling.cc:634)
   // mini-batch (Robbins-Monro) steps, svils_step(); all neutral for full sweeps
   int32_t stoch;          // 1: this launch is a mini-batch step over the node window [node_begin, node_end)
   double tau0, kappa;     // step size of a node that has been updated c times: (tau0 + c)^-kappa (node_tau0/node_kappa)

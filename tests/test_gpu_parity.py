@@ -176,9 +176,13 @@ def test_no_device_is_loud():
 # HIP path directly against the reference authors' shipped runs (real GSL; older
 # revision: eta = 0.001, held-out links kept in training -- tests/golden/README.md)
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("key,d,n,k,hr,stop_iter", [("lfr", "ref_lfr_k28", 1000, 28, 0.01, 43),
-                                                    ("astroph", "ref_astroph_k20", 17903, 20, 0.02, 99)])
-def test_against_shipped_reference_runs(graph_files, key, d, n, k, hr, stop_iter):
+@pytest.mark.parametrize("key,d,n,k,hr,anneal_end,stop_iter", [("lfr", "ref_lfr_k28", 1000, 28, 0.01, 32, 43),
+                                                               ("astroph", "ref_astroph_k20", 17903, 20, 0.02, 79, 99)])
+def test_against_shipped_reference_runs(graph_files, key, d, n, k, hr, anneal_end, stop_iter):
+    """The three differences of the revision that made the shipped runs are inputs of the C ABI: eta,
+    the link list (held-out links kept) and sparse_after_iter = 0.  Checked sweep by sweep against the
+    authors' infer.log (links taking the full softmax / the active-set branch), heldout.txt, max.txt and
+    the final model."""
     import os
     from conftest import GOLDEN
     from svinet_amd._svils import Engine
@@ -186,18 +190,29 @@ def test_against_shipped_reference_runs(graph_files, key, d, n, k, hr, stop_iter
     s = Setup(graph_files[key], n, k, heldout_ratio=hr)
     all_links = Setup(graph_files[key], n, k, heldout_ratio=hr, accuracy=True).links   # nothing held out
     assert all_links.shape[0] == s.ones
-    eng = Engine(s.n, s.k, ones=s.ones, ones_prob=s.ones_prob, eta=(0.001, 0.001))
+    eng = Engine(s.n, s.k, ones=s.ones, ones_prob=s.ones_prob, eta=(0.001, 0.001), sparse_after_iter=0)
     eng.set_graph(all_links)
     eng.set_validation(s.validation_sorted)
     eng.set_state(s.gamma, np.full((k, 2), 0.001))
     gold = np.array([[float(x) for x in l.split("\t")] for l in
                      open(os.path.join(GOLDEN, d, "heldout.txt")).read().split("\n") if l])
+    steps = np.loadtxt(os.path.join(GOLDEN, d, "local_steps.txt"), dtype=np.int64)
     np.testing.assert_allclose(eng.validation_row()[1:], np.delete(gold[0], 1)[1:], rtol=0, atol=6e-10)
-    eng.sweep(gold.shape[0] + 10)            # the device-side stop rule must fire where the authors' run did
+    switched = None
+    for sw in range(steps.shape[0]):
+        was = eng.control().annealing
+        eng.sweep(1)
+        c = eng.control()
+        assert (c.links_dense, c.links_sparse, c.links_dense + c.links_sparse + c.links_shortcut) == \
+               (steps[sw, 0], steps[sw, 1], steps[sw, 3]), "sweep %d" % sw
+        if was and not c.annealing:
+            switched = sw
+    assert switched == anneal_end
+    eng.sweep(10)                            # the device-side stop rule fired where the authors' run did
     c = eng.control()
     assert c.stopped == 1 and c.iter == stop_iter and c.sweeps_done == gold.shape[0] - 1
     rows = eng.rows()
-    np.testing.assert_allclose(rows[:, 1:], np.delete(gold[1:], 1, axis=1)[:, 1:], rtol=0, atol=6e-9)
+    np.testing.assert_allclose(rows[:, 1:], np.delete(gold[1:], 1, axis=1)[:, 1:], rtol=0, atol=1e-9)
     assert np.array_equal(rows[:, 0], gold[1:, 0])
     g, lam, _ = eng.state()
     np.testing.assert_allclose(lam, np.loadtxt(os.path.join(GOLDEN, d, "lambda.txt"))[:, 1:], rtol=0, atol=1.1e-5)

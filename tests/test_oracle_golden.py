@@ -157,8 +157,9 @@ def test_writers_round_trip(graph_files, tmp_path):
 # Those runs used an older revision: eta = (0.001, 0.001) and held-out links kept
 # in the training list (tests/golden/README.md); the arithmetic is today's.
 # ---------------------------------------------------------------------------
-LEGACY = dict(eta_override=(0.001, 0.001), train_on_heldout=True)
-SHIPPED = {"lfr": ("ref_lfr_k28", 1000, 28, 0.01, 20, 43), "astroph": ("ref_astroph_k20", 17903, 20, 0.02, 26, 99)}
+# the three differences of the revision that produced the shipped runs (tests/golden/README.md)
+LEGACY = dict(eta_override=(0.001, 0.001), train_on_heldout=True, sparse_after_iter=0)
+SHIPPED = {"lfr": ("ref_lfr_k28", 1000, 28, 0.01, 32, 43), "astroph": ("ref_astroph_k20", 17903, 20, 0.02, 79, 99)}
 
 
 def _gold_rows(d):
@@ -167,27 +168,35 @@ def _gold_rows(d):
 
 @pytest.mark.parametrize("key", ["lfr", "astroph"])
 def test_shipped_trajectory_stop_and_model(graph_files, key):
-    d, n, k, hr, exact_rows, stop_iter = SHIPPED[key]
+    d, n, k, hr, anneal_end, stop_iter = SHIPPED[key]
     net = O.Network(graph_files[key], n)
     ls = O.LinkSampling(net, k, heldout_ratio=hr, **LEGACY)          # validation stop ON, as shipped
     gold = _gold_rows(d)
-    sweeps = 0
+    # infer.log of the shipped run: "local step on (dense, sparse, dense+sparse, links) links" per sweep and
+    # "annealing phase completed ... at iteration <anneal_end>"
+    steps = np.loadtxt(os.path.join(GOLDEN, d, "local_steps.txt"), dtype=np.int64)
+    sweeps, switched = 0, None
     while True:
+        was = ls.annealing
         rc = ls.sweep()
+        dense, sparse, shortcut = ls.link_counts()
+        assert (dense, sparse, dense + sparse + shortcut) == (steps[sweeps, 0], steps[sweeps, 1], steps[sweeps, 3]), sweeps
+        if was and not ls.annealing:
+            switched = sweeps
         sweeps += 1
         assert sweeps <= len(gold)
         if rc == 2:
             break
+    assert switched == anneal_end and sweeps == steps.shape[0]
     # same stopping sweep as the authors' run (max.txt: "<iter> <secs> ... 1")
     assert ls.iter == stop_iter == int(open(os.path.join(GOLDEN, d, "max.txt")).read().split()[0])
     assert sweeps == len(gold) - 1
     rows = ls.rows
-    # every printed digit of every column for the first sweeps ...
-    for i in range(exact_rows + 1):
+    # every printed digit of every column of EVERY row: through the converged-node shortcuts, the active-set
+    # branch (from sweep 18 on LFR), the annealing switch and up to the stop
+    assert len(rows) == len(gold)
+    for i in range(len(gold)):
         assert _fmt_row(rows[i]) == [gold[i][0]] + gold[i][2:], "row %d" % i
-    # ... and the last printed digit afterwards (through the annealing switch, up to the stop)
-    g = np.array([[float(x) for x in r] for r in gold])
-    np.testing.assert_allclose(rows[:, 1:], np.delete(g, 1, axis=1)[:, 1:], rtol=0, atol=6e-9)
     # final model against the shipped gamma.txt / lambda.txt (printed with 5 decimals)
     lam = np.loadtxt(os.path.join(GOLDEN, d, "lambda.txt"))
     np.testing.assert_allclose(ls.lam, lam[:, 1:], rtol=0, atol=1.1e-5)
