@@ -66,7 +66,8 @@ Env::Env(const Args &a)
       batch_mode(a.batch), link_sampling(a.link_sampling), strid(a.strid),
       terminate(0), total_pairs(0), ones_prob(0), zeros_prob(1),
       device(a.device), sweep_batch(a.sweep_batch ? a.sweep_batch : 1), write_files(a.write_files),
-      minibatch(a.minibatch), tau0(a.tau0), kappa(a.kappa), nodetau0(a.nodetau0), nodekappa(a.nodekappa) {
+      minibatch(a.minibatch), tau0(a.tau0), kappa(a.kappa), nodetau0(a.nodetau0), nodekappa(a.nodekappa),
+      sparse_after(a.sparse_after) {
   if (!write_files) {
     if (plogf_) { fclose(plogf_); plogf_ = nullptr; }
     prefix.clear();

@@ -44,6 +44,7 @@ class Env {
     // mini-batch mode of -link-sampling (include/svils.h, svils_step): 0 = full sweeps (the reference's loop)
     uint32_t minibatch = 0;     // nodes per mini-batch
     double tau0 = 1024, kappa = 0.9, nodetau0 = 1024, nodekappa = 0.5;   // src/env.hh:405-408
+    int32_t sparse_after = 1000;   // the active-set branch needs _iter > this (src/linksampling.cc:634)
   };
 
   explicit Env(const Args &a);
@@ -84,6 +85,7 @@ class Env {
   bool write_files;
   uint32_t minibatch;
   double tau0, kappa, nodetau0, nodekappa;
+  int32_t sparse_after;
 
   static std::string prefix;
   static std::string file_str(const std::string &fname) { return prefix + fname; }

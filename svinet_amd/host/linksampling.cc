@@ -160,6 +160,7 @@ void LinkSampling::attach() {
   cfg.ones_prob = ones_prob_;
   cfg.zeros_prob = zeros_prob_;
   cfg.device = env_.device;
+  cfg.sparse_after_iter = env_.sparse_after;
   if (svils_create(&cfg, &h_)) die_svils("svils_create");
   if (env_.minibatch) {
     // random relabelling (own generator: the GSL stream of the samplers / init is not disturbed)

@@ -55,6 +55,8 @@ static void usage() {
           "\t\t\tinformation of every communities.txt against it is appended to mutual.txt\n\n"
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
           "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
+          "\t-sparse-after <i>\tthe active-set branch of the phi pass is used once the iteration count exceeds i\n"
+          "\t\t\t(default 1000, the reference's constant)\n\n"
           "\t-minibatch <m>\tmini-batch mode of -link-sampling: one step = the links of m randomly chosen nodes,\n"
           "\t\t\tRobbins-Monro step sizes (-tau0 -kappa -nodetau0 -nodekappa; defaults 1024 0.9 1024 0.5);\n"
           "\t\t\tgive -rfreq <steps> after -link-sampling to evaluate the stop rule every <steps> steps\n\n");
@@ -105,6 +107,7 @@ int main(int argc, char **argv) {
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
     else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
+    else if (is("-sparse-after")) { need(i); a.sparse_after = atoi(argv[++i]); }
     else if (is("-minibatch")) { need(i); a.minibatch = atoi(argv[++i]); }
     else if (is("-tau0")) { need(i); a.tau0 = atof(argv[++i]); }
     else if (is("-kappa")) { need(i); a.kappa = atof(argv[++i]); }
