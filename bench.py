@@ -159,6 +159,8 @@ def main():
         data = ("synthetic sparse MMSB graph (svinet_amd/mmsbgen_sparse.py: Dirichlet(0.05) top-4 memberships, "
                 "Beta(4700.59,0.77) rates, Philox seed %d), seeded init" % mmsbgen_sparse.DEFAULT_SEED)
     else:
+        if args.workload not in WORKLOADS and args.workload.startswith("astroph-k"):   # any K on ca-AstroPh
+            WORKLOADS[args.workload] = ("ca-AstroPh.csv.gz", 17903, int(args.workload[len("astroph-k"):]))
         fixture, n, k = WORKLOADS[args.workload]
         path = _fixture(fixture)
         setup = Setup(path, n, k)
