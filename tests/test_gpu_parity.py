@@ -222,3 +222,26 @@ def test_against_shipped_reference_runs(graph_files, key, d, n, k, hr, anneal_en
         gg = np.loadtxt(os.path.join(GOLDEN, d, "gamma_rows_mod16.txt.gz"))
         np.testing.assert_allclose(g[gg[:, 0].astype(np.int64)], gg[:, 2:], rtol=0, atol=1.1e-5)
         np.testing.assert_allclose(g.sum(0), np.loadtxt(os.path.join(GOLDEN, d, "gamma_colsums.txt")), rtol=1e-8)
+
+
+def test_lfr_long_run_into_the_active_set_regime(graph_files):
+    """1150 sweeps without the stop rule: the run crosses _iter = 1000 on its own, after which the
+    active-set branch takes over most of the links that are not shortcuts (435 400 sparse
+    evaluations in a 1100-sweep LFR run of the compiled reference).  State, link-branch counts and
+    communities must still agree with the oracle after the whole trajectory."""
+    net = O.Network(graph_files["lfr"], 1000)
+    ref = O.LinkSampling(net, 28, use_validation_stop=False)
+    eng = _engine_from_oracle(ref, net, use_validation_stop=False)
+    sparse_total = 0
+    for upto in (1000, 1002, 1150):
+        while ref.iter < upto:
+            ref.sweep()
+            sparse_total += ref.link_counts()[1]
+        eng.sweep(upto - eng.control().iter)
+        c = eng.control()
+        assert c.iter == ref.iter == upto
+        assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
+        _check_state(eng, ref, "lfr after %d sweeps" % upto)
+    assert sparse_total > 100000 and ref.link_counts()[1] > 0
+    assert np.array_equal(eng.communities(), ref.communities())
+    np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
