@@ -300,9 +300,9 @@ __global__ __launch_bounds__(256) void k_s3_lpl(Geometry geo, DeviceState d) {
 
 // ------------------------------------------------------------------ launchers
 bool use_lpl(uint32_t K) { return K <= 32; }
-// waves per block of k_phi_lpl: static LDS must stay under 64 KiB
-constexpr int lpl_waves(int KC) { return KC >= 16 ? 3 : 4; }
-int lpl_phi_waves(uint32_t K) { return K > 28 ? 3 : 4; }
+// waves per block of k_phi_lpl (with the 32-row staging area every KC fits four)
+constexpr int lpl_waves(int) { return 4; }
+int lpl_phi_waves(uint32_t) { return 4; }
 
 #define LPL_DISPATCH(K_, CALL)                 \
   do {                                         \

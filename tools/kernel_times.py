@@ -14,6 +14,8 @@ elif wl.startswith("mmsb"):
     _, sn, sk, sd = wl.split(":")
     setup = Setup(n=int(sn), k=int(sk), pairs=mmsbgen_sparse.generate(int(sn), int(sk), int(sd)))
 else:
+    if wl not in WORKLOADS and wl.startswith("astroph-k"):
+        WORKLOADS[wl] = ("ca-AstroPh.csv.gz", 17903, int(wl[len("astroph-k"):]))
     f, n, k = WORKLOADS[wl]
     setup = Setup(_fixture(f), n, k)
 eng = setup.engine(use_validation_stop=False)
