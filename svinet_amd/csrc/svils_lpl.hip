@@ -37,7 +37,7 @@ __device__ __forceinline__ void load_row_lane(const double *__restrict__ row, do
 
 // ============================================================== phi pass (A6)
 template <int KC, int NW>
-__global__ __launch_bounds__(64 * NW) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
