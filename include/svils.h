@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 1
+#define SVILS_ABI_VERSION 2
 
 typedef enum {
   SVILS_OK = 0,
@@ -128,7 +128,9 @@ int svils_validation_row(svils_handle *h, double *row10);
 
 /* Enqueue `nsweeps` iterations of the loop body; asynchronous.  The stop
  * rule, the annealing switch and _iter++ run on the device, so no host
- * round trip is needed between sweeps. */
+ * round trip is needed between sweeps.  At most 65536 * reportfreq sweeps per
+ * call: the likelihood rows go to a ring of 65536 entries that the host drains
+ * with svils_get_rows between calls. */
 int svils_sweep(svils_handle *h, uint32_t nsweeps);
 int svils_synchronize(svils_handle *h);
 
@@ -198,7 +200,10 @@ int svils_debug_eval(svils_handle *h, int which, const double *in, double *out, 
 /* ---- measurement --------------------------------------------------------- */
 enum {
   SVILS_KERNEL_PHI = 0, SVILS_KERNEL_REDUCE_SUM, SVILS_KERNEL_FINALIZE, SVILS_KERNEL_S3,
-  SVILS_KERNEL_VALIDATION, SVILS_KERNEL_REDUCE_S, SVILS_KERNEL_TAIL, SVILS_KERNEL_COUNT
+  SVILS_KERNEL_VALIDATION /* part of the tail kernel since ABI 2: never timed */,
+  SVILS_KERNEL_REDUCE_S, SVILS_KERNEL_TAIL /* likelihood + lambda + stop rule */,
+  SVILS_KERNEL_CLASSIFY /* stand-alone link classification (k <= 32; normally fused into the s3 launch) */,
+  SVILS_KERNEL_COUNT
 };
 /* mask: bit i set = bracket kernel i with hipEvents on the library's stream */
 int svils_enable_timing(svils_handle *h, uint32_t kernel_mask);
@@ -209,6 +214,13 @@ int svils_set_timing_period(svils_handle *h, uint32_t period);
  * the last svils_enable_timing call.  Arrays of SVILS_KERNEL_COUNT. */
 int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches);
 const char *svils_kernel_name(int kernel);
+/* How the links of sweeps [first, first+count) (numbered since create) were evaluated
+ * (src/linksampling.cc:622-719; the c / d counters of :602,:726): out[count][3] =
+ * full softmax, active-set softmax, O(1) shortcut.  The device keeps the last 4096 sweeps. */
+int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint64_t *out);
+/* The same three counts summed over exactly those sweeps whose phi launch was bracketed with
+ * hipEvents since the last svils_enable_timing call: what the timed launches processed. */
+int svils_get_timed_links(svils_handle *h, uint64_t *out3);
 
 /* ---- multi-GPU hooks (one process per GPU; collectives stay with the caller) */
 /* The sweep split at its two exchange points.  With node-block ownership each
@@ -225,7 +237,7 @@ int svils_sweep_phase(svils_handle *h, svils_phase phase);
 
 typedef enum {
   SVILS_BUF_KVEC_A = 0,   /* double[k]   : sum (phase A -> all-reduce SUM)          */
-  SVILS_BUF_KVEC_C,       /* double[3k+4]: s1,s2,s3, validation partials (C -> SUM) */
+  SVILS_BUF_KVEC_C,       /* double[3k]  : s1,s2,s3 (phase C -> all-reduce SUM)          */
   SVILS_BUF_GAMMA,        /* double[n_pad][ld] rows, all-gather by node block      */
   SVILS_BUF_ELOGPI,       /* double[n_pad][ld]  (re-derived by EXPAND; exchange optional) */
   SVILS_BUF_MPHI,         /* double[n_pad][ld]  (re-derived by EXPAND; exchange optional) */

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVILS_LIB", os.path.join(_HERE, "lib", "libsvils.so"))  # SVILS_LIB: A/B kernel builds
 
-KERNEL_NAMES = ("phi", "reduce_sum", "finalize", "s3", "validation", "reduce_s", "tail")
+KERNEL_NAMES = ("phi", "reduce_sum", "finalize", "s3", "validation", "reduce_s", "tail", "classify")
 KERNEL_PHI = 0
 
 # every symbol include/svils.h declares (checked by tests/test_abi.py)
@@ -24,6 +24,7 @@ EXPORTS = (
     "svils_get_timing", "svils_kernel_name", "svils_sweep_phase", "svils_device_buffer",
     "svils_stream", "svils_last_error", "svils_abi_version", "svils_debug_eval",
     "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default", "svils_step_phase", "svils_step_window",
+    "svils_get_sweep_stats", "svils_get_timed_links",
 )
 
 
@@ -107,9 +108,11 @@ def load():
     L.svils_stream.argtypes = [vp, C.POINTER(vp)]
     L.svils_debug_eval.argtypes = [vp, C.c_int, vp, vp, C.c_uint32]
     L.svils_set_timing_period.argtypes = [vp, C.c_uint32]
+    L.svils_get_sweep_stats.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.svils_get_timed_links.argtypes = [vp, vp]
     for name in EXPORTS:
         f = getattr(L, name)
-        if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version"):
+        if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -268,6 +271,21 @@ class Engine:
         cnt = np.zeros(len(KERNEL_NAMES), dtype=np.uint64)
         _chk(load().svils_get_timing(self._h, ms.ctypes.data, cnt.ctypes.data))
         return {KERNEL_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(len(KERNEL_NAMES))}
+
+    def sweep_stats(self, first=0, count=None):
+        """(dense, sparse, shortcut) link counts of sweeps [first, first+count)"""
+        if count is None:
+            count = self.control().sweeps_done - first
+        out = np.zeros((count, 3), dtype=np.uint64)
+        if count:
+            _chk(load().svils_get_sweep_stats(self._h, first, count, out.ctypes.data))
+        return out
+
+    def timed_links(self):
+        """(dense, sparse, shortcut) links summed over the sweeps whose phi launch was timed"""
+        out = np.zeros(3, dtype=np.uint64)
+        _chk(load().svils_get_timed_links(self._h, out.ctypes.data))
+        return out
 
     def device_buffer(self, which):
         p, b, r = C.c_void_p(), C.c_size_t(), C.c_size_t()

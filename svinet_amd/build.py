@@ -47,6 +47,14 @@ def build_svils(force=False):
     return out
 
 
+def build_stamps():
+    """libsvils_stamps.so: the same kernels with wall-clock stamps at phase boundaries (tools/stamps.py)"""
+    out = os.path.join(LIBDIR, "libsvils_stamps.so")
+    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip")]
+    _run([HIPCC] + HIP_FLAGS + ["-DSVILS_STAMPS", "-shared", "-o", out] + srcs)
+    return out
+
+
 def build_host(force=False):
     """C++ host side: libsvinet_host.so (C entry points for Python) and the svinet CLI."""
     srcs = _glob(HOST, (".cc",))
@@ -74,4 +82,7 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all("--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build_stamps()
+    else:
+        build_all("--force" in sys.argv)

@@ -53,6 +53,13 @@ struct svils_handle {
   Params prm;
   hipStream_t stream = nullptr;
   bool have_graph = false, have_state = false;
+  // lane-per-link layout: the link classes on the device describe the sweep about to run (k_s3_lpl
+  // refreshes them for the next sweep); cleared whenever flags / _iter / the window change under them
+  bool cls_valid = false;
+  void *cls_zero = nullptr;      // ltot + shist + scan descriptors, one contiguous block
+  size_t cls_zero_bytes = 0;
+  std::vector<uint32_t> timed_sweeps;   // sweeps_done index of every sweep whose phi launch was bracketed
+  uint64_t sweeps_issued = 0;           // sweeps enqueued so far (== DevCtrl.sweeps_done unless stopped)
   // hipGraph replay of whole sweeps (host launch cost: 8 launches x ~7 us per sweep eager)
   static constexpr uint32_t kGraphSweeps = 8;
   hipGraphExec_t gexec1 = nullptr, gexecN = nullptr;   // 1 sweep / kGraphSweeps sweeps
@@ -133,12 +140,32 @@ struct Timed {
   }
 };
 
-int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceState &d, const Params &prm) {
+// (re)classify the links of the sweep about to run from the flags as they stand
+int classify_now(svils_handle *h, const Geometry &g, const DeviceState &d, const Params &prm) {
+  Timed t(h, SVILS_KERNEL_CLASSIFY);
+  HIPCHK(hipMemsetAsync(h->cls_zero, 0, h->cls_zero_bytes, h->stream));
+  launch_classify(g, d, prm, h->stream);
+  return 0;
+}
+
+// `fused`: the whole sweep is enqueued by this library with no exchange between the phases, so
+// (small K) consumers fold the producers' partial rows themselves and k_s3_lpl classifies the
+// links of the next sweep; otherwise the K-vectors are materialised for the caller's collectives.
+int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceState &d0, const Params &prm,
+              bool fused) {
   hipStream_t s = h->stream;
+  DeviceState d = d0;
+  d.fold = (fused && d.lpl) ? 1 : 0;
+  d.cls_next = (d.lpl && !prm.stoch) ? 1 : 0;
   switch (ph) {
     case SVILS_PHASE_A: {
+      if (d.lpl && (!h->cls_valid || prm.stoch)) {
+        int rc = classify_now(h, g, d, prm);
+        if (rc) return rc;
+        h->cls_valid = true;
+      }
       { Timed t(h, SVILS_KERNEL_PHI); launch_phi(g, d, prm, s); }
-      { Timed t(h, SVILS_KERNEL_REDUCE_SUM); launch_reduce_a(g, d, s); }
+      if (!d.fold) { Timed t(h, SVILS_KERNEL_REDUCE_SUM); launch_reduce_a(g, d, s); }
     } break;
     case SVILS_PHASE_B: {
       Timed t(h, SVILS_KERNEL_FINALIZE);
@@ -146,15 +173,17 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
       if (prm.stoch) launch_carry_flags(g, d, s);
     } break;
     case SVILS_PHASE_C: {
-      { Timed t(h, SVILS_KERNEL_S3); launch_s3(g, d, s); }
-      { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
+      { Timed t(h, SVILS_KERNEL_S3); launch_s3(g, d, prm, s); }
+      if (!d.fold) { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
     } break;
     case SVILS_PHASE_EXPAND: {
       launch_expand(g, d, prm, s);
     } break;
     case SVILS_PHASE_D: {
-      { Timed t(h, SVILS_KERNEL_VALIDATION); launch_validation(g, d, prm, 1, s); }
-      { Timed t(h, SVILS_KERNEL_TAIL); launch_tail(g, d, prm, s); }
+      Timed t(h, SVILS_KERNEL_TAIL);
+      launch_tail(g, d, prm, s);
+      if (d.lpl && !d.cls_next) h->cls_valid = false;
+      ++h->sweeps_issued;
     } break;
     default:
       return fail(SVILS_ERR_ARG, "unknown phase %d", (int)ph);
@@ -166,7 +195,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   return 0;
 }
 
-int run_phase(svils_handle *h, svils_phase ph) { return run_phase(h, ph, h->geo, h->d, h->prm); }
+int run_phase(svils_handle *h, svils_phase ph, bool fused) { return run_phase(h, ph, h->geo, h->d, h->prm, fused); }
 
 void drop_graphs_of(svils_handle *h) {
   if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
@@ -205,7 +234,7 @@ int svils_abi_version(void) { return SVILS_ABI_VERSION; }
 
 const char *svils_kernel_name(int k) {
   static const char *names[SVILS_KERNEL_COUNT] = {"phi", "reduce_sum", "finalize", "s3",
-                                                  "validation", "reduce_s", "tail"};
+                                                  "validation", "reduce_s", "tail", "classify"};
   return (k >= 0 && k < SVILS_KERNEL_COUNT) ? names[k] : "?";
 }
 
@@ -308,6 +337,12 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
     }
   }
   guard(dalloc(h, &h->row_scratch, 10));
+  d.sweep_stats_cap = 1u << 12;
+  guard(dalloc(h, &d.sweep_stats, (size_t)d.sweep_stats_cap * 4));
+  guard(dalloc(h, &d.stamps, 4 * 1024 * 8));
+  guard(dalloc(h, &d.tail_ctl, 4));
+  guard(dalloc(h, &d.tail_part, 128 * 4));
+  d.nb_t = 1;
   if (rc) { svils_destroy(h); return rc; }
   DevCtrl c;
   memset(&c, 0, sizeof c);
@@ -395,13 +430,13 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   d.nb_a = cap((d.nitems_phi + 3) / 4, 4 * rpw_resident_blocks(g, 0, h->cfg.device));
   d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), rpw_resident_blocks(g, 2, h->cfg.device));
   d.nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
-  // lane-per-link layout for small K: wave-items of 64 consecutive CSR entries
+  // lane-per-link layout for small K: wave-items of 64 consecutive entries of a class list
   d.lpl = use_lpl(g.K) ? 1 : 0;
   d.nlinks = nlinks;
   d.ent_begin = rowptr[g.node_begin];
   d.ent_end = rowptr[g.node_end];
-  d.lpl_w0 = d.ent_begin >> 6;
-  d.lpl_nitems = d.ent_end > d.ent_begin ? (uint32_t)(((d.ent_end + 63) >> 6) - d.lpl_w0) : 0;
+  d.lpl_w0 = 0;
+  d.lpl_nitems = (uint32_t)(((d.ent_end - d.ent_begin) + 63) >> 6) + 1u;
   {
     // owned links = those whose first endpoint is in the node block (list is sorted by p)
     uint64_t lb = 0, le = nlinks;
@@ -413,12 +448,26 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   }
   std::vector<uint32_t> erow;
   if (d.lpl) {
-    erow.resize(std::max<uint64_t>(2 * nlinks, 1));
+    if (2 * nlinks >= (1ull << 27))
+      return fail(SVILS_ERR_UNSUPPORTED, "k <= 32 supports up to 2^26 training links (got %llu)", (unsigned long long)nlinks);
+    // classification tiles: 1024 entries, more on large graphs so that there are at most ~2048 tiles
+    // (the scatter pass adds up the counts of all tiles below its own); erow / col padded to whole tiles
+    d.cls_tile = 1024u * (uint32_t)std::max<uint64_t>(1, (2 * nlinks + 1024ull * 2048 - 1) / (1024ull * 2048));
+    d.ent_pad = ((2 * nlinks + d.cls_tile - 1) / d.cls_tile) * d.cls_tile;
+    if (d.ent_pad == 0) d.ent_pad = d.cls_tile;
+    erow.assign(d.ent_pad, 0xffffffffu);
+    col.resize(d.ent_pad, 0xffffffffu);
     for (uint32_t p = 0; p < n; ++p)
       for (uint64_t e = rowptr[p]; e < rowptr[p + 1]; ++e) erow[e] = p;
+    d.cls_tile0 = (uint32_t)(d.ent_begin / d.cls_tile);
+    d.cls_ntiles = d.ent_end > d.ent_begin
+                       ? (uint32_t)((d.ent_end + d.cls_tile - 1) / d.cls_tile) - d.cls_tile0 : 0u;
+    // one block per CU for the three passes: at most SVILS_FOLD_ROWS partial rows per K-vector
     const int nw = lpl_phi_waves(g.K);
-    d.nb_a = cap((d.lpl_nitems + nw - 1) / nw, lpl_phi_resident_blocks(g.K, h->cfg.device));
-    d.nb_c = cap((d.link_end - d.link_begin + 255) / 256, 1024);
+    const uint32_t phi_items = d.lpl_nitems;
+    d.nb_a = cap((phi_items + nw - 1) / nw, std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_phi_resident_blocks(g.K, h->cfg.device)));
+    d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 16 * G - 1) / (16 * G), 256);   // one 16-wave block per CU
+    d.nb_c = cap((d.link_end - d.link_begin + 1023) / 1024, 192);   // + up to 64 count-pass blocks
   }
 
   int rc = 0;
@@ -435,10 +484,30 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   if (d.lpl) {
     guard(dalloc(h, &d.erow, erow.size(), false));
     guard(dalloc(h, &d.links, std::max<uint64_t>(2 * nlinks, 1), false));
-    guard(dalloc(h, &d.slot_f, (size_t)d.lpl_nitems * g.ld));
-    guard(dalloc(h, &d.slot_l, (size_t)d.lpl_nitems * g.ld));
+    guard(dalloc(h, &d.slot_f, 2 * (size_t)d.lpl_nitems * g.ld));
+    guard(dalloc(h, &d.slot_l, 2 * (size_t)d.lpl_nitems * g.ld));
+    guard(dalloc(h, &d.gacc1, (size_t)g.n_alloc * g.ld));
     guard(dalloc(h, &d.member_acc, g.n_alloc));
     if (h->prm.lt_min_deg > 0) guard(dalloc(h, &d.fcnt, (size_t)g.n_alloc * g.ld));
+    const size_t own = std::max<uint64_t>(d.ent_end - d.ent_begin, 1);
+    for (int l = 0; l < 2; ++l) {
+      guard(dalloc(h, &d.cp[l], own, false));
+      guard(dalloc(h, &d.cq[l], own, false));
+    }
+    guard(dalloc(h, &d.scol, own, false));
+    for (int l = 0; l < 3; ++l) guard(dalloc(h, &d.npos[l], (size_t)g.n_alloc + 1));
+    const uint32_t tiles_all = (uint32_t)(d.ent_pad / d.cls_tile);
+    guard(dalloc(h, &d.tcnt, tiles_all));
+    guard(dalloc(h, &d.cls_args, 4));
+    // ltot [2][8] u32 | shist [2][K] u64, cleared together before a stand-alone classification
+    h->cls_zero_bytes = 64 + 2 * (size_t)g.K * sizeof(unsigned long long);
+    unsigned char *cz = nullptr;
+    guard(dalloc(h, &cz, h->cls_zero_bytes));
+    h->cls_zero = cz;
+    if (cz) {
+      d.ltot = reinterpret_cast<uint32_t *>(cz);
+      d.shist = reinterpret_cast<unsigned long long *>(cz + 64);
+    }
   }
   guard(dalloc(h, &d.part_a, (size_t)d.nb_a * g.K));
   guard(dalloc(h, &d.part_links, (size_t)d.nb_a * 3));
@@ -454,6 +523,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     HIPCHK(hipMemcpyAsync(d.items_s3, items_s3.data(), items_s3.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.split_first, split_first.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.split_cnt, split_cnt.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  h->cls_valid = false;
   if (d.lpl) {
     HIPCHK(hipMemcpyAsync(d.erow, erow.data(), erow.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     if (nlinks)
@@ -485,6 +555,7 @@ int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) 
   if (nv) HIPCHK(hipMemcpyAsync(d.vpairs, pairs_y, 3 * nv * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   d.nv = (uint32_t)nv;
+  d.nb_t = tail_blocks(h->geo, d.nv);
   return 0;
 }
 
@@ -508,6 +579,7 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
   launch_lambda_exp(g, d, h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->cls_valid = false;   // the converged flags changed under the link classes
   h->have_state = true;
   return 0;
 }
@@ -534,6 +606,7 @@ int svils_set_control(svils_handle *h, const svils_control *in) {
   c.iter = in->iter; c.annealing = in->annealing; c.write_comm = in->write_comm; c.nh = in->nh;
   c.prev_h = in->prev_h; c.max_h = in->max_h;
   HIPCHK(hipMemcpy(h->d.ctrl, &c, sizeof c, hipMemcpyHostToDevice));
+  h->cls_valid = false;   // _iter decides between the dense and the active-set class
   return 0;
 }
 
@@ -542,7 +615,7 @@ int svils_validation_row(svils_handle *h, double *row10) {
   if (!h->have_state) return fail(SVILS_ERR_ARG, "svils_validation_row: call svils_set_state first");
   if (h->d.nv == 0) return fail(SVILS_ERR_ARG, "svils_validation_row: no validation set");
   HIPCHK(hipSetDevice(h->cfg.device));
-  launch_validation(h->geo, h->d, h->prm, 0, h->stream);
+  launch_validation(h->geo, h->d, h->prm, h->stream);
   launch_row_only(h->geo, h->d, h->prm, h->row_scratch, h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(row10, h->row_scratch, 10 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -554,7 +627,7 @@ int svils_sweep_phase(svils_handle *h, svils_phase phase) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_phase: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep_phase: set graph and state first");
   HIPCHK(hipSetDevice(h->cfg.device));
-  return run_phase(h, phase);
+  return run_phase(h, phase, false);
 }
 
 namespace {
@@ -562,10 +635,11 @@ namespace {
 int eager_sweeps(svils_handle *h, uint32_t nsweeps) {
   for (uint32_t i = 0; i < nsweeps; ++i) {
     int rc;
-    if ((rc = run_phase(h, SVILS_PHASE_A))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_B))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_C))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_D))) return rc;
+    if ((h->tmask >> SVILS_KERNEL_PHI) & 1u) h->timed_sweeps.push_back((uint32_t)h->sweeps_issued);
+    if ((rc = run_phase(h, SVILS_PHASE_A, true))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_B, true))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_C, true))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_D, true))) return rc;
   }
   return 0;
 }
@@ -581,13 +655,26 @@ void drop_graphs(svils_handle *h) {
 hipGraphExec_t capture_sweeps(svils_handle *h, uint32_t nsweeps) {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  const uint64_t issued = h->sweeps_issued;
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
   const int rc = eager_sweeps(h, nsweeps);
   const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  h->sweeps_issued = issued;   // nothing ran
   if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
   if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
   (void)hipGraphDestroy(graph);
   return exec;
+}
+
+// the captured sweeps assume valid link classes on entry (each sweep leaves them valid for the next)
+int ensure_classes(svils_handle *h) {
+  if (!h->d.lpl || h->cls_valid) return 0;
+  DeviceState d = h->d;
+  int rc = classify_now(h, h->geo, d, h->prm);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  h->cls_valid = true;
+  return 0;
 }
 
 }  // namespace
@@ -596,6 +683,8 @@ namespace {
 
 // replay `n` sweeps from the untimed graphs (captured on first use, with event recording off)
 int graph_sweeps(svils_handle *h, uint32_t n) {
+  int rc = ensure_classes(h);
+  if (rc) return rc;
   if (!h->gexec1) {
     const uint32_t saved = h->tmask;
     h->tmask = 0;
@@ -604,6 +693,7 @@ int graph_sweeps(svils_handle *h, uint32_t n) {
     h->tmask = saved;
     if (!h->gexec1 || !h->gexecN) { drop_graphs(h); h->graphs_ok = false; return eager_sweeps(h, n); }
   }
+  h->sweeps_issued += n;
   for (; n >= svils_handle::kGraphSweeps; n -= svils_handle::kGraphSweeps) HIPCHK(hipGraphLaunch(h->gexecN, h->stream));
   for (; n > 0; --n) HIPCHK(hipGraphLaunch(h->gexec1, h->stream));
   return 0;
@@ -616,6 +706,12 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
   if (h->stoch) return fail(SVILS_ERR_ARG, "svils_sweep: the handle is in mini-batch mode, use svils_step");
   HIPCHK(hipSetDevice(h->cfg.device));
+  // likelihood rows go to a ring of rows_cap entries: never enqueue more reports than it holds
+  // between two host polls (svils_get_rows)
+  const uint64_t max_batch = (uint64_t)h->d.rows_cap * h->prm.reportfreq;
+  if (nsweeps > max_batch)
+    return fail(SVILS_ERR_ARG, "svils_sweep: at most %llu sweeps per call (likelihood-row ring of %u entries)",
+                (unsigned long long)max_batch, h->d.rows_cap);
   if (!h->graphs_ok || nsweeps < 4) return eager_sweeps(h, nsweeps);   // short calls are not worth a capture
   if (h->tmask == 0) return graph_sweeps(h, nsweeps);
   // Per-kernel hipEvent timing needs eager launches: events captured as graph nodes cannot be read
@@ -671,9 +767,14 @@ int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
         g0.n_alloc % cfg->shard_block != 0)
       return fail(SVILS_ERR_ARG, "svils_set_stochastic: shard_block does not match the handle's node block");
   }
+  // the running totals s1/s2 of the mini-batch mode start from mphi == 0: full sweeps first would
+  // leave rows it knows nothing about
+  if (!h->stoch && h->sweeps_issued > 0)
+    return fail(SVILS_ERR_ARG, "svils_set_stochastic: enable the mini-batch mode before the first sweep");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
   DeviceState &d = h->d;
+  h->cls_valid = false;
   if (!h->stoch) {
     int rc = 0;
     double *gacc = nullptr;
@@ -721,8 +822,11 @@ int open_step(svils_handle *h) {
   g.node_end = e;
   d.ent_begin = h->h_rowptr[b];
   d.ent_end = h->h_rowptr[e];
-  d.lpl_w0 = d.ent_begin >> 6;
-  d.lpl_nitems = d.ent_end > d.ent_begin ? (uint32_t)(((d.ent_end + 63) >> 6) - d.lpl_w0) : 0;
+  if (d.lpl) {   // classification tiles covering the window's entries (slot capacity stays the handle's)
+    d.cls_tile0 = (uint32_t)(d.ent_begin / d.cls_tile);
+    d.cls_ntiles = d.ent_end > d.ent_begin
+                       ? (uint32_t)((d.ent_end + d.cls_tile - 1) / d.cls_tile) - d.cls_tile0 : 0u;
+  }
   d.link_begin = h->h_linkptr[b];
   d.link_end = h->h_linkptr[e];
   d.item0_phi = h->h_item_phi[b];
@@ -736,8 +840,10 @@ int open_step(svils_handle *h) {
     d.nb_b = fit(((uint64_t)(e - b) + 4 * G - 1) / (4 * G), h->d.nb_b);
     if (d.lpl) {
       const int nw = lpl_phi_waves(g.K);
-      d.nb_a = fit((d.lpl_nitems + nw - 1) / nw, h->d.nb_a);
-      d.nb_c = fit((d.link_end - d.link_begin + 255) / 256, h->d.nb_c);
+      const uint64_t items = ((d.ent_end - d.ent_begin + 63) >> 6) + 1;
+      d.nb_a = fit((items + nw - 1) / nw, h->d.nb_a);
+      d.nb_b = fit(((uint64_t)(e - b) + 16 * G - 1) / (16 * G), h->d.nb_b);
+      d.nb_c = fit((d.link_end - d.link_begin + 1023) / 1024, h->d.nb_c);
     } else {
       d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);
       d.nb_c = fit(((uint64_t)d.nitems_s3 + 3) / 4, h->d.nb_c);
@@ -770,7 +876,13 @@ int svils_step_window(svils_handle *h, uint32_t *begin, uint32_t *end) {
   return 0;
 }
 
-int svils_step_phase(svils_handle *h, svils_phase phase) {
+namespace {
+int step_phase_impl(svils_handle *h, svils_phase phase, bool fused);
+}
+int svils_step_phase(svils_handle *h, svils_phase phase) { return step_phase_impl(h, phase, false); }
+
+namespace {
+int step_phase_impl(svils_handle *h, svils_phase phase, bool fused) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_step_phase: null handle");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_phase: call svils_set_stochastic first");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_step_phase: set graph and state first");
@@ -791,24 +903,28 @@ int svils_step_phase(svils_handle *h, svils_phase phase) {
     }
     return 0;
   }
-  if ((rc = run_phase(h, phase, h->sg, h->sd, h->sp))) return rc;
+  if ((rc = run_phase(h, phase, h->sg, h->sd, h->sp, fused))) return rc;
   if (phase == SVILS_PHASE_D) {
     h->step_open = false;
     ++h->steps_done;
   }
   return 0;
 }
+}  // namespace
 
 int svils_step(svils_handle *h, uint32_t nsteps) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_step: null handle");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step: call svils_set_stochastic first");
   if (h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step: a node-block shard is driven with svils_step_phase");
+  if (nsteps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
+    return fail(SVILS_ERR_ARG, "svils_step: at most %llu steps per call (likelihood-row ring of %u entries)",
+                (unsigned long long)h->d.rows_cap * h->prm.reportfreq, h->d.rows_cap);
   for (uint32_t s = 0; s < nsteps; ++s) {
     int rc;
-    if ((rc = svils_step_phase(h, SVILS_PHASE_A))) return rc;
-    if ((rc = svils_step_phase(h, SVILS_PHASE_B))) return rc;
-    if ((rc = svils_step_phase(h, SVILS_PHASE_C))) return rc;
-    if ((rc = svils_step_phase(h, SVILS_PHASE_D))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_A, true))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_B, true))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_C, true))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_D, true))) return rc;
   }
   return 0;
 }
@@ -900,6 +1016,9 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
       for (uint32_t p = 0; p < g.n; ++p) tl[p] = 2.0 * (double)(h->h_rowptr[p + 1] - h->h_rowptr[p]);
       return 0;
     }
+    case 5:   // profiling stamps (zeros unless the library was built with -DSVILS_STAMPS)
+      HIPCHK(hipMemcpy(out, h->d.stamps, 4 * 1024 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      return 0;
     default:
       return fail(SVILS_ERR_ARG, "svils_get_aux: unknown selector %d", which);
   }
@@ -929,6 +1048,7 @@ int svils_enable_timing(svils_handle *h, uint32_t kernel_mask) {
   int rc = drain_timing(h);
   if (rc) return rc;
   h->tmask = kernel_mask;
+  h->timed_sweeps.clear();
   for (int i = 0; i < SVILS_KERNEL_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   return 0;
 }
@@ -940,6 +1060,37 @@ int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches) {
   int rc = drain_timing(h);
   if (rc) return rc;
   for (int i = 0; i < SVILS_KERNEL_COUNT; ++i) { ms[i] = h->t_ms[i]; launches[i] = h->t_n[i]; }
+  return 0;
+}
+
+int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint64_t *out) {
+  if (!h || (!out && count)) return fail(SVILS_ERR_ARG, "svils_get_sweep_stats: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DevCtrl c;
+  HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if ((uint64_t)first + count > c.sweeps_done)
+    return fail(SVILS_ERR_ARG, "sweeps [%u,%u) not run yet (have %u)", first, first + count, c.sweeps_done);
+  if (c.sweeps_done - first > h->d.sweep_stats_cap) return fail(SVILS_ERR_ARG, "sweep %u is no longer in the ring", first);
+  for (uint32_t i = 0; i < count; ++i) {
+    unsigned long long st[4];
+    const uint32_t slot = (first + i) % h->d.sweep_stats_cap;
+    HIPCHK(hipMemcpy(st, h->d.sweep_stats + (size_t)slot * 4, sizeof st, hipMemcpyDeviceToHost));
+    if (st[3] != first + i) return fail(SVILS_ERR_DEVICE, "sweep statistics ring is inconsistent at sweep %u", first + i);
+    out[3 * (size_t)i] = st[0]; out[3 * (size_t)i + 1] = st[1]; out[3 * (size_t)i + 2] = st[2];
+  }
+  return 0;
+}
+
+int svils_get_timed_links(svils_handle *h, uint64_t *out3) {
+  if (!h || !out3) return fail(SVILS_ERR_ARG, "svils_get_timed_links: null argument");
+  out3[0] = out3[1] = out3[2] = 0;
+  for (uint32_t sw : h->timed_sweeps) {
+    uint64_t one[3];
+    int rc = svils_get_sweep_stats(h, sw, 1, one);
+    if (rc) return rc;
+    out3[0] += one[0]; out3[1] += one[1]; out3[2] += one[2];
+  }
   return 0;
 }
 

@@ -1,0 +1,235 @@
+// svils_cls.h -- per-sweep link classification for the lane-per-link layout (K <= 32), shared by
+// the kernels that carry its two passes as extra workgroups (k_s3_lpl, k_tail) and by the
+// stand-alone k_cls_count / k_cls_scatter.
+//
+// src/linksampling.cc:622-634 evaluated once per sweep for every owned CSR entry, then a stable
+// three-way partition of the entries: 0 full softmax, 1 active-set softmax (_iter > 1000),
+// 2 exactly one endpoint converged (O(1) shortcut).  Two plain data-parallel passes over tiles of
+// `cls_tile` raw entries (a multiple of 1024, chosen so that a graph has at most a few thousand
+// tiles), with no communication between workgroups inside a launch:
+//   count   : classify, count the class-0 / class-1 entries of the tile -> tcnt[tile]
+//   scatter : (next launch) every worker adds up tcnt[] below its tile, classifies again, scans
+//             locally and writes the compacted lists, the per-row prefixes npos[], the totals.
+// A worker is 256 threads (four wavefronts); a 1024-thread block hosts four of them.  Inside a
+// full sweep the two passes ride on the s3 and the tail launch as extra workgroups, on CUs those
+// launches leave idle, so the classification is off the sweep's critical path.
+#pragma once
+#include "svils_devutil.h"
+
+namespace svils {
+
+struct ClsWork {
+  unsigned long long wred[4];
+  uint32_t wsum[4];
+  uint32_t hist[64];
+  uint32_t upper[4];
+};
+
+// class of the CSR entry (p, q): 0 softmax, 1 active-set softmax, 2 exactly one endpoint converged
+__device__ __forceinline__ int classify_entry(const uint32_t *__restrict__ conv, const uint32_t *__restrict__ active,
+                                              uint32_t k10, bool sparse_iter, uint32_t p, uint32_t q, uint32_t *col2) {
+  const uint32_t pc = conv[p], qc = conv[q];
+  if ((pc != 0) != (qc != 0)) {          // :622-631
+    *col2 = (pc ? pc : qc) - 1u;
+    return 2;
+  }
+  *col2 = 0;
+  return (sparse_iter && active[p] < k10 && active[q] < k10) ? 1 : 0;   // :634
+}
+
+// next = false: classes of the sweep about to run (flags conv[parity], _iter);
+// next = true : classes of the FOLLOWING sweep, computed after prune() of the current one
+//               (flags conv[parity ^ 1], _iter + 1), written to the other ltot/shist half.
+// Role block `rb` of `nrb`, NWORK workers per block.  Worker 0 also records the arguments for the
+// scatter pass, which must not read the control block: it shares its launch with the kernel that
+// advances it.
+template <int NWORK>
+__device__ __forceinline__ void cls_count_tiles(const Geometry &geo, const DeviceState &d, const Params &prm,
+                                                ClsWork (&shw)[NWORK], uint32_t rb, uint32_t nrb, bool next) {
+  const DevCtrl *ctrl = d.ctrl;
+  const uint32_t conv_idx = next ? (ctrl->parity ^ 1u) : ctrl->parity;
+  const bool sparse_iter = ((long long)ctrl->iter + (next ? 1 : 0)) > (long long)prm.sparse_after;
+  if (rb == 0 && threadIdx.x == 0) {
+    d.cls_args[0] = conv_idx;
+    d.cls_args[1] = sparse_iter ? 1u : 0u;
+    d.cls_args[2] = next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par;
+  }
+  uint32_t *ltot = d.ltot + (next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par) * 8u;
+  unsigned long long *shist = d.shist + (size_t)(next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par) * geo.K;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
+  const uint32_t wk = threadIdx.x >> 8, tid = threadIdx.x & 255u;
+  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
+  ClsWork &sh = shw[wk];
+  const uint32_t rw = rb * NWORK + wk, nrw = nrb * NWORK;
+  const uint64_t eb = d.ent_begin, ee = d.ent_end;
+  const uint32_t subs = d.cls_tile >> 10;
+  const uint32_t iters = (d.cls_ntiles + nrw - 1) / nrw;
+  if (tid < 64) sh.hist[tid] = 0;
+  if (tid < 4) sh.upper[tid] = 0;
+  uint32_t up[3] = {0, 0, 0};
+  __syncthreads();
+  for (uint32_t it = 0; it < iters; ++it) {
+    const uint32_t tile = rw + it * nrw;
+    const bool act = tile < d.cls_ntiles;
+    unsigned long long n01 = 0;   // class-0 count << 32 | class-1 count
+    if (act) {
+      for (uint32_t sub = 0; sub < subs; ++sub) {
+        const uint64_t e0 = (uint64_t)(d.cls_tile0 + tile) * d.cls_tile + 1024u * sub + 4u * tid;
+        const uint4 pr = *reinterpret_cast<const uint4 *>(d.erow + e0);
+        const uint4 qr = *reinterpret_cast<const uint4 *>(d.col + e0);
+        const uint32_t pp[4] = {pr.x, pr.y, pr.z, pr.w}, qq[4] = {qr.x, qr.y, qr.z, qr.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t e = e0 + j;
+          if (e >= eb && e < ee) {
+            uint32_t c2;
+            const int c = classify_entry(conv, d.active_cnt, geo.k10, sparse_iter, pp[j], qq[j], &c2);
+            n01 += (c == 0 ? (1ull << 32) : 0ull) + (c == 1 ? 1ull : 0ull);
+            if (qq[j] > pp[j]) up[c]++;
+            if (c == 2) atomicAdd(&sh.hist[c2 & 63u], 1u);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n01 += (unsigned long long)__shfl_xor((long long)n01, o, 64);
+    __syncthreads();
+    if (lane == 0) sh.wred[wv] = n01;
+    __syncthreads();
+    if (act && tid == 0) d.tcnt[tile] = sh.wred[0] + sh.wred[1] + sh.wred[2] + sh.wred[3];
+  }
+  // this block's statistics row: shortcut entries per community column (-> `sum`), then the links
+  // (q > p) per class (-> the c, d counters of src/linksampling.cc:726), over all its tiles
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uint32_t u = up[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u += (uint32_t)__shfl_xor((int)u, o, 64);
+    if (lane == 0 && u) atomicAdd(&sh.upper[c], u);
+  }
+  __syncthreads();
+  // one integer atomic per block and word (the words were cleared by k_tail two sweeps ago, or by the
+  // host before a stand-alone classification); nobody waits for them inside this launch
+  if (threadIdx.x < 64 + 3) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < NWORK; ++w) t += threadIdx.x < 64 ? shw[w].hist[threadIdx.x] : shw[w].upper[threadIdx.x - 64];
+    if (t) {
+      if (threadIdx.x < 64) { if (threadIdx.x < geo.K) atomicAdd(&shist[threadIdx.x], (unsigned long long)t); }
+      else atomicAdd(&ltot[3 + (threadIdx.x - 64)], t);
+    }
+  }
+}
+
+template <int NWORK>
+__device__ __forceinline__ void cls_scatter_tiles(const Geometry &geo, const DeviceState &d, ClsWork (&shw)[NWORK],
+                                                  uint32_t rb, uint32_t nrb) {
+  const uint32_t conv_idx = d.cls_args[0];
+  const bool sparse_iter = d.cls_args[1] != 0u;
+  const uint32_t par = d.cls_args[2];
+  const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
+  uint32_t *ltot = d.ltot + par * 8u;
+  unsigned long long *shist = d.shist + (size_t)par * geo.K;
+  const uint32_t wk = threadIdx.x >> 8, tid = threadIdx.x & 255u;
+  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
+  ClsWork &sh = shw[wk];
+  const uint32_t rw = rb * NWORK + wk, nrw = nrb * NWORK;
+  const uint64_t eb = d.ent_begin, ee = d.ent_end;
+  if (d.cls_ntiles == 0) {
+    // no owned entry: every owned row is empty in every list, every total is zero
+    if (rb == 0) {
+      for (uint32_t x = geo.node_begin + threadIdx.x; x <= geo.node_end; x += blockDim.x) {
+        d.npos[0][x] = 0; d.npos[1][x] = 0; d.npos[2][x] = 0;
+      }
+      if (threadIdx.x < 3) ltot[threadIdx.x] = 0;
+    }
+    return;
+  }
+  const uint32_t subs = d.cls_tile >> 10;
+  const uint32_t iters = (d.cls_ntiles + nrw - 1) / nrw;
+  for (uint32_t it = 0; it < iters; ++it) {
+    const uint32_t tile = rw + it * nrw;
+    const bool act = tile < d.cls_ntiles;
+    // class-0 / class-1 entries in the tiles below this one
+    unsigned long long pre = 0ull;
+    if (act)
+      for (uint32_t i = tid; i < tile; i += 256u) pre += d.tcnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += (unsigned long long)__shfl_xor((long long)pre, o, 64);
+    __syncthreads();
+    if (lane == 0) sh.wred[wv] = pre;
+    __syncthreads();
+    pre = sh.wred[0] + sh.wred[1] + sh.wred[2] + sh.wred[3];
+    uint32_t run0 = (uint32_t)(pre >> 32), run1 = (uint32_t)pre;   // running bases over the sub-tiles
+    for (uint32_t sub = 0; sub < subs; ++sub) {
+      const uint64_t e0 = (uint64_t)(d.cls_tile0 + tile) * d.cls_tile + 1024u * sub + 4u * tid;
+      uint32_t pp[4] = {0, 0, 0, 0}, qq[4] = {0, 0, 0, 0}, pprev = 0xffffffffu;
+      int cls[4] = {3, 3, 3, 3};
+      uint32_t c2[4] = {0, 0, 0, 0};
+      uint32_t n01 = 0;   // class-0 | class-1 << 16 of this thread's four entries
+      if (act) {
+        const uint4 pr = *reinterpret_cast<const uint4 *>(d.erow + e0);
+        const uint4 qr = *reinterpret_cast<const uint4 *>(d.col + e0);
+        pp[0] = pr.x; pp[1] = pr.y; pp[2] = pr.z; pp[3] = pr.w;
+        qq[0] = qr.x; qq[1] = qr.y; qq[2] = qr.z; qq[3] = qr.w;
+        if (e0 > 0) pprev = d.erow[e0 - 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t e = e0 + j;
+          if (e >= eb && e < ee) {
+            cls[j] = classify_entry(conv, d.active_cnt, geo.k10, sparse_iter, pp[j], qq[j], &c2[j]);
+            n01 += (cls[j] == 0 ? 1u : 0u) + (cls[j] == 1 ? 0x10000u : 0u);
+          }
+        }
+      }
+      // exclusive scan of n01 over the worker
+      uint32_t inc = n01;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      __syncthreads();
+      if (lane == 63) sh.wsum[wv] = inc;
+      __syncthreads();
+      uint32_t woff = 0, ttot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t t = sh.wsum[w];
+        if (w < wv) woff += t;
+        ttot += t;
+      }
+      const uint32_t excl = woff + inc - n01;
+      uint32_t pos0 = run0 + (excl & 0xffffu), pos1 = run1 + (excl >> 16);
+      run0 += ttot & 0xffffu;
+      run1 += ttot >> 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t e = e0 + j;
+        if (cls[j] != 3) {
+          const uint32_t p = pp[j], q = qq[j];
+          const uint32_t pos2 = (uint32_t)(e - eb) - pos0 - pos1;
+          // first entry of a row: class prefixes of this node and of the empty rows just before it
+          const uint32_t prev = j == 0 ? pprev : pp[j - 1];
+          if (e == eb || p != prev) {
+            for (uint32_t x = (e == eb) ? geo.node_begin : prev + 1u; x <= p; ++x) {
+              d.npos[0][x] = pos0; d.npos[1][x] = pos1; d.npos[2][x] = pos2;
+            }
+          }
+          uint32_t a0 = pos0, a1 = pos1, a2 = pos2;
+          if (cls[j] == 0) { d.cp[0][pos0] = p; d.cq[0][pos0] = q; a0 = ++pos0; }
+          else if (cls[j] == 1) { d.cp[1][pos1] = p; d.cq[1][pos1] = q; a1 = ++pos1; }
+          else { d.scol[pos2] = (uint16_t)c2[j]; a2 = pos2 + 1u; }
+          if (e == ee - 1) {   // last owned entry: totals, and the empty rows after it
+            ltot[0] = a0; ltot[1] = a1; ltot[2] = a2;
+            for (uint32_t x = p + 1u; x <= geo.node_end; ++x) {
+              d.npos[0][x] = a0; d.npos[1][x] = a1; d.npos[2][x] = a2;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace svils

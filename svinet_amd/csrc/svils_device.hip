@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "svils_cls.h"
 #include "svils_devutil.h"
 
 namespace svils {
@@ -334,43 +335,8 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
     const uint32_t p = geo.node_begin + i;
     const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
     double acc[V];
-    const int32_t sf = d.lpl ? -1 : d.split_first[p];
-    if (d.lpl) {
-      // pieces left by k_phi_lpl: interior run -> gamma[p]; run starting at lane 0 of a
-      // wave-item -> slot_f[item]; run ending at lane 63 -> slot_l[item]; added in item order
-      const uint64_t r0 = d.rowptr[p], r1 = d.rowptr[p + 1];
-      double s = 0.0;
-      if (r1 > r0 && (uint32_t)lw < ld) {
-        const uint64_t w0 = r0 >> 6, w1 = (r1 - 1) >> 6;
-        if (w0 == w1) {
-          const double *src = ((r0 & 63) == 0) ? d.slot_f + (size_t)(w0 - d.lpl_w0) * ld
-                              : (((r1 - 1) & 63) == 63) ? d.slot_l + (size_t)(w0 - d.lpl_w0) * ld
-                                                        : d.gacc + (size_t)p * ld;
-          s = src[lw];
-        } else {
-          for (uint64_t w = w0; w <= w1; ++w) {
-            const double *src = (w == w0 && (r0 & 63) != 0) ? d.slot_l : d.slot_f;
-            s += src[(size_t)(w - d.lpl_w0) * ld + lw];
-          }
-        }
-      }
-#pragma unroll
-      for (int v = 0; v < V; ++v) acc[v] = (v == 0) ? s : 0.0;
-      if (write_comm) {
-        unsigned long long b;
-        if (d.fcnt) {
-          uint32_t c = 0;
-          if (kval[0]) { c = d.fcnt[(size_t)p * ld + kidx[0]]; d.fcnt[(size_t)p * ld + kidx[0]] = 0; }
-          b = (__ballot(kval[0] && c > prm.lt_min_deg) >> (g * W)) & (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull));
-        } else {
-          b = d.member_acc[p];
-        }
-        if (lw == 0) {
-          d.member[(size_t)p * geo.kw] = b;
-          if (!d.fcnt) d.member_acc[p] = 0ull;
-        }
-      }
-    } else if (sf < 0) {
+    const int32_t sf = d.split_first[p];
+    if (sf < 0) {
       load_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
     } else {
 #pragma unroll
@@ -605,8 +571,8 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
 // Returns the running s1, s2 through s1r/s2r (what k_tail stores back in mini-batch mode).
 template <bool STOCH>
 __device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Params &prm, uint32_t K, uint32_t k,
-                                                double &l0, double &l1, double &s1r, double &s2r) {
-  double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = d.kvec_c[2 * K + k];
+                                                const double *s3v, double &l0, double &l1, double &s1r, double &s2r) {
+  double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = s3v[k];
   if constexpr (!STOCH) {
     l0 = prm.eta0 + d.kvec_a[k];
     l1 = prm.eta1 + (s1 * s1 - s2 - s3);
@@ -624,18 +590,38 @@ __device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Para
 }
 
 // ================================================== validation likelihood (A10)
-// edge_likelihood (src/linksampling.hh:258-292), one group per held-out pair.
+// edge_likelihood (src/linksampling.hh:258-292) of one held-out pair, by a group of W lanes.
 // The non-link K^2 double loop collapses exactly:
 //   sum_{z,z'} pi_p[z] pi_q[z'] (1 - [z==z'] beta_z - [z!=z'] eps), 1 - eps == 1.0 in double
 //   = (sum pi_p)(sum pi_q) - sum_z pi_p[z] pi_q[z] beta_z .
-template <int W, int V, bool STOCH>
-__global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d, Params prm,
-                                                    int in_loop) {
-  const DevCtrl *ctrl = d.ctrl;
-  if (in_loop) {
-    if (ctrl->stopped) return;
-    if (ctrl->iter % prm.reportfreq != 0) return;
+template <int W, int V>
+__device__ __forceinline__ double pair_loglik(const DeviceState &d, uint32_t ld, int lw, uint32_t i,
+                                              const double (&beta)[V], uint32_t *y_out) {
+  const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1];
+  const uint32_t y = d.vpairs[3 * (size_t)i + 2];
+  double gp[V], gq[V];
+  load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gp);
+  load_row<W, V>(d.gamma + (size_t)q * ld, lw, ld, gq);
+  double sp = 0.0, sq = 0.0, dot = 0.0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    sp += gp[v];
+    sq += gq[v];
+    dot += gp[v] * gq[v] * beta[v];
   }
+  sp = group_sum<W>(sp);
+  sq = group_sum<W>(sq);
+  dot = group_sum<W>(dot);
+  const double pq = dot / (sp * sq);
+  double s = y ? pq : 1.0 - pq;
+  if (s < 1e-30) s = 1e-30;
+  *y_out = y;
+  return log(s);
+}
+
+// the constructor's call (src/linksampling.cc:149-150): lambda as it stands, results to uval[]
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d) {
   constexpr int G = 64 / W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / W, lw = lane % W;
@@ -646,37 +632,14 @@ __global__ __launch_bounds__(256) void k_validation(Geometry geo, DeviceState d,
     const int k = kmap<W, V>(lw, v);
     beta[v] = 0.0;
     if ((uint32_t)k < K) {
-      double l0, l1;
-      if (in_loop) {  // lambda of this sweep, same expression as k_tail
-        double s1r, s2r;
-        lambda_of_sweep<STOCH>(d, prm, K, (uint32_t)k, l0, l1, s1r, s2r);
-      } else {
-        l0 = d.lambda[2 * k];
-        l1 = d.lambda[2 * k + 1];
-      }
+      const double l0 = d.lambda[2 * k], l1 = d.lambda[2 * k + 1];
       beta[v] = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
     }
   }
   for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < d.nv; i += gridDim.x * 4 * G) {
-    const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1];
-    const uint32_t y = d.vpairs[3 * (size_t)i + 2];
-    double gp[V], gq[V];
-    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gp);
-    load_row<W, V>(d.gamma + (size_t)q * ld, lw, ld, gq);
-    double sp = 0.0, sq = 0.0, dot = 0.0;
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      sp += gp[v];
-      sq += gq[v];
-      dot += gp[v] * gq[v] * beta[v];
-    }
-    sp = group_sum<W>(sp);
-    sq = group_sum<W>(sq);
-    dot = group_sum<W>(dot);
-    const double pq = dot / (sp * sq);
-    double s = y ? pq : 1.0 - pq;
-    if (s < 1e-30) s = 1e-30;
-    if (lw == 0) d.uval[i] = log(s);
+    uint32_t y;
+    const double u = pair_loglik<W, V>(d, ld, lw, i, beta, &y);
+    if (lw == 0) d.uval[i] = u;
   }
 }
 
@@ -726,43 +689,162 @@ __global__ __launch_bounds__(256) void k_carry_flags(Geometry geo, DeviceState d
 }
 
 // =============================================================== tail (A8/A10/A11)
-// lambda update + set_dir_exp(lambda) (src/linksampling.cc:748-759), the
-// likelihood row, stop rule and annealing switch of validation_likelihood
-// (:994-1049), write_comm for the next sweep (:768-774) and _iter++ (:787).
-template <bool STOCH>
+// One launch for everything after the s3 pass: lambda of this sweep and the held-out likelihood
+// of validation_likelihood() (src/linksampling.cc:966-1002) by every block over its share of the
+// pairs; the LAST block to arrive (ticket + agent-scope atomics, no L2 write-back) then adds the
+// blocks' partial sums in block order and runs the serial part: lambda update + set_dir_exp(lambda)
+// (:748-759), the likelihood row, stop rule and annealing switch (:994-1049), write_comm for the
+// next sweep (:768-774) and _iter++ (:787).
+template <int W, int V, bool STOCH>
 __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Params prm) {
-  // the control block is read once, updated in registers by thread 0 and written back once
+  if (blockIdx.x >= d.nb_t) {
+    // extra workgroups (K <= 32, full sweeps): scatter pass of the NEXT sweep's link classes.  They
+    // take everything from cls_args, never from the control block this launch is about to advance.
+    __shared__ ClsWork csh[1];
+    STAMP(3, 0);
+    if (!d.ctrl->stopped) cls_scatter_tiles<1>(geo, d, csh, blockIdx.x - d.nb_t, gridDim.x - d.nb_t);
+    STAMP(3, 7);
+    return;
+  }
+  STAMP(3, 0);
   DevCtrl c = *d.ctrl;
   if (c.stopped) return;
-  // one combined block reduction: {szeros, sones} doubles and {kzeros, dense, sparse, shortcut} counts
+  STAMP(3, 1);
+  constexpr int G = 64 / W;
+  constexpr int NPRE = V <= 2 ? 2 : 1;   // held-out pairs whose rows are fetched before lambda is known
   __shared__ double red[2][256];
   __shared__ unsigned long long cred[4][256];
   __shared__ double2 logtab[128];
-  load_logtab(logtab, d.logtab);
-  __syncthreads();
-  const uint32_t K = geo.K;
+  __shared__ double s3l[32];
+  __shared__ double ftmp[8 * 32];
+  __shared__ uint32_t lastflag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t iter = c.iter;
   const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
-  double sz = 0.0, so = 0.0;
-  unsigned long long kz = 0, t0 = 0, t1 = 0, t2 = 0;
-  if (do_val) {
-    // contiguous slices per thread, then a fixed-order tree
-    const uint32_t per = (d.nv + blockDim.x - 1) / blockDim.x;
-    const uint32_t b = threadIdx.x * per, e = min(d.nv, b + per);
-    for (uint32_t i = b; i < e; ++i) {
-      const double u = d.uval[i];
-      if (d.vpairs[3 * (size_t)i + 2]) so += u; else { sz += u; kz++; }
+  // Every dependent global access of this launch costs a cold miss, so the independent chains are
+  // started together, the one with a second level first: (1) the held-out pairs, whose gamma rows
+  // (level 2) do not need lambda -- their products wait in registers; (2) the log table the last
+  // block will need; (3) the s3 pass's partial rows to fold.
+  const uint32_t i0 = (blockIdx.x * 4 + wave) * G + g, istride = d.nb_t * 4 * G;
+  uint32_t pp[NPRE], qq[NPRE], yy[NPRE];
+#pragma unroll
+  for (int t = 0; t < NPRE; ++t) {
+    const uint32_t i = i0 + t * istride;
+    pp[t] = 0; qq[t] = 0; yy[t] = 0;
+    if (do_val && i < d.nv) {
+      pp[t] = d.vpairs[3 * (size_t)i]; qq[t] = d.vpairs[3 * (size_t)i + 1]; yy[t] = d.vpairs[3 * (size_t)i + 2];
     }
   }
-  for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {   // link statistics of the phi pass
-    t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+  double2 ltv = make_double2(0.0, 0.0);
+  if (threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
+  FoldRows<32, 256> fold;
+  if (d.fold) fold.issue(d.part_c, d.nb_c, K);
+  double prod[NPRE][V], spq[NPRE];
+#pragma unroll
+  for (int t = 0; t < NPRE; ++t) {
+    const uint32_t i = i0 + t * istride;
+    spq[t] = 1.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) prod[t][v] = 0.0;
+    if (do_val && i < d.nv) {
+      double gp[V], gq[V];
+      load_row<W, V>(d.gamma + (size_t)pp[t] * ld, lw, ld, gp);
+      load_row<W, V>(d.gamma + (size_t)qq[t] * ld, lw, ld, gq);
+      double sp = 0.0, sq = 0.0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { sp += gp[v]; sq += gq[v]; prod[t][v] = gp[v] * gq[v]; }
+      spq[t] = group_sum<W>(sp) * group_sum<W>(sq);
+    }
   }
-  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so;
-  cred[0][threadIdx.x] = kz; cred[1][threadIdx.x] = t0; cred[2][threadIdx.x] = t1; cred[3][threadIdx.x] = t2;
+  if (threadIdx.x < 128) logtab[threadIdx.x] = ltv;
+  // s3 of this sweep: folded from the s3 pass's per-block partial rows, or the reduced vector
+  const double *s3v = d.kvec_c + 2 * (size_t)K;
+  if (d.fold) {
+    fold.finish(ftmp, s3l);
+    s3v = s3l;
+  }
+  STAMP(3, 2);
+  double sz = 0.0, so = 0.0;
+  unsigned long long kz = 0;
+  if (do_val) {
+    double beta[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int k = kmap<W, V>(lw, v);
+      beta[v] = 0.0;
+      if ((uint32_t)k < K) {
+        double l0, l1, s1r, s2r;
+        lambda_of_sweep<STOCH>(d, prm, K, (uint32_t)k, s3v, l0, l1, s1r, s2r);
+        beta[v] = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {
+      const uint32_t i = i0 + t * istride;
+      double dot = 0.0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) dot += prod[t][v] * beta[v];
+      dot = group_sum<W>(dot);
+      if (i < d.nv) {
+        const double pq = dot / spq[t];
+        double sv = yy[t] ? pq : 1.0 - pq;
+        if (sv < 1e-30) sv = 1e-30;
+        const double u = log(sv);
+        if (lw == 0) { if (yy[t]) so += u; else { sz += u; kz++; } }
+      }
+    }
+    for (uint32_t i = i0 + NPRE * istride; i < d.nv; i += istride) {
+      uint32_t y;
+      const double u = pair_loglik<W, V>(d, ld, lw, i, beta, &y);
+      if (lw == 0) { if (y) so += u; else { sz += u; kz++; } }
+    }
+  }
+  STAMP(3, 3);
+  // block partial in thread order (fixed tree), published for the last block
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = kz;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      cred[0][threadIdx.x] += cred[0][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    st_agent(d.tail_part + (size_t)blockIdx.x * 4, red[0][0]);
+    st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 1, red[1][0]);
+    st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 2, (double)cred[0][0]);
+  }
+  STAMP(3, 4);
+  if (!last_block_arrives(d.tail_ctl, d.nb_t, &lastflag)) return;
+  STAMP(3, 5);
+
+  // ---- last block only ----
+  // the blocks' partial sums: one thread per block, then a fixed-order tree (nb_t <= 128)
+  sz = 0.0; so = 0.0;
+  double kzd = 0.0;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (threadIdx.x < d.nb_t) {
+    sz = ld_agent(d.tail_part + (size_t)threadIdx.x * 4);
+    so = ld_agent(d.tail_part + (size_t)threadIdx.x * 4 + 1);
+    kzd = ld_agent(d.tail_part + (size_t)threadIdx.x * 4 + 2);
+  }
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = (unsigned long long)kzd;
+  const uint32_t cpar0 = c.cls_par;
+  uint32_t *ltot = d.lpl ? d.ltot + cpar0 * 8u : nullptr;
+  if (!d.lpl)
+    for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {   // link statistics of the phi pass
+      t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+    }
+  cred[1][threadIdx.x] = t0; cred[2][threadIdx.x] = t1; cred[3][threadIdx.x] = t2;
+  __syncthreads();
   // lambda update + set_dir_exp(lambda), src/linksampling.cc:748-759
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
     double l0, l1, s1r, s2r;
-    lambda_of_sweep<STOCH>(d, prm, K, k, l0, l1, s1r, s2r);
+    lambda_of_sweep<STOCH>(d, prm, K, k, s3v, l0, l1, s1r, s2r);
     d.lambda[2 * k] = l0;
     d.lambda[2 * k + 1] = l1;
     if constexpr (STOCH) { d.s12run[k] = s1r; d.s12run[K + k] = s2r; }
@@ -770,26 +852,31 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
     d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
   }
-  __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
       red[0][threadIdx.x] += red[0][threadIdx.x + o];
       red[1][threadIdx.x] += red[1][threadIdx.x + o];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) cred[c][threadIdx.x] += cred[c][threadIdx.x + o];
+      for (int cc = 0; cc < 4; ++cc) cred[cc][threadIdx.x] += cred[cc][threadIdx.x + o];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    sz = red[0][0]; so = red[1][0]; kzd = (double)cred[0][0];
     c.parity ^= 1u;  // prune()'s flags become current
-    c.links_dense = cred[1][0]; c.links_sparse = cred[2][0]; c.links_shortcut = cred[3][0];
+    if (d.lpl) { c.links_dense = ltot[3]; c.links_sparse = ltot[4]; c.links_shortcut = ltot[5]; }
+    else { c.links_dense = cred[1][0]; c.links_sparse = cred[2][0]; c.links_shortcut = cred[3][0]; }
+    if (d.sweep_stats) {
+      unsigned long long *st = d.sweep_stats + (size_t)(c.sweeps_done % d.sweep_stats_cap) * 4;
+      st[0] = c.links_dense; st[1] = c.links_sparse; st[2] = c.links_shortcut; st[3] = c.sweeps_done;
+    }
     c.sweeps_done++;
     // (mini-batch steps tag on every step: a window is only visited once per pass over the nodes)
     c.write_comm = (STOCH || iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
     bool exit_now = false;
     if (do_val) {
-      const double szeros = red[0][0], sones = red[1][0];
-      const uint32_t kzeros = (uint32_t)cred[0][0], kones = d.nv - kzeros;
+      const double szeros = sz, sones = so;
+      const uint32_t kzeros = (uint32_t)kzd, kones = d.nv - kzeros;
       const double mean0 = szeros / kzeros, mean1 = sones / kones;
       const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
       double *row = d.rows + (size_t)(c.rows % d.rows_cap) * 10;
@@ -817,7 +904,16 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     }
     if (exit_now) c.stopped = 1;  // do_on_stop(); exit(0): _iter is not advanced
     else c.iter = iter + 1;
+    c.cls_par ^= 1u;   // the classes k_s3_lpl computed for the next sweep become current
     *d.ctrl = c;
+  }
+  STAMP(3, 6);
+  // the link counts / shortcut histogram of the finished sweep are consumed: clear them for the
+  // classification two sweeps ahead
+  __syncthreads();
+  if (d.lpl) {
+    if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) d.shist[(size_t)cpar0 * K + k] = 0ull;
   }
 }
 
@@ -908,6 +1004,17 @@ bool pick_layout(uint32_t K, int *W, int *V) {
     else { CALL(64, 32); }                                                     \
   } while (0)
 
+// K > 32: one row per wavefront, W == 64
+#define SVILS_DISPATCH_V(geo, CALL)                                            \
+  do {                                                                         \
+    if ((geo).V == 1) { CALL(64, 1); }                                         \
+    else if ((geo).V == 2) { CALL(64, 2); }                                    \
+    else if ((geo).V == 4) { CALL(64, 4); }                                    \
+    else if ((geo).V == 8) { CALL(64, 8); }                                    \
+    else if ((geo).V == 16) { CALL(64, 16); }                                  \
+    else { CALL(64, 32); }                                                     \
+  } while (0)
+
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   if (d.lpl) { launch_phi_lpl(g, d, p, s); return; }
   // link_thresh < 1/2 needs the argmax form of the tagging rule (k_phi<V, true>)
@@ -944,7 +1051,7 @@ uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
     }
   } else if (which == 2) {
 #define CALL(W_, V_) OCC((k_finalize<W_, V_, false>))
-    SVILS_DISPATCH(g, CALL);
+    SVILS_DISPATCH_V(g, CALL);
 #undef CALL
   } else {
     switch (g.V) {
@@ -967,16 +1074,17 @@ void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s) {
   hipLaunchKernelGGL(k_colreduce, dim3(nblk0), dim3(256), 0, s, j0, j0, nblk0, d.ctrl);
 }
 void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  if (d.lpl) { launch_finalize_lpl(g, d, p, s); return; }
 #define CALL(W_, V_)                                                                                     \
   do {                                                                                                   \
     if (p.stoch) hipLaunchKernelGGL((k_finalize<W_, V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p); \
     else hipLaunchKernelGGL((k_finalize<W_, V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p);        \
   } while (0)
-  SVILS_DISPATCH(g, CALL);
+  SVILS_DISPATCH_V(g, CALL);
 #undef CALL
 }
-void launch_s3(const Geometry &g, const DeviceState &d, hipStream_t s) {
-  if (d.lpl) { launch_s3_lpl(g, d, s); return; }
+void launch_s3(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  if (d.lpl) { launch_s3_lpl(g, d, p, s); return; }
   switch (g.V) {   // K > 32 => W == 64
     case 1: hipLaunchKernelGGL((k_s3<64, 1>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
     case 2: hipLaunchKernelGGL((k_s3<64, 2>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
@@ -992,23 +1100,32 @@ void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const uint32_t nblk0 = (2 * g.K + 3) / 4, nblk1 = (g.K + 3) / 4;
   hipLaunchKernelGGL(k_colreduce, dim3(nblk0 + nblk1), dim3(256), 0, s, j0, j1, nblk0, d.ctrl);
 }
-void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
-                       hipStream_t s) {
+void launch_validation(const Geometry &g, const DeviceState &d, const Params &, hipStream_t s) {
   if (d.nv == 0) return;
   const int G = 64 / g.W;
   uint32_t nb = (d.nv + 4 * G - 1) / (4 * G);
   if (nb > 2048) nb = 2048;
-#define CALL(W_, V_) \
-  do {                                                                                                       \
-    if (p.stoch) hipLaunchKernelGGL((k_validation<W_, V_, true>), dim3(nb), dim3(256), 0, s, g, d, p, in_loop); \
-    else hipLaunchKernelGGL((k_validation<W_, V_, false>), dim3(nb), dim3(256), 0, s, g, d, p, in_loop);        \
-  } while (0)
+#define CALL(W_, V_) hipLaunchKernelGGL((k_validation<W_, V_>), dim3(nb), dim3(256), 0, s, g, d)
   SVILS_DISPATCH(g, CALL);
 #undef CALL
 }
+// blocks of k_tail: enough groups for one or two passes over the held-out pairs, few enough that
+// the last block's in-order sum of the block partials stays short
+uint32_t tail_blocks(const Geometry &g, uint32_t nv) {
+  const uint32_t per_block = 4u * (uint32_t)(64 / g.W);
+  uint32_t nb = (nv + 2 * per_block - 1) / (2 * per_block);
+  if (nb < 1) nb = 1;
+  if (nb > 128) nb = 128;
+  return nb;
+}
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-  if (p.stoch) hipLaunchKernelGGL(k_tail<true>, dim3(1), dim3(256), 0, s, g, d, p);
-  else hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(256), 0, s, g, d, p);
+#define CALL(W_, V_)                                                                                   \
+  do {                                                                                                 \
+    if (p.stoch) hipLaunchKernelGGL((k_tail<W_, V_, true>), dim3(d.nb_t), dim3(256), 0, s, g, d, p);   \
+    else hipLaunchKernelGGL((k_tail<W_, V_, false>), dim3(d.nb_t + lpl_scatter_blocks(d)), dim3(256), 0, s, g, d, p); \
+  } while (0)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
 }
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s) {
   if (g.node_end - g.node_begin >= g.n) return;

@@ -9,6 +9,19 @@ namespace svils {
 
 #define NEG_INF (-__builtin_huge_val())
 
+// ------------------------------------------------------------ profiling stamps
+// STAMP(kernel, slot): thread 0 of the block records the 100 MHz wall clock.  Compiled in only with
+// -DSVILS_STAMPS (tools/stamps.py); the product build carries none of it.
+#ifdef SVILS_STAMPS
+#define STAMP(KERNEL, SLOT)                                                                         \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x < 1024)                                                      \
+      d.stamps[((size_t)(KERNEL) * 1024 + blockIdx.x) * 8 + (SLOT)] = wall_clock64();               \
+  } while (0)
+#else
+#define STAMP(KERNEL, SLOT) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- lane maps
 template <int W, int V>
 __device__ __forceinline__ int kmap(int lw, int v) {
@@ -223,6 +236,88 @@ __device__ __forceinline__ double digamma(double x, const double2 *tab) {
                            xi2 * (1.0 / 240.0 -
                                   xi2 * (1.0 / 132.0 - xi2 * (691.0 / 32760.0 - xi2 * (1.0 / 12.0)))))));
   return log_tab(y, tab) - 0.5 * xi - ser - shift;
+}
+
+// ------------------------------------------------ cross-workgroup hand-off inside one launch
+// 8-byte agent-scope relaxed atomics on both sides (global_store/global_load ... sc1): the
+// stores are written through, the loads bypass the CU's L1; no L2 write-back or invalidate is
+// needed (MI355X_MICROARCH.md, "Valid forms": {8-B agent atomics both sides}).
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Arrival ticket: every thread of the block has issued its st_agent() stores; returns true in
+// exactly one block of the grid -- the last one to arrive -- after which that block may ld_agent()
+// what the others published.  The counter is reset by the last arriver (the launch is over for
+// everybody else), so the same word serves every launch.
+__device__ __forceinline__ bool last_block_arrives(uint32_t *ticket, uint32_t nblocks, uint32_t *lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t last = (t == nblocks - 1u) ? 1u : 0u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_flag = last;
+  }
+  __syncthreads();
+  return *lds_flag != 0u;
+}
+
+// ------------------------------------------ column sums of a few per-block partial rows
+// out[c] = sum_r part[r][c], r < nrows (<= SVILS_FOLD_ROWS), c < ncols <= CW, by the whole block in
+// a fixed order (row groups of NT/CW, NT = blockDim.x, then the groups in order): every block that folds the
+// same rows gets the same bits.  `tmp` holds NT doubles.  Ends with __syncthreads().
+template <int CW, int NT>
+struct FoldRows {
+  static constexpr uint32_t R = NT / CW;
+  static constexpr uint32_t MAXL = (SVILS_FOLD_ROWS + R - 1) / R;   // loads per thread, all in flight at once
+  double v[MAXL];
+  // first half: only issues the loads, so that the caller can start other independent accesses
+  // before anything waits (every dependent access after a kernel boundary is a cold miss)
+  __device__ __forceinline__ void issue(const double *__restrict__ part, uint32_t nrows, uint32_t ncols) {
+    const uint32_t c = threadIdx.x % CW, r0 = threadIdx.x / CW;
+#pragma unroll
+    for (uint32_t i = 0; i < MAXL; ++i) {
+      const uint32_t r = r0 + i * R;
+      v[i] = (c < ncols && r < nrows) ? part[(size_t)r * ncols + c] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void finish(double *tmp, double *out) {
+    const uint32_t c = threadIdx.x % CW, r0 = threadIdx.x / CW;
+    double s = 0.0;
+#pragma unroll
+    for (uint32_t i = 0; i < MAXL; ++i) s += v[i];
+    tmp[r0 * CW + c] = s;
+    __syncthreads();
+    if (threadIdx.x < CW) {
+      double w[R];
+#pragma unroll
+      for (uint32_t i = 0; i < R; ++i) w[i] = tmp[i * CW + threadIdx.x];
+      double t = 0.0;
+#pragma unroll
+      for (uint32_t i = 0; i < R; ++i) t += w[i];
+      out[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+};
+template <int CW, int NT>
+__device__ __forceinline__ void fold_rows(const double *__restrict__ part, uint32_t nrows, uint32_t ncols,
+                                          double *tmp, double *out) {
+  FoldRows<CW, NT> f;
+  f.issue(part, nrows, ncols);
+  f.finish(tmp, out);
 }
 
 // per-block link statistics without atomics: every wave's counts go through LDS,

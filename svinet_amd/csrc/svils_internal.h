@@ -33,7 +33,7 @@ struct DevCtrl {
   uint32_t rows;
   unsigned long long links_dense, links_sparse, links_shortcut;       // of the last sweep
   uint32_t parity;  // conv[parity] is the current _converged, conv[parity^1] receives prune()'s
-  uint32_t pad;
+  uint32_t cls_par; // lane-per-link layout: ltot/shist[cls_par] describe the link classes of the CURRENT sweep
 };
 
 struct Geometry {
@@ -65,9 +65,31 @@ struct DeviceState {
   uint64_t ent_begin, ent_end;   // owned CSR entries = [rowptr[node_begin], rowptr[node_end])
   uint64_t link_begin, link_end; // owned links (first endpoint in the node block)
   uint64_t lpl_w0;      // first wave-item (ent_begin / 64)
-  uint32_t lpl_nitems;
-  double *slot_f;       // [lpl_nitems][ld] segment that starts at lane 0 of an item
-  double *slot_l;       // [lpl_nitems][ld] segment that ends at lane 63 (and does not start at 0)
+  uint32_t lpl_nitems;  // capacity: wave-items per class list
+  double *slot_f;       // [2][lpl_nitems][ld] run that starts at lane 0 of a wave-item (per class list)
+  double *slot_l;       // [2][lpl_nitems][ld] run that ends at lane 63 (and does not start at lane 0)
+  double *gacc1;        // [n_alloc][ld] interior runs of class list 1 (list 0 writes gacc)
+  // Per-sweep link classes (k_classify, src/linksampling.cc:622-634): every owned CSR entry is
+  //   0 dense  (full softmax), 1 sparse (active-set softmax, _iter > 1000), 2 shortcut (exactly one
+  //   endpoint converged, O(1)); the entries of each class are stream-compacted in CSR order.
+  uint32_t *cp[2], *cq[2];        // [2L] (p, q) of the class-0 / class-1 entries
+  uint16_t *scol;                 // [2L] community column (pc or qc, minus 1) of the class-2 entries
+  uint32_t *npos[3];              // [n_alloc+1] class-l entries before row p (exclusive prefix at row starts)
+  unsigned long long *tcnt;       // [ntiles] class-0 << 32 | class-1 entry counts per classification tile
+  uint32_t *cls_args;             // [4] conv half, sparse flag, ltot/shist half of the classification in flight
+  uint32_t *ltot;                 // [2][8] per cls_par: entries of class 0,1,2; entries with q > p of class 0,1,2
+  unsigned long long *shist;      // [2][K] per cls_par: class-2 entries per community column
+  uint32_t cls_tile;              // raw entries per classification tile (a multiple of 1024)
+  uint32_t cls_tile0, cls_ntiles; // tiles covering the owned entries
+  uint64_t ent_pad;               // erow / col are padded to this many entries (0xffffffff)
+  int fold;             // 1: consumers sum the producers' per-block partial rows themselves (no k_colreduce)
+  int cls_next;         // the s3 / tail launches carry the two classification passes for the NEXT sweep
+  unsigned long long *sweep_stats;  // [sweep_stats_cap][4] ring: dense, sparse, shortcut links and index of each sweep
+  uint32_t sweep_stats_cap;
+  unsigned long long *stamps;   // [4][1024][8] wall-clock stamps of blocks (builds with -DSVILS_STAMPS only)
+  uint32_t *tail_ctl;   // [4] arrival ticket of k_tail's blocks
+  double *tail_part;    // [nb_t][4] per-block held-out partial sums of k_tail
+  uint32_t nb_t;
   unsigned long long *member_acc; // [n_alloc] tag bits OR-ed during the phi pass (lt_min_deg == 0)
   uint32_t *fcnt;       // [n_alloc][ld] tag counts (lt_min_deg > 0), else null
   // state
@@ -118,20 +140,25 @@ struct Params {
 };
 
 // launchers (svils_device.hip); all asynchronous on `s`
+constexpr uint32_t SVILS_FOLD_ROWS = 512;   // most per-block partial rows a consumer folds itself
 bool use_lpl(uint32_t K);
 int lpl_phi_waves(uint32_t K);
 uint32_t lpl_phi_resident_blocks(uint32_t K, int device);
+void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 uint32_t rpw_resident_blocks(const Geometry &g, int which /*0 phi, 1 s3, 2 finalize*/, int device);
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
-void launch_s3_lpl(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_reduce_a(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
-void launch_s3(const Geometry &g, const DeviceState &d, hipStream_t s);
+void launch_s3(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s);
-void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, int in_loop,
-                       hipStream_t s);
+void launch_validation(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+uint32_t tail_blocks(const Geometry &g, uint32_t nv);
+uint32_t lpl_cls_blocks(const DeviceState &d);
+uint32_t lpl_scatter_blocks(const DeviceState &d);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
                           uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s);

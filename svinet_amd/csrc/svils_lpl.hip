@@ -2,17 +2,27 @@
 //
 // With K = 20..28 a group-per-row layout leaves 37 % of a wavefront's lanes idle
 // and spends more time in cross-lane softmax reductions than in exp().  Here one
-// LANE owns one directed link: wave-item w = the 64 consecutive entries
-// [64w, 64w+64) of the symmetric CSR, each lane loops over k in registers (no
-// cross-lane reduction for the softmax at all), and the per-node sums of
-// gammanext are formed by staging the 64 phi rows in LDS and letting lane k walk
-// column k over the 64 rows IN ENTRY ORDER -- which is exactly the order in which
-// the reference's link loop adds to gammanext[x] (src/linksampling.cc:696-701).
-// A node's run of entries can straddle wave-items; the piece that starts at lane
-// 0 of an item goes to slot_f[item], a piece that ends at lane 63 to
-// slot_l[item], interior pieces straight to gamma[node]; the finalise kernel
-// re-derives the same rule from rowptr and adds the pieces in item order.  No
-// floating-point atomics, bit-reproducible, perfectly balanced (hubs included).
+// LANE owns one directed link, loops over k in registers (no cross-lane reduction
+// for the softmax at all), and the per-node sums of gammanext are formed by
+// staging the 64 phi rows of a wave-item in LDS and letting lane k walk column k
+// over the rows IN ENTRY ORDER (the order in which the reference's link loop adds
+// to gammanext[x], src/linksampling.cc:696-701).
+//
+// The cost of a sweep follows the work the reference's loop does
+// (src/linksampling.cc:622-681): once per sweep k_classify sorts every CSR entry
+// into one of three classes -- 0: full softmax, 1: active-set softmax (_iter > 1000),
+// 2: exactly one endpoint converged (O(1) shortcut) -- and stream-compacts each
+// class in CSR order (one pass, decoupled look-back scan).  k_phi_lpl then runs
+// only over the compacted class-0 and class-1 lists (a wave-item = 64 consecutive
+// entries of ONE list, so every lane does the same amount of work), and the
+// shortcut entries cost one 2-byte column id each, added per node by
+// k_finalize_lpl.  Because compaction is stable, the entries of a node stay
+// contiguous in every list: a node's run can straddle wave-items; the piece that
+// starts at lane 0 of an item goes to slot_f[list][item], a piece that ends at
+// lane 63 to slot_l[list][item], interior pieces straight to the node's row;
+// k_finalize_lpl re-derives the same rule from npos[list][] and adds the pieces in
+// item order.  No floating-point atomics, bit-reproducible, perfectly balanced.
+#include "svils_cls.h"
 #include "svils_devutil.h"
 
 namespace svils {
@@ -35,112 +45,114 @@ __device__ __forceinline__ void load_row_lane(const double *__restrict__ row, do
   }
 }
 
+// stand-alone classification of the sweep about to run (first sweep, mini-batch steps, after the
+// host changed flags or _iter)
+__global__ __launch_bounds__(1024) void k_cls_count(Geometry geo, DeviceState d, Params prm) {
+  if (d.ctrl->stopped) return;
+  __shared__ ClsWork shw[4];
+  cls_count_tiles<4>(geo, d, prm, shw, blockIdx.x, gridDim.x, false);
+}
+__global__ __launch_bounds__(1024) void k_cls_scatter(Geometry geo, DeviceState d) {
+  if (d.ctrl->stopped) return;
+  __shared__ ClsWork shw[4];
+  cls_scatter_tiles<4>(geo, d, shw, blockIdx.x, gridDim.x);
+}
+
 // ============================================================== phi pass (A6)
 template <int KC, int NW>
-__global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(64 * NW, (KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+  STAMP(0, 0);
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
+  STAMP(0, 1);
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
   __shared__ __attribute__((aligned(16))) double lds[NW][32 * SROW];
-  __shared__ double red[NW][64];
+  __shared__ double red[NW][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
-  const bool sparse_iter = (long long)ctrl->iter > (long long)prm.sparse_after;  // _iter > 1000, src/linksampling.cc:634
-  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const uint32_t cpar = ctrl->cls_par;
+  const uint32_t tot0 = d.ltot[cpar * 8u], tot1 = d.ltot[cpar * 8u + 1u];
+  const uint32_t n0 = (tot0 + 63u) >> 6, n1 = (tot1 + 63u) >> 6;
   const double *__restrict__ elogpi = d.elogpi;
   double *mylds = lds[wave];
 
-  // Elogbeta[.][0], wave-uniform but kept in VGPRs on purpose: as KR scalar pairs it made the
+  // Elogbeta[.][0], wave-uniform but kept in LDS/VGPRs on purpose: as KR scalar pairs it made the
   // SGPR file spill through v_writelane/v_readlane inside the hot loop.  Padding columns
   // (k >= K) get -inf, which masks them in the softmax without any select.
   __shared__ double eb[KR];
   if (threadIdx.x < KR) eb[threadIdx.x] = (threadIdx.x < K) ? d.elogbeta[2 * threadIdx.x] : NEG_INF;
   __syncthreads();
   double csum = 0.0;  // lane k: partial of sum[k]
-  unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
+  STAMP(0, 2);
 
-  for (uint32_t it = blockIdx.x * NW + wave; it < d.lpl_nitems; it += gridDim.x * NW) {
-    const uint64_t e = (d.lpl_w0 + it) * 64 + lane;
-    const bool valid = e >= d.ent_begin && e < d.ent_end;
+  for (uint32_t it = blockIdx.x * NW + wave; it < n0 + n1; it += gridDim.x * NW) {
+    const uint32_t list = it >= n0 ? 1u : 0u;            // wave-uniform
+    const uint32_t w = list ? it - n0 : it;
+    const uint32_t g = w * 64u + lane;
+    const bool valid = g < (list ? tot1 : tot0);
     uint32_t p = 0xffffffffu, q = 0;
     if (valid) {
-      p = d.erow[e];
-      q = d.col[e];
+      p = d.cp[list][g];
+      q = d.cq[list][g];
     }
     double phi[KR];
     double *mine = mylds + (lane & 31) * SROW;   // this lane's staged phi row (two passes of 32 rows)
     int tagk = -1;   // community this link tags (src/linksampling.cc:668-681,704-717), -1: none
-    int one_at = -1; // >= 0: the row is the unit vector e_c (converged shortcut), stored straight to LDS
     bool dense_row = false;
     if (valid) {
-      const uint32_t pc = conv[p], qc = conv[q];
-      const bool count_me = q > p;
-      if ((pc != 0) != (qc != 0)) {
-        // exactly one endpoint converged: src/linksampling.cc:622-631
-        one_at = (int)(pc ? pc : qc) - 1;
-        n_short += count_me;
+      dense_row = true;
+      // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686)
+      {
+        const double *rp = elogpi + (size_t)p * ld, *rq = elogpi + (size_t)q * ld;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const double2 a = *reinterpret_cast<const double2 *>(rp + 2 * c);
+          const double2 b = *reinterpret_cast<const double2 *>(rq + 2 * c);
+          phi[2 * c] = (a.x + b.x) + eb[2 * c];
+          phi[2 * c + 1] = (a.y + b.y) + eb[2 * c + 1];
+        }
+      }
+      if (list) {   // active-set path (:634-681): columns outside the union of the two active sets drop out
+        const unsigned long long inmask = d.amask[p] | d.amask[q];   // kw == 1 for K <= 64
+#pragma unroll
+        for (int k = 0; k < KR; ++k) phi[k] = ((inmask >> k) & 1ull) ? phi[k] : NEG_INF;
+      }
+      // branch-free from here so the KR independent exp chains interleave
+      double m = NEG_INF;
+#pragma unroll
+      for (int k = 0; k < KR; ++k) m = max_f64(m, phi[k]);   // padding columns are -inf via eb[]
+      if (m != NEG_INF) {
+        int best = 0;
+#pragma unroll
+        for (int k = KR - 1; k >= 0; --k) best = (phi[k] == m) ? k : best;   // first strict maximum
+        double s = 0.0;
+        // KR is even: exps in interleaved groups of 4 (or 2 for the tail)
+#pragma unroll
+        for (int k0 = 0; k0 + 4 <= KR; k0 += 4) {
+          double t[4] = {phi[k0] - m, phi[k0 + 1] - m, phi[k0 + 2] - m, phi[k0 + 3] - m};
+          exp_neg_n<4>(t);   // exp_neg(-inf) == 0 for masked / padding columns
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { phi[k0 + j] = t[j]; s += t[j]; }
+        }
+        if constexpr (KR % 4 != 0) {
+          double t[2] = {phi[KR - 2] - m, phi[KR - 1] - m};
+          exp_neg_n<2>(t);
+          phi[KR - 2] = t[0]; phi[KR - 1] = t[1];
+          s += t[0]; s += t[1];
+        }
+        const double inv = fast_rcp(s);
+#pragma unroll
+        for (int k = 0; k < KR; ++k) phi[k] *= inv;
+        // community tagging: the first strict maximum of phi is 1/s
+        if (write_comm && inv > prm.link_thresh) tagk = best;
       } else {
-        dense_row = true;
-        // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686)
-        {
-          const double *rp = elogpi + (size_t)p * ld, *rq = elogpi + (size_t)q * ld;
-#pragma unroll
-          for (int c = 0; c < KC; ++c) {
-            const double2 a = *reinterpret_cast<const double2 *>(rp + 2 * c);
-            const double2 b = *reinterpret_cast<const double2 *>(rq + 2 * c);
-            phi[2 * c] = (a.x + b.x) + eb[2 * c];
-            phi[2 * c + 1] = (a.y + b.y) + eb[2 * c + 1];
-          }
-        }
-        bool sparse = false;
-        if (sparse_iter) {
-          sparse = d.active_cnt[p] < geo.k10 && d.active_cnt[q] < geo.k10;
-          if (sparse) {
-            const unsigned long long inmask = d.amask[p] | d.amask[q];   // kw == 1 for K <= 64
-#pragma unroll
-            for (int k = 0; k < KR; ++k) phi[k] = ((inmask >> k) & 1ull) ? phi[k] : NEG_INF;
-          }
-        }
-        // branch-free from here so the KR independent exp chains interleave
-        double m = NEG_INF;
-#pragma unroll
-        for (int k = 0; k < KR; ++k) m = max_f64(m, phi[k]);   // padding columns are -inf via eb[]
-        if (m != NEG_INF) {
-          int best = 0;
-#pragma unroll
-          for (int k = KR - 1; k >= 0; --k) best = (phi[k] == m) ? k : best;   // first strict maximum
-          double s = 0.0;
-          // KR is even: exps in interleaved groups of 4 (or 2 for the tail)
-#pragma unroll
-          for (int k0 = 0; k0 + 4 <= KR; k0 += 4) {
-            double t[4] = {phi[k0] - m, phi[k0 + 1] - m, phi[k0 + 2] - m, phi[k0 + 3] - m};
-            exp_neg_n<4>(t);   // exp_neg(-inf) == 0 for masked / padding columns
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { phi[k0 + j] = t[j]; s += t[j]; }
-          }
-          if constexpr (KR % 4 != 0) {
-            double t[2] = {phi[KR - 2] - m, phi[KR - 1] - m};
-            exp_neg_n<2>(t);
-            phi[KR - 2] = t[0]; phi[KR - 1] = t[1];
-            s += t[0]; s += t[1];
-          }
-          const double inv = fast_rcp(s);
-#pragma unroll
-          for (int k = 0; k < KR; ++k) phi[k] *= inv;
-          // community tagging: the first strict maximum of phi is 1/s
-          if (write_comm && inv > prm.link_thresh) tagk = best;
-        } else {
-          dense_row = false;  // empty active-set union (:642-664): the row is zero
-        }
-        if (count_me) { if (sparse) n_sparse++; else n_dense++; }
+        dense_row = false;  // empty active-set union (:642-664): the row is zero
       }
     }
     // Stage the phi rows in LDS and let lane k sum column k over them in entry order, flushing at
     // node boundaries.  The 64 rows go through LDS in two passes of 32 (lanes 0-31, then 32-63):
     // half the LDS per wavefront, so that the register file, not LDS, sets the occupancy.
-    // Dense rows come from registers; shortcut / invalid / empty rows are zeros (+ a single 1.0)
-    // without ever being materialised in registers.
     // heads of the node runs: bit r set <=> row r starts a new node
     const uint32_t pprev = __shfl_up((int)p, 1, 64);
     const unsigned long long heads = __ballot(lane == 0 || p != pprev);
@@ -155,6 +167,9 @@ __global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometr
         tmask = (lane == k) ? mk : tmask;
       }
     }
+    double *const slotf = d.slot_f + ((size_t)list * d.lpl_nitems + w) * ld;
+    double *const slotl = d.slot_l + ((size_t)list * d.lpl_nitems + w) * ld;
+    double *const direct = list ? d.gacc1 : d.gacc;
     double acc = 0.0;
     int a = 0;
     // one run [a, b] of node `cur` is complete: store its partial gammanext row and its tags.
@@ -187,7 +202,6 @@ __global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometr
         } else {
 #pragma unroll
           for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(0.0, 0.0);
-          if (one_at >= 0) mine[one_at] = 1.0;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometr
             for (int j = 0; j < 16; ++j) {
               const int r = half * 32 + rb + j;
               if (r > 0 && ((heads >> r) & 1ull)) {      // run [a, r-1] ends (wave-uniform branch)
-                LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.gacc + (size_t)cur * ld, r - 1);
+                LPL_FLUSH((a == 0) ? slotf : direct + (size_t)cur * ld, r - 1);
                 a = r;
               }
               acc += v[j];
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometr
           }
         }
         // last run ends at lane 63
-        if (half == 1) LPL_FLUSH((a == 0) ? d.slot_f + (size_t)it * ld : d.slot_l + (size_t)it * ld, 63);
+        if (half == 1) LPL_FLUSH((a == 0) ? slotf : slotl, 63);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -226,29 +240,207 @@ __global__ __launch_bounds__(64 * NW, (KC >= 16 ? 3 : 1)) void k_phi_lpl(Geometr
 #undef LPL_FLUSH
   }
 
-  // per-block partial of `sum`: waves in order
-  red[wave][lane] = csum;
+  // per-block partial of `sum` (src/linksampling.cc:625,630,663,700 summed per node): waves in
+  // order; block 0 adds the shortcut entries' share (+1 per directed entry at its column, :625,:630)
+  STAMP(0, 3);
+  if (lane < 32) red[wave][lane] = csum;
   __syncthreads();
+  STAMP(0, 4);
   if (threadIdx.x < K) {
     double t = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < NW; ++w) t += red[w][threadIdx.x];
+    if (blockIdx.x == 0) t += (double)d.shist[(size_t)cpar * K + threadIdx.x];
     d.part_a[(size_t)blockIdx.x * K + threadIdx.x] = t;
   }
-  __shared__ unsigned long long lcnt[3 * NW];
-  block_store_link_counts(n_dense, n_sparse, n_short, d.part_links, lcnt, NW);
+}
+
+// ======================================= node finalise (A7 + swap + A5 + A9), K <= 32
+// compute_mean_indicators (src/linksampling.cc:526-545), the gamma swap/reset (:751-755),
+// set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491), one group of W lanes per
+// owned node, lane = community.  gammanext[p] = the pieces k_phi_lpl left for the node in both
+// class lists (item order) + 1.0 per shortcut entry at its column.
+template <int W, bool STOCH>
+__global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
+  STAMP(1, 0);
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  STAMP(1, 1);
+  constexpr int G = 64 / W;
+  __shared__ double2 logtab[128];
+  __shared__ double ksum[32];
+  __shared__ double tmp[32 * 32];
+  __shared__ double s12l[16][64][2];
+  __shared__ uint32_t shh[16][64];   // per-group histogram of shortcut columns (G * W == 64 counters per wave)
+  load_logtab(logtab, d.logtab);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool annealing = ctrl->annealing != 0;
+  const bool write_comm = ctrl->write_comm != 0;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
+  const uint32_t cpar = ctrl->cls_par;
+  const bool have1 = d.ltot[cpar * 8u + 1u] != 0u, have2 = d.ltot[cpar * 8u + 2u] != 0u;
+  // `sum`: folded from the phi pass's per-block partial rows (block 0 also publishes it), or the
+  // reduced / all-reduced vector when the caller splits the sweep at its exchange points
+  if (d.fold) {
+    if (annealing || blockIdx.x == 0) {
+      fold_rows<32, 1024>(d.part_a, d.nb_a, K, tmp, ksum);
+      if (blockIdx.x == 0 && threadIdx.x < K) d.kvec_a[threadIdx.x] = ksum[threadIdx.x];
+    }
+  } else if (threadIdx.x < 32) {
+    ksum[threadIdx.x] = threadIdx.x < K ? d.kvec_a[threadIdx.x] : 1.0;
+  }
+  __syncthreads();
+  STAMP(1, 2);
+  const bool kval = (uint32_t)lw < K;
+  // _network.ones() / _sum[k], src/linksampling.cc:542
+  // (mini-batch step: the window's sum, scaled to an estimate of the full one)
+  const double scale = (annealing && kval) ? (double)prm.ones / (STOCH ? ksum[lw] * prm.scale_a : ksum[lw]) : 1.0;
+  double s1 = 0.0, s2 = 0.0;
+
+  const uint32_t nown = geo.node_end - geo.node_begin;
+  for (uint32_t i = (blockIdx.x * nw + wave) * G + g; i < nown; i += gridDim.x * nw * G) {
+    const uint32_t p = geo.node_begin + i;
+    const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
+    double acc = 0.0;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (l == 1 && !have1) continue;
+      const uint32_t r0 = d.npos[l][p], r1 = d.npos[l][p + 1];
+      if (r1 > r0) {
+        const double *sf = d.slot_f + (size_t)l * d.lpl_nitems * ld, *sl = d.slot_l + (size_t)l * d.lpl_nitems * ld;
+        const double *direct = l ? d.gacc1 : d.gacc;
+        const uint32_t w0 = r0 >> 6, w1 = (r1 - 1u) >> 6;
+        if (w0 == w1) {
+          const double *src = ((r0 & 63u) == 0u) ? sf + (size_t)w0 * ld
+                              : (((r1 - 1u) & 63u) == 63u) ? sl + (size_t)w0 * ld
+                                                           : direct + (size_t)p * ld;
+          acc += src[lw];
+        } else {
+          for (uint32_t w = w0; w <= w1; ++w) {
+            const double *src = (w == w0 && (r0 & 63u) != 0u) ? sl : sf;
+            acc += src[(size_t)w * ld + lw];
+          }
+        }
+      }
+    }
+    if (have2) {   // exactly-one-converged links: +1 at the converged community (:622-631)
+      const uint32_t c0 = d.npos[2][p], c1 = d.npos[2][p + 1];
+      if (__any(c1 > c0)) {
+        // W entries at a time per group, counted with integer LDS atomics (order-free)
+        uint32_t *hh = &shh[wave][g * W];
+        hh[lw] = 0;
+        for (uint32_t j = c0 + (uint32_t)lw; j < c1; j += W) atomicAdd(&hh[d.scol[j] % W], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        acc += (double)hh[lw];
+      }
+    }
+    if (write_comm) {
+      unsigned long long b;
+      if (d.fcnt) {
+        uint32_t c = 0;
+        if (kval) { c = d.fcnt[(size_t)p * ld + lw]; d.fcnt[(size_t)p * ld + lw] = 0; }
+        b = (__ballot(kval && c > prm.lt_min_deg) >> (g * W)) & ((1ull << W) - 1ull);
+      } else {
+        b = d.member_acc[p];
+      }
+      if (lw == 0) {
+        d.member[(size_t)p * geo.kw] = b;
+        if (!d.fcnt) d.member_acc[p] = 0ull;
+      }
+    }
+    double gn, m = 0.0;
+    if (tl > 0.0) {
+      const double g0 = prm.alpha + acc;
+      m = (g0 - prm.alpha) / tl;
+      gn = g0 + ((double)geo.n - tl - 1.0) * m;
+      if (annealing) gn *= scale;
+      if (kval) { s1 += m; s2 += m * m; }
+      else { m = 0.0; gn = 0.0; }
+      if constexpr (STOCH) {
+        // Robbins-Monro step of this node: gamma <- (1 - rho) gamma + rho gamma_hat with
+        // rho = (tau0 + c)^-kappa, c = updates the node has had; s1/s2 are kept as running sums
+        // over the stored mphi rows, so this row contributes (new - old)
+        const uint32_t c = d.ncnt[p];
+        const double rho = exp_neg(-prm.kappa * log_tab(prm.tau0 + (double)c, logtab));
+        if (kval) {
+          const double gold = d.gamma[(size_t)p * ld + lw], mold = d.mphi[(size_t)p * ld + lw];
+          gn = (1.0 - rho) * gold + rho * gn;
+          s1 -= mold;
+          s2 -= mold * mold;
+        }
+        if (lw == 0) d.ncnt[p] = c + 1u;
+      }
+      if (kval) d.mphi[(size_t)p * ld + lw] = m;
+    } else {
+      // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
+      gn = kval ? prm.alpha : 0.0;
+    }
+    if (kval) d.gamma[(size_t)p * ld + lw] = gn;   // padding columns stay 0
+    double rs = group_sum<W>(gn);
+    double el;
+    if (K < (uint32_t)W) {
+      // lane K of the group is idle: let it evaluate psi(row sum) in the same digamma call
+      const double arg = ((uint32_t)lw == K) ? rs : (kval ? gn : 1.0);
+      const double ps = digamma(arg, logtab);
+      const double psi_rs = __shfl(ps, g * W + (int)K, 64);
+      el = kval ? ps - psi_rs : 0.0;
+    } else {
+      const double psi_rs = digamma(rs, logtab);
+      el = kval ? digamma(gn, logtab) - psi_rs : 0.0;
+    }
+    if (kval) d.elogpi[(size_t)p * ld + lw] = el;
+    // prune / check_and_set_converged, src/linksampling.cc:455-475
+    const bool act = kval && (gn - prm.alpha >= 1.0);
+    const unsigned long long bits = (__ballot(act) >> (g * W)) & ((1ull << W) - 1ull);
+    const uint32_t active = (uint32_t)__popcll(bits);
+    if (lw == 0) {
+      conv_new[p] = (active == 1) ? (uint32_t)(63 - __builtin_clzll(bits)) + 1u : conv_old[p];
+      d.active_cnt[p] = active;
+      d.amask[(size_t)p * geo.kw] = (active <= geo.k10) ? bits : 0ull;
+    }
+  }
+  STAMP(1, 3);
+  // per-block partials of s1, s2: waves in order, then the groups of a wave in order
+  s12l[wave][lane][0] = s1;
+  s12l[wave][lane][1] = s2;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t which = threadIdx.x >> 5, k = threadIdx.x & 31u;
+    if (k < K) {
+      double t = 0.0;
+      for (int w = 0; w < nw; ++w)
+        for (int gg = 0; gg < G; ++gg) t += s12l[w][gg * W + (int)k][which];
+      d.part_b[(size_t)blockIdx.x * 2 * K + which * K + k] = t;
+    }
+  }
 }
 
 // ================================================================ s3 pass (A8)
-// One lane per training link (the reference's own list, p < q): per-lane
-// accumulators over all of a lane's links, one LDS transpose per wave at the end.
+// One lane per training link (the reference's own list, p < q): per-lane accumulators over
+// all of a lane's links, then the same two-pass LDS column walk as the phi kernel.  Block 0 also
+// publishes s1, s2 (folded from k_finalize_lpl's partial rows).  When cls_next is set the launch
+// carries extra blocks after the nb_c s3 blocks: they classify the links for the NEXT sweep at the
+// same time on other CUs (prune() of this sweep is complete: the launch follows k_finalize_lpl);
+// the scatter pass follows on the tail launch.
 template <int KC>
-__global__ __launch_bounds__(256) void k_s3_lpl(Geometry geo, DeviceState d) {
+__global__ __launch_bounds__(1024) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
-  __shared__ __attribute__((aligned(16))) double lds[256 * SROW];
-  __shared__ double red[8][32];
+  __shared__ __attribute__((aligned(16))) double lds[16][32 * SROW];
+  __shared__ double red[16][32];
+  __shared__ ClsWork shw[4];
+  STAMP(2, 0);
+  if (blockIdx.x >= d.nb_c) {   // the blocks after the s3 blocks: count pass of the NEXT sweep's link classes
+    cls_count_tiles<4>(geo, d, prm, shw, blockIdx.x - d.nb_c, gridDim.x - d.nb_c, true);
+    STAMP(2, 7);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
@@ -257,7 +449,7 @@ __global__ __launch_bounds__(256) void k_s3_lpl(Geometry geo, DeviceState d) {
 #pragma unroll
   for (int k = 0; k < KR; ++k) s3[k] = 0.0;
   const uint64_t nl = d.link_end - d.link_begin;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nl; i += (uint64_t)gridDim.x * 256) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += (uint64_t)d.nb_c * blockDim.x) {
     const uint64_t l = d.link_begin + i;
     const uint32_t p = d.links[2 * l], q = d.links[2 * l + 1];
     const uint32_t pc = conv[p], qc = conv[q];
@@ -277,32 +469,68 @@ __global__ __launch_bounds__(256) void k_s3_lpl(Geometry geo, DeviceState d) {
       for (int k = 0; k < KR; ++k) s3[k] += mp[k] * mq[k];
     }
   }
-  // block total in a fixed order: 8 groups of 32 rows per column, then the 8 partials
+  STAMP(2, 1);
+  // wave total per column: the 64 rows go through LDS in two passes of 32; lane (part, k) adds the
+  // rows r = part, part + NP, ... of column k (NP = 64 / KR lanes share a column), then the parts
   {
-    double *mine = lds + (wave * 64 + lane) * SROW;
+    constexpr int NP = 64 / KR;
+    double *mylds = lds[wave];
+    double *mine = mylds + (lane & 31) * SROW;
+    const int kcol = lane % KR, part = lane / KR;
+    double acc = 0.0;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(s3[2 * c], s3[2 * c + 1]);
+    for (int half = 0; half < 2; ++half) {
+      if ((lane >> 5) == half) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(s3[2 * c], s3[2 * c + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (part < NP) {
+        double v[(32 + NP - 1) / NP];
+#pragma unroll
+        for (int i = 0; i < (32 + NP - 1) / NP; ++i) {
+          const int r = part + i * NP;
+          v[i] = r < 32 ? mylds[r * SROW + kcol] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < (32 + NP - 1) / NP; ++i) acc += v[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // parts in order
+    double tot = 0.0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) tot += __shfl(acc, pp * KR + kcol, 64);
+    if (lane < KR && lane < 32) red[wave][lane] = tot;
   }
-  __syncthreads();
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  double part = 0.0;
-  if (col < KR)
-    for (int r = 0; r < 32; ++r) part += lds[(grp * 32 + r) * SROW + col];
-  red[grp][col] = part;
   __syncthreads();
   if (threadIdx.x < K) {
     double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) t += red[w][threadIdx.x];
     d.part_c[(size_t)blockIdx.x * K + threadIdx.x] = t;
+  }
+  STAMP(2, 2);
+  if (d.fold && blockIdx.x == 0) {   // s1, s2 of this sweep for k_tail
+    __syncthreads();
+    double *tmp = &lds[0][0];        // 16 row groups x 64 columns; the staging area is free again
+    __shared__ double out64[64];
+    fold_rows<64, 1024>(d.part_b, d.nb_b, 2 * K, tmp, out64);
+    if (threadIdx.x < 2 * K) d.kvec_c[threadIdx.x] = out64[threadIdx.x];
   }
 }
 
 // ------------------------------------------------------------------ launchers
 bool use_lpl(uint32_t K) { return K <= 32; }
-// waves per block of k_phi_lpl (with the 32-row staging area every KC fits four)
-constexpr int lpl_waves(int) { return 4; }
-int lpl_phi_waves(uint32_t) { return 4; }
+// waves per block of k_phi_lpl.  The register file holds 4 waves per SIMD up to K = 24 and 3 for
+// K = 25..32 (a phi row of more than 128 VGPRs): two blocks per CU fill it, and a grid of two blocks
+// per CU leaves at most SVILS_FOLD_ROWS partial rows of `sum` for the consumers to fold.  (One
+// 16-wave block per CU measured 25 % slower on ca-AstroPh K = 20, 256-thread blocks 2 % faster.)
+constexpr int lpl_waves(int kc) { return kc >= 14 ? 6 : 8; }
+int lpl_phi_waves(uint32_t K) { return K > 24 ? 6 : 8; }
 
 #define LPL_DISPATCH(K_, CALL)                 \
   do {                                         \
@@ -323,10 +551,31 @@ uint32_t lpl_phi_resident_blocks(uint32_t K, int device) {
   LPL_DISPATCH(K, CALL);
 #undef CALL
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  if (per_cu <= 0 || cus <= 0) return 768;
+  if (per_cu <= 0 || cus <= 0) return SVILS_FOLD_ROWS;
   return (uint32_t)per_cu * (uint32_t)cus;
 }
 
+void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  uint32_t nb = (d.cls_ntiles + 3u) / 4u;
+  if (nb > 256u) nb = 256u;
+  if (nb == 0) nb = 1;
+  hipLaunchKernelGGL(k_cls_count, dim3(nb), dim3(1024), 0, s, g, d, p);
+  hipLaunchKernelGGL(k_cls_scatter, dim3(nb), dim3(1024), 0, s, g, d);
+}
+// count-pass blocks riding on the s3 launch (four workers each): with the <= 192 s3 blocks at most
+// one block per CU
+uint32_t lpl_cls_blocks(const DeviceState &d) {
+  if (!d.cls_next) return 0;
+  uint32_t nb = (d.cls_ntiles + 3u) / 4u;
+  if (nb > 64u) nb = 64u;
+  return nb ? nb : 1u;
+}
+// scatter-pass blocks (one worker each) riding on the tail launch
+uint32_t lpl_scatter_blocks(const DeviceState &d) {
+  if (!d.cls_next) return 0;
+  uint32_t nb = d.cls_ntiles < 512u ? d.cls_ntiles : 512u;
+  return nb ? nb : 1u;
+}
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define CALL(KC_)                                                                                   \
   hipLaunchKernelGGL((k_phi_lpl<KC_, lpl_waves(KC_)>), dim3(d.nb_a), dim3(64 * lpl_waves(KC_)), 0, s, \
@@ -334,8 +583,19 @@ void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hi
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }
-void launch_s3_lpl(const Geometry &g, const DeviceState &d, hipStream_t s) {
-#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
+void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+#define FIN(W_)                                                                                     \
+  do {                                                                                              \
+    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, true>), dim3(d.nb_b), dim3(1024), 0, s, g, d, p); \
+    else hipLaunchKernelGGL((k_finalize_lpl<W_, false>), dim3(d.nb_b), dim3(1024), 0, s, g, d, p);  \
+  } while (0)
+  if (g.W == 8) FIN(8);
+  else if (g.W == 16) FIN(16);
+  else FIN(32);
+#undef FIN
+}
+void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d)), dim3(1024), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }

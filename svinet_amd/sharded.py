@@ -85,7 +85,9 @@ class HipShard:
         self.amask = am.view(self.n_alloc, rb // 8)
         mem, rb = t(_svils.BUF_MEMBER, "<i8")
         self.member = mem.view(self.n_alloc, rb // 8)
-        self.sweeps = 0
+        # conv[parity] is the current _converged; parity flips once per completed sweep on the device
+        # (k_tail), so the host mirror starts from the engine's own sweep count
+        self.sweeps = int(self.engine.control().sweeps_done)
 
     def phase(self, ph):
         self.engine.sweep_phase(ph)

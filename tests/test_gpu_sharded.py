@@ -101,7 +101,11 @@ def test_sharded_driver_world1(graph_files):
         plain = setup.engine(use_validation_stop=False)
         plain.sweep(10)
         a, b = shard.engine.state(), plain.state()
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        # same kernels; the sharded driver materialises the K-vectors with k_colreduce where the plain
+        # engine folds the per-block partial rows in the consumers: a different (fixed) summation order
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-12)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-12)
+        assert np.array_equal(a[2], b[2])
         # the aliasing tensors really see the device buffers
         shard.engine.synchronize()
         torch.cuda.synchronize()

@@ -20,7 +20,7 @@ else:
     setup = Setup(_fixture(f), n, k)
 eng = setup.engine(use_validation_stop=False)
 eng.sweep(5); eng.synchronize()
-eng.enable_timing(0x7f)
+eng.enable_timing(0xff)
 eng.sweep(steps); eng.synchronize()
 t = eng.timing()
 tot = sum(v[0] for v in t.values())
