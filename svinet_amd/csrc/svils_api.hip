@@ -164,6 +164,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
         if (rc) return rc;
         h->cls_valid = true;
       }
+      if ((h->tmask >> SVILS_KERNEL_PHI) & 1u) h->timed_sweeps.push_back((uint32_t)h->sweeps_issued);
       { Timed t(h, SVILS_KERNEL_PHI); launch_phi(g, d, prm, s); }
       if (!d.fold) { Timed t(h, SVILS_KERNEL_REDUCE_SUM); launch_reduce_a(g, d, s); }
     } break;
@@ -635,7 +636,6 @@ namespace {
 int eager_sweeps(svils_handle *h, uint32_t nsweeps) {
   for (uint32_t i = 0; i < nsweeps; ++i) {
     int rc;
-    if ((h->tmask >> SVILS_KERNEL_PHI) & 1u) h->timed_sweeps.push_back((uint32_t)h->sweeps_issued);
     if ((rc = run_phase(h, SVILS_PHASE_A, true))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_B, true))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_C, true))) return rc;

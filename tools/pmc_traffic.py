@@ -4,7 +4,7 @@ into HBM bytes per kernel launch, and update profiles/traffic.json for the phi k
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_X -o p -- python tools/kernel_times.py WORKLOAD 15
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_X -o p -- python tools/kernel_times.py WORKLOAD 15
-  python tools/pmc_traffic.py WORKLOAD gpurun_out/pmc_fetch_X gpurun_out/pmc_write_X
+  python tools/pmc_traffic.py WORKLOAD gpurun_out/pmc_fetch_X gpurun_out/pmc_write_X [profiles/<file this table is kept in>]
 
 Counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
 (MI355X_MICROARCH.md, HBM section), so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -38,9 +38,20 @@ def main():
         if k.startswith("k_phi"):
             phi = b
     if phi is not None:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, "profiles", "traffic.json")
         t = json.load(open(path)) if os.path.exists(path) else {}
-        t[wl] = {"phi_hbm_bytes_per_launch": phi}
+        import subprocess
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+            dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "svinet_amd/csrc"], text=True).strip())
+            commit += "+uncommitted kernel changes" if dirty else ""
+        except Exception:
+            commit = None
+        t[wl] = {"phi_hbm_bytes_per_launch": phi,
+                 "source": sys.argv[4] if len(sys.argv) > 4 else None,   # the profiles/ file holding this table
+                 "commit": commit,
+                 "counters": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB"}
         json.dump(t, open(path, "w"), indent=1)
 
 
