@@ -1,0 +1,76 @@
+"""-m gpu: BASELINE config 5 (synthetic MMSB, n = 1,000,000, k = 512) at FULL size on one GPU, and an
+HBM-bound parity point against the oracle.
+
+At n = 10^6 the oracle needs ~155 s per sweep, so the full-size run is checked through the
+size-independent properties of the sweep (tests/test_gpu_properties.py); parity proper is pinned one
+size down (n = 2*10^5, k = 512: 0.82 GB per n-by-k array, far outside the 256 MB Infinity Cache, the
+same kernels and layouts), one sweep against the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_full_size_invariants():
+    from svinet_amd import mmsbgen_sparse as G
+    from svinet_amd.host_api import Setup
+    n, k = 1_000_000, 512
+    pairs = G.generate(n, k, 24)
+    s = Setup(n=n, k=k, pairs=pairs)
+    assert s.n == n and s.singles == 0                     # no isolated node, so -n 1000000 holds (Q9)
+    L = int(s.nlinks)
+    assert 1.0e7 < L < 6.0e7                               # below the reference's 6e7-link cap (Q6)
+    # quirk Q5: n(n-1)/2 in uint32 arithmetic wraps at this size; the host reproduces the wrapped value
+    assert s.total_pairs == float((np.uint64(n) * np.uint64(n - 1) % np.uint64(2**32)) // np.uint64(2))
+    e1 = s.engine(use_validation_stop=False)
+    e2 = s.engine(use_validation_stop=False)
+    e1.sweep(2)
+    e2.sweep(2)
+    g1, l1, c1 = e1.state()
+    g2, l2, c2 = e2.state()
+    # bitwise run-to-run determinism (no floating-point atomics anywhere)
+    assert np.array_equal(l1, l2) and np.array_equal(c1, c2) and np.array_equal(g1, g2)
+    del g2
+    assert np.isfinite(g1).all() and (g1 > 0).all()
+    # phi rows are probability vectors: every link adds 2 to `_sum` (src/linksampling.cc:625,630,663,700)
+    tot = float((l1[:, 0] - s.eta[0]).sum())
+    assert abs(tot - 2.0 * L) < 1e-6 * L, (tot, 2 * L)
+    # mean indicators: sum_k mphi[p][k] == 1/2 for every node with a training link (tl = 2 deg, quirk Q3)
+    rs = e1.aux(2).sum(1)
+    tl = e1.aux(4)
+    assert np.allclose(rs[tl > 0], 0.5, rtol=0, atol=1e-12)
+    deg = np.bincount(s.links.ravel(), minlength=s.n)
+    assert np.array_equal(tl, 2.0 * deg)
+    # the link-branch counters partition the training links
+    c = e1.control()
+    assert c.links_dense + c.links_sparse + c.links_shortcut == L and c.sweeps_done == 2 and c.rows == 2
+    rows = e1.rows()
+    assert np.isfinite(rows).all() and list(rows[:, 0]) == [0.0, 1.0] and rows[0, 2] == s.validation_sorted.shape[0]
+    assert np.array_equal(rows, e2.rows())
+
+
+def test_hbm_bound_sweep_against_oracle():
+    """one sweep at n = 2e5, k = 512 on the planted MMSB graph: gamma / lambda within 1e-5 relative
+    (the north-star bar; observed ~1e-13), flags, counters and the likelihood row equal"""
+    from oracle import oracle as O
+    from svinet_amd import mmsbgen_sparse as G
+    from svinet_amd.host_api import Setup
+    n, k = 200_000, 512
+    pairs = G.generate(n, k, 24)
+    s = Setup(n=n, k=k, pairs=pairs)
+    ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, use_validation_stop=False)
+    assert np.array_equal(ref.links, s.links) and np.array_equal(ref.validation_sorted, s.validation_sorted)
+    eng = s.engine(use_validation_stop=False)
+    ref.sweep()
+    eng.sweep(1)
+    g, lam, conv = eng.state()
+    rg, rl = ref.gamma, ref.lam
+    assert np.max(np.abs(g - rg) / rg) < 1e-5
+    assert np.max(np.abs(lam - rl) / np.abs(rl)) < 1e-5
+    assert np.max(np.abs(g - rg) / rg) < 1e-9            # what fp64 with re-ordered sums actually gives
+    assert np.array_equal(conv, ref.converged)
+    assert np.array_equal(eng.aux(3), ref.active_comms)
+    c = eng.control()
+    assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
+    np.testing.assert_allclose(eng.rows()[0, 1:], ref.rows[1, 1:], rtol=1e-9, atol=1e-13)
