@@ -182,151 +182,144 @@ def cpu_baseline(path, pairs, n, k, warmup, steps, budget_s=25.0):
             "host_cpus": os.cpu_count(), "warmup_s_per_sweep": per}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="astroph-k20",
-                    help="|".join(WORKLOADS) + "|synthetic:<n>:<k>:<mean_deg>|mmsb:<n>:<k>:<mean_deg>")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU driver even at N=1")
-    ap.add_argument("--event-period", type=int, default=9,
-                    help="bracket k_phi with hipEvents on every P-th sweep of the timed region (those sweeps are "
-                         "launched eagerly, the others replay hipGraphs); 1 = every sweep.  Lowered automatically "
-                         "so that at least 10 launches are timed")
-    ap.add_argument("--no-hbm-bound", action="store_true",
-                    help="skip the HBM-bound sub-record (n=2e5, k=512; ~15 s)")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket k_phi with hipEvents in the timed region (lets svils_sweep replay hipGraphs; "
-                         "roofline then comes from a separate short eager pass)")
-    ap.add_argument("--replicate", action="store_true",
-                    help="N>1, problem too small to shard: run the SAME chain on every rank (value = one chain, "
-                         "'strong') instead of independent restarts (value = all chains, 'weak')")
-    ap.add_argument("--no-sharded-extra", action="store_true",
-                    help="N>1, replicated main run: skip the extra timing of the node-block sharded path")
-    ap.add_argument("--extra-timeout", type=int, default=150,
-                    help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
-    ap.add_argument("--shard", choices=["auto", "always", "never"], default="auto",
-                    help="N>1: node-block sharding with RCCL exchanges, or replicate the sweep on every "
-                         "rank (auto: shard only when K*L/N is large enough to amortise 3 collectives/sweep)")
-    args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    from svinet_amd import _svils
+def _load_workload(name):
+    """-> (setup, path, pairs, n, k, data description)"""
     from svinet_amd.host_api import Setup
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("SVILS_BENCH_ONE_DEVICE"):   # protocol debugging on a 1-GPU box: every rank on device 0
-        local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or args.force_sharded:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            import datetime
-            backend = os.environ.get("SVILS_BENCH_BACKEND", "nccl")
-            kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600), **kw)
-
-    # ---- inputs: product host side (C++), resident in HBM before timing ----
     path, pairs = None, None
-    if args.workload.startswith("synthetic"):
-        _, sn, sk, sd = args.workload.split(":")
+    if name.startswith("synthetic"):
+        _, sn, sk, sd = name.split(":")
         n, k = int(sn), int(sk)
         pairs = _synthetic_pairs(n, int(sd), 20240517)
         setup = Setup(n=n, k=k, pairs=pairs)
         data = "synthetic sparse graph (ring + uniform random pairs, seed 20240517), seeded init"
-    elif args.workload.startswith("mmsb"):
+    elif name.startswith("mmsb"):
         from svinet_amd import mmsbgen_sparse
-        _, sn, sk, sd = args.workload.split(":")
+        _, sn, sk, sd = name.split(":")
         n, k = int(sn), int(sk)
         pairs = mmsbgen_sparse.generate(n, k, int(sd))
         setup = Setup(n=n, k=k, pairs=pairs)
         data = ("synthetic sparse MMSB graph (svinet_amd/mmsbgen_sparse.py: Dirichlet(0.05) top-4 memberships, "
                 "Beta(4700.59,0.77) rates, Philox seed %d), seeded init" % mmsbgen_sparse.DEFAULT_SEED)
     else:
-        if args.workload not in WORKLOADS and args.workload.startswith("astroph-k"):   # any K on ca-AstroPh
-            WORKLOADS[args.workload] = ("ca-AstroPh.csv.gz", 17903, int(args.workload[len("astroph-k"):]))
-        fixture, n, k = WORKLOADS[args.workload]
+        if name not in WORKLOADS and name.startswith("astroph-k"):   # any K on ca-AstroPh
+            WORKLOADS[name] = ("ca-AstroPh.csv.gz", 17903, int(name[len("astroph-k"):]))
+        fixture, n, k = WORKLOADS[name]
         path = _fixture(fixture)
         setup = Setup(path, n, k)
         data = "reference example graph %s (fixture copy), seeded init (MT19937 4357)" % fixture
-    setup0 = setup          # the seed-0 problem (also what the optional sharded-path timing uses)
+    return setup, path, pairs, n, k, data
+
+
+class _Sharded:
+    """One chain over all ranks: node-block sharding with the exchanges issued by the device library itself
+    (svils_sweep_sharded: RCCL all-reduce / all-gather on the engine's stream between the phases of a sweep)."""
+
+    def __init__(self, setup, rank, world, device, dist):
+        from svinet_amd import _svils
+        from svinet_amd.sharded import block_size, node_block
+        B = block_size(setup.n, world)
+        self.eng = setup.engine(use_validation_stop=False, device=device,
+                                node_block=node_block(setup.n, world, rank), n_alloc=B * world)
+        ids = [_svils.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        self.eng.comm_init(ids[0], rank, world)
+
+    def sweep(self, n):
+        self.eng.sweep_sharded(n)
+
+
+def _timed(runner, eng, steps, dist, torch):
+    """barrier + device sync on both sides of exactly `steps` sweeps; MAX over ranks"""
+    eng.synchronize(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.sweep(steps)
+    eng.synchronize(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="astroph-k20",
+                    help="|".join(WORKLOADS) + "|astroph-k<K>|synthetic:<n>:<k>:<mean_deg>|mmsb:<n>:<k>:<mean_deg>")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-period", type=int, default=9,
+                    help="N=1: bracket the phi launch with hipEvents on every P-th sweep of the timed region (those "
+                         "sweeps are launched eagerly, the others replay hipGraphs); lowered automatically so that "
+                         "at least 10 launches are timed")
+    ap.add_argument("--no-hbm-bound", action="store_true", help="skip the HBM-bound sub-record (n=2e5, k=512; ~15 s)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="N=1: no hipEvents in the timed region (pure hipGraph replay); the roofline then comes from an "
+                         "eager pass after it")
+    ap.add_argument("--no-extra", action="store_true", help="N>1: skip the side records (config 4, HBM-bound size)")
+    ap.add_argument("--extra-timeout", type=int, default=240,
+                    help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
+    args = ap.parse_args()
+
+    import torch
+    from svinet_amd import _svils
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600),
+                                device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: product host side (C++), resident in HBM before timing ----
+    setup, path, pairs, n, k, data = _load_workload(args.workload)
     L = int(setup.nlinks)
     V = int(setup.validation_sorted.shape[0])
 
-    # A sweep has three exchange points; below ~5e7 (link,k) pairs per GPU the sweep is tens of
-    # microseconds and sharding it only adds collective latency, so small problems are replicated.
-    work_per_gpu = float(k) * L / max(world, 1)
-    shard = world > 1 and (args.shard == "always" or (args.shard == "auto" and work_per_gpu >= 5e7))
-    if args.force_sharded:
-        shard = True
-    # N > 1 and too small to shard: every rank runs its own chain -- an independent restart with -seed <rank>
-    # (different held-out sample and initialisation), the way a multi-GPU node is used on a small graph.
-    # `value` is then the aggregate over the N chains ("weak"); the strong-scaling number of ONE chain over
-    # the N GPUs is timed separately below (`sharded_path`).
-    restarts = world > 1 and not shard and not args.replicate
-    if restarts and rank > 0:
-        setup = Setup(path, n, k, seed=rank) if path else Setup(n=n, k=k, pairs=pairs, seed=rank)
-        L = int(setup.nlinks)
-        V = int(setup.validation_sorted.shape[0])
-    if not shard:
+    # N = 1: the plain engine (hipGraph replay).  N > 1: ONE chain, node-block sharded over the N ranks with
+    # the RCCL exchanges inside the timed region -- strong scaling of the metric's own workload, whatever
+    # its size (SURVEY 8e: ca-AstroPh K=20 is a ~65 us sweep, four collectives per sweep cannot speed it up).
+    if world == 1:
         eng = setup.engine(use_validation_stop=False, device=local_rank)
         runner = eng
-        sync = eng.synchronize
     else:
-        from svinet_amd.sharded import HipShard, ShardedSweep
-        shard = HipShard(setup, rank, world, local_rank, use_validation_stop=False)
-        eng = shard.engine
-        runner = ShardedSweep(shard, dist)
-        sync = eng.synchronize
-
-    def barrier():
-        sync()
-        torch.cuda.synchronize()
-        if dist is not None and world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
+        runner = _Sharded(setup, rank, world, local_rank, dist)
+        eng = runner.eng
     runner.sweep(args.warmup)
-    barrier()
     period = max(1, min(args.event_period, args.steps // 10))   # >= 10 timed launches whenever steps >= 10
-    if not args.no_kernel_events:
-        # hipEvents around the phi kernel, on the engine's own stream, sampled every P-th sweep
+    if world > 1:
+        eng.enable_timing((1 << _svils.KERNEL_PHI) | (1 << _svils.KERNEL_EXCHANGE), 1)
+    elif not args.no_kernel_events:
         eng.enable_timing(1 << _svils.KERNEL_PHI, period)
-    t0 = time.perf_counter()
-    runner.sweep(args.steps)
-    sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    links_all_chains = float(L)
-    if dist is not None and world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        if restarts:
-            ll = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
-            dist.all_reduce(ll, op=dist.ReduceOp.SUM)
-            links_all_chains = float(ll.item())
+    elapsed = _timed(runner, eng, args.steps, dist, torch)
     ctrl = eng.control()
     assert ctrl.sweeps_done >= args.warmup + args.steps, "sweeps were skipped"
+
     same_window = None
+    exch = None
     if rank == 0:
-        if args.no_kernel_events:        # separate eager pass for the phi timing
+        if world > 1:
+            exch = eng.timing()["exchange"]
+            same_window = _phi_record(eng, k, "every sweep of the timed region (sweeps %d..%d), this rank's node block"
+                                      % (args.warmup, args.warmup + args.steps))
+        elif args.no_kernel_events:        # separate eager pass for the phi timing
             eng.enable_timing(1 << _svils.KERNEL_PHI)
             runner.sweep(max(10, min(args.steps, 20)))
-            sync()
+            eng.synchronize()
             same_window = _phi_record(eng, k, "eager pass of sweeps %d.. after the timed region" % (args.warmup + args.steps))
         else:
             same_window = _phi_record(eng, k, "every %d-th sweep of the timed region (sweeps %d..%d)"
@@ -335,7 +328,7 @@ def main():
                 extra = 10 - same_window["launches_timed"]
                 eng.enable_timing(1 << _svils.KERNEL_PHI, 1)
                 runner.sweep(extra)
-                sync()
+                eng.synchronize()
                 more = _phi_record(eng, k, "")
                 n0, n1 = same_window["launches_timed"], more["launches_timed"]
                 t = (same_window["avg_launch_us"] or 0) * n0 + more["avg_launch_us"] * n1
@@ -348,50 +341,51 @@ def main():
                                "algorithmic_bytes_per_launch": alg / (n0 + n1), "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
 
+    out = None
     if rank == 0:
+        g, lam, conv = eng.state()
         out = {
             "metric": "edge-updates/sec (link-sampling SVI step)",
-            "value": (links_all_chains if restarts else L) * args.steps / elapsed,
+            "value": L * args.steps / elapsed,
             "unit": "edge-updates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if restarts else "strong",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": data,
             "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
-                       "parallelism": ("node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world) if shard
-                                      else (("%d independent chains, one per GPU (restarts with -seed 0..%d; no exchange): the "
-                                             "problem is too small to shard (K*L/N = %.1e), see sharded_path for one chain over "
-                                             "%d GPUs" % (world, world - 1, work_per_gpu, world)) if restarts
-                                            else ("the same chain replicated on %d GPUs" % world) if world > 1 else "single GPU"),
-                       "converged_nodes_at_end": None},
-            "roofline": None,
+                       "parallelism": ("one chain, node-block sharding x%d: per sweep 2 RCCL all-reduces (K and 3K doubles) and "
+                                       "one grouped all-gather (gamma rows n*ld*8 B + packed flags), issued by the device "
+                                       "library between the phases (svils_sweep_sharded)" % world) if world > 1 else "single GPU",
+                       "converged_nodes_at_end": int((conv > 0).sum()),
+                       # how the last sweep's links were evaluated (src/linksampling.cc:622-719): full softmax,
+                       # active-set path (_iter > 1000 only), O(1) shortcut of links with exactly one converged endpoint
+                       "links_last_sweep": {"dense": int(ctrl.links_dense), "sparse": int(ctrl.links_sparse),
+                                            "shortcut": int(ctrl.links_shortcut),
+                                            "scope": "this rank's node block" if world > 1 else "all links"}},
         }
-        tr = _traffic(args.workload)
+        tr = _traffic(args.workload) if world == 1 else None
         roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 32 else "k_phi (phi pass, A6)"}
         roof.update(same_window)
-        roof["timing"] = "hipEvents around the phi launch on the engine's own stream; sampled sweeps launch eagerly, the rest replay hipGraphs"
+        roof["timing"] = ("hipEvents around the phi launch on the engine's own stream" +
+                          ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if world == 1 else ""))
         roof["traffic"] = tr["phi_hbm_bytes_per_launch"] if tr else None
         roof["traffic_source"] = ({kk: tr.get(kk) for kk in ("source", "commit", "counters")} if tr else None)
         roof["note"] = ("achieved = 32*K bytes x (dense + active-set links of the timed sweeps) / phi time.  The state of this "
-                        "workload (%.1f MB per n-by-k array) is resident in the 256 MB Infinity Cache, so this is a cache-fed "
-                        "rate, not HBM traffic: see hbm_bound for the HBM figure" % (n * ((k + 15) // 16 * 16) * 8 / 1e6))
+                        "workload (%.1f MB per n-by-k array) is %s" % (
+                            n * ((k + 15) // 16 * 16) * 8 / 1e6,
+                            "resident in the 256 MB Infinity Cache, so this is a cache-fed rate, not HBM traffic: see hbm_bound "
+                            "for the HBM figure" if n * k * 8 < 200e6 else "larger than the 256 MB Infinity Cache"))
         out["roofline"] = roof
-        if restarts:
-            out["single_chain"] = {"value": L * args.steps / elapsed, "unit": "edge-updates/s",
-                                   "note": "rank 0's chain alone (the N=1 workload); `value` sums the %d chains" % world}
-        g, lam, conv = eng.state()
-        out["config"]["converged_nodes_at_end"] = int((conv > 0).sum())
-        # how the last sweep's links were evaluated (src/linksampling.cc:622-719): full softmax, active-set
-        # (sparse) path (_iter > 1000 only), O(1) shortcut of links with exactly one converged endpoint
-        out["config"]["links_last_sweep"] = {"dense": int(ctrl.links_dense), "sparse": int(ctrl.links_sparse),
-                                             "shortcut": int(ctrl.links_shortcut)}
-        if world == 1 and not shard and n * k * 8 < 256e6:
+        if exch is not None:
+            out["exchange"] = {"ms_per_sweep": exch[0] / max(args.steps, 1),
+                               "note": "hipEvent time of the RCCL collectives on the engine stream (3 event brackets per sweep)"}
+        if world == 1 and n * k * 8 < 256e6:
             try:
                 out["roofline_dense_only"] = dense_only_window(setup, k, local_rank)
             except Exception as exc:
@@ -404,27 +398,24 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
-    # The hipEvents around k_phi force eager launches (8 per sweep).  Without per-kernel timing
-    # svils_sweep replays whole sweeps as hipGraphs; report that throughput over the SAME sweep
-    # window next to `value` (a fresh engine from the same seeded inputs).
-    if rank == 0 and not shard and not args.no_kernel_events:
-        try:
-            eng2 = setup.engine(use_validation_stop=False, device=local_rank)
-            eng2.sweep(args.warmup)
-            eng2.synchronize(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            eng2.sweep(args.steps)
-            eng2.synchronize(); torch.cuda.synchronize()
-            el2 = time.perf_counter() - t1
-            out["graph_replay"] = {"value": L * args.steps / el2, "unit": "edge-updates/s",
-                                   "ms_per_step": el2 / args.steps * 1e3,
-                                   "note": "same workload and sweep window, no per-kernel events, "
-                                           "svils_sweep replays 8-sweep hipGraphs"}
-            eng2.close()
-        except Exception as exc:
-            out["graph_replay"] = {"error": repr(exc)[:200]}
+        # The hipEvents around the phi launch force eager launches for the sampled sweeps.  Without per-kernel
+        # timing svils_sweep replays whole sweeps as hipGraphs; report that throughput over the SAME sweep
+        # window next to `value` (a fresh engine from the same seeded inputs).
+        if world == 1 and not args.no_kernel_events:
+            try:
+                eng2 = setup.engine(use_validation_stop=False, device=local_rank)
+                eng2.sweep(args.warmup)
+                el2 = _timed(eng2, eng2, args.steps, None, torch)
+                out["graph_replay"] = {"value": L * args.steps / el2, "unit": "edge-updates/s",
+                                       "ms_per_step": el2 / args.steps * 1e3,
+                                       "note": "same workload and sweep window, no per-kernel events, "
+                                               "svils_sweep replays 8-sweep hipGraphs"}
+                eng2.close()
+            except Exception as exc:
+                out["graph_replay"] = {"error": repr(exc)[:200]}
+
     # The one JSON line is owed to the driver whatever happens below: a watchdog emits it (without the
-    # optional extra) and leaves if the extra measurement or the teardown ever blocks on a collective.
+    # side records) and leaves if a side measurement or the teardown ever blocks on a collective.
     import threading
     emit_lock = threading.Lock()
     state = {"emitted": False}
@@ -441,7 +432,7 @@ def main():
     def watchdog():
         if not finished.wait(timeout=args.extra_timeout):
             if rank == 0:
-                out.setdefault("sharded_path", {"error": "timed out after %d s" % args.extra_timeout})
+                out.setdefault("sharded_extra", {"error": "timed out after %d s" % args.extra_timeout})
             emit()
             sys.stderr.write("bench.py: rank %d left on the watchdog\n" % rank)
             sys.stderr.flush()
@@ -450,29 +441,31 @@ def main():
     if world > 1:
         threading.Thread(target=watchdog, daemon=True).start()
 
-    # N>1 and the main run was replicated: also time the node-block sharded path (RCCL
-    # exchanges) on the same problem, reported next to `value`, never instead of it.
-    if world > 1 and not shard and dist is not None and not args.no_sharded_extra:
-        sh = {}
-        try:
-            from svinet_amd.sharded import HipShard, ShardedSweep
-            shard2 = HipShard(setup0, rank, world, local_rank, use_validation_stop=False)
-            run2 = ShardedSweep(shard2, dist)
-            nst = min(args.steps, 50)
-            run2.sweep(args.warmup)
-            shard2.engine.synchronize(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run2.sweep(nst)
-            shard2.engine.synchronize(); torch.cuda.synchronize()
-            el2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-            dist.all_reduce(el2, op=dist.ReduceOp.MAX)
-            sh = {"value": int(setup0.nlinks) * nst / float(el2.item()), "unit": "edge-updates/s", "steps": nst,
-                  "ms_per_step": float(el2.item()) / nst * 1e3,
-                  "parallelism": "node-block sharding x%d, RCCL all-reduce/all-gather per sweep" % world}
-        except Exception as exc:  # the main measurement must survive a failure here
-            sh = {"error": repr(exc)[:300]}
+    # N > 1 side records: the same sharded driver on the workloads SURVEY 8e expects to scale -- BASELINE
+    # config 4 (ca-AstroPh K=200) and the HBM-bound size (n=2e5, k=512) -- one chain over the N ranks each.
+    if world > 1 and not args.no_extra:
+        extra = {}
+        for name, wl, wsteps in (("config4_astroph_k200", "astroph-k200", 50), ("hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10)):
+            try:
+                s2, p2, _, n2, k2, _ = _load_workload(wl)
+                r2 = _Sharded(s2, rank, world, local_rank, dist)
+                r2.sweep(3)
+                r2.eng.enable_timing((1 << _svils.KERNEL_PHI) | (1 << _svils.KERNEL_EXCHANGE), 1)
+                el2 = _timed(r2, r2.eng, wsteps, dist, torch)
+                if rank == 0:
+                    tm = r2.eng.timing()
+                    extra[name] = {"value": int(s2.nlinks) * wsteps / el2, "unit": "edge-updates/s", "steps": wsteps,
+                                   "ms_per_step": el2 / wsteps * 1e3, "n": n2, "k": k2, "links": int(s2.nlinks),
+                                   "phi_us_rank0": tm["phi"][0] / max(tm["phi"][1], 1) * 1e3,
+                                   "exchange_ms_per_sweep_rank0": tm["exchange"][0] / wsteps}
+                r2.eng.close()
+                s2.close()
+                if p2:
+                    os.unlink(p2)
+            except Exception as exc:  # the main measurement must survive a failure here
+                extra[name] = {"error": repr(exc)[:300]}
         if rank == 0:
-            out["sharded_path"] = sh
+            out["sharded_extra"] = extra
     if path:
         os.unlink(path)
     if dist is not None:

@@ -203,6 +203,7 @@ enum {
   SVILS_KERNEL_VALIDATION /* part of the tail kernel since ABI 2: never timed */,
   SVILS_KERNEL_REDUCE_S, SVILS_KERNEL_TAIL /* likelihood + lambda + stop rule */,
   SVILS_KERNEL_CLASSIFY /* stand-alone link classification (k <= 32; normally fused into the s3 launch) */,
+  SVILS_KERNEL_EXCHANGE /* the RCCL collectives of svils_sweep_sharded */,
   SVILS_KERNEL_COUNT
 };
 /* mask: bit i set = bracket kernel i with hipEvents on the library's stream */
@@ -244,13 +245,35 @@ typedef enum {
   SVILS_BUF_CONV,         /* uint32[n_pad] new converged flags                      */
   SVILS_BUF_ACTIVE,       /* uint32[n_pad] active_comms                             */
   SVILS_BUF_AMASK,        /* uint64[n_pad][kw] active-set bitmask                   */
-  SVILS_BUF_MEMBER        /* uint64[n_pad][kw] community bitmask                    */
+  SVILS_BUF_MEMBER,       /* uint64[n_pad][kw] community bitmask                    */
+  SVILS_BUF_XFLAGS        /* uint32[n_pad][2+2kw] new converged flag, active_comms and active-set
+                             bitmask of every row, packed by phase B: all-gather THIS by node block
+                             (instead of CONV/ACTIVE/AMASK); PHASE_EXPAND unpacks the others' rows */
 } svils_buffer;
 /* device pointer + geometry of an exchange buffer (valid until destroy) */
 int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr,
                         size_t *bytes, size_t *row_bytes);
 /* the hipStream_t the library launches on, as void* */
 int svils_stream(svils_handle *h, void **stream);
+
+/* ---- native multi-GPU driver: one process per GPU, RCCL over xGMI ------------------------------
+ * The reference has no distributed path; its one reduce analogue is the in-process sum of per-thread
+ * partials in MMSBInfer::multithreaded_process (src/mmsbinfer.cc:1770-1827).  Here every process
+ * creates its handle on its own GPU with the node block of its rank (svils_config node_begin /
+ * node_end = [rank*B, min(n, (rank+1)*B)), n_alloc = world*B, B = ceil(n/world)) and the library
+ * issues the exchanges itself, on the handle's stream, between the phases of a sweep:
+ *   phi pass -> all-reduce(sum) -> finalise -> all-gather(gamma rows, packed flags) -> expand ->
+ *   s3 pass -> all-reduce(s1,s2,s3) -> tail (replicated).
+ * librccl is loaded at run time (dlopen) the first time one of these entry points is used. */
+#define SVILS_COMM_ID_BYTES 128
+/* rank 0: a fresh ncclUniqueId to hand to every rank (any transport: pipe, file, MPI, torch store) */
+int svils_comm_unique_id(void *id128);
+/* collective over all ranks: ncclCommInitRank on the handle's device */
+int svils_comm_init(svils_handle *h, const void *id128, int rank, int world);
+/* Enqueue `nsweeps` sharded sweeps (asynchronous, like svils_sweep).  Collective. */
+int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps);
+/* all-gather of the community bitmasks before svils_get_communities on a sharded handle.  Collective. */
+int svils_gather_communities(svils_handle *h);
 
 const char *svils_last_error(void);
 int svils_abi_version(void);

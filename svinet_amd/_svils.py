@@ -12,8 +12,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVILS_LIB", os.path.join(_HERE, "lib", "libsvils.so"))  # SVILS_LIB: A/B kernel builds
 
-KERNEL_NAMES = ("phi", "reduce_sum", "finalize", "s3", "validation", "reduce_s", "tail", "classify")
+KERNEL_NAMES = ("phi", "reduce_sum", "finalize", "s3", "validation", "reduce_s", "tail", "classify", "exchange")
 KERNEL_PHI = 0
+KERNEL_EXCHANGE = 8
 
 # every symbol include/svils.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -25,6 +26,7 @@ EXPORTS = (
     "svils_stream", "svils_last_error", "svils_abi_version", "svils_debug_eval",
     "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default", "svils_step_phase", "svils_step_window",
     "svils_get_sweep_stats", "svils_get_timed_links",
+    "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
 )
 
 
@@ -110,6 +112,10 @@ def load():
     L.svils_set_timing_period.argtypes = [vp, C.c_uint32]
     L.svils_get_sweep_stats.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.svils_get_timed_links.argtypes = [vp, vp]
+    L.svils_comm_unique_id.argtypes = [vp]
+    L.svils_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.svils_sweep_sharded.argtypes = [vp, C.c_uint32]
+    L.svils_gather_communities.argtypes = [vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -124,7 +130,15 @@ def _chk(rc):
 
 
 BUF_KVEC_A, BUF_KVEC_C, BUF_GAMMA, BUF_ELOGPI, BUF_MPHI, BUF_CONV, BUF_ACTIVE, BUF_AMASK, \
-    BUF_MEMBER = range(9)
+    BUF_MEMBER, BUF_XFLAGS = range(10)
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rank 0: a fresh ncclUniqueId (bytes) for Engine.comm_init on every rank"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(load().svils_comm_unique_id(buf))
+    return buf.raw
 PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND = range(5)
 
 
@@ -286,6 +300,17 @@ class Engine:
         out = np.zeros(3, dtype=np.uint64)
         _chk(load().svils_get_timed_links(self._h, out.ctypes.data))
         return out
+
+    # ---- native multi-GPU driver (RCCL inside the library) ----
+    def comm_init(self, comm_id, rank, world):
+        assert len(comm_id) == COMM_ID_BYTES
+        _chk(load().svils_comm_init(self._h, C.c_char_p(comm_id), rank, world))
+
+    def sweep_sharded(self, nsweeps=1):
+        _chk(load().svils_sweep_sharded(self._h, nsweeps))
+
+    def gather_communities(self):
+        _chk(load().svils_gather_communities(self._h))
 
     def device_buffer(self, which):
         p, b, r = C.c_void_p(), C.c_size_t(), C.c_size_t()

@@ -14,6 +14,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: librccl is dlopen()ed on first use
+
 #include "svils_internal.h"
 
 using namespace svils;
@@ -58,6 +61,9 @@ struct svils_handle {
   bool cls_valid = false;
   void *cls_zero = nullptr;      // ltot + shist + scan descriptors, one contiguous block
   size_t cls_zero_bytes = 0;
+  // native multi-GPU driver (svils_comm_init)
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
   std::vector<uint32_t> timed_sweeps;   // sweeps_done index of every sweep whose phi launch was bracketed
   uint64_t sweeps_issued = 0;           // sweeps enqueued so far (== DevCtrl.sweeps_done unless stopped)
   // hipGraph replay of whole sweeps (host launch cost: 8 launches x ~7 us per sweep eager)
@@ -235,7 +241,7 @@ int svils_abi_version(void) { return SVILS_ABI_VERSION; }
 
 const char *svils_kernel_name(int k) {
   static const char *names[SVILS_KERNEL_COUNT] = {"phi", "reduce_sum", "finalize", "s3",
-                                                  "validation", "reduce_s", "tail", "classify"};
+                                                  "validation", "reduce_s", "tail", "classify", "exchange"};
   return (k >= 0 && k < SVILS_KERNEL_COUNT) ? names[k] : "?";
 }
 
@@ -315,6 +321,8 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.active_cnt, g.n_alloc));
   guard(dalloc(h, &d.amask, (size_t)g.n_alloc * g.kw));
   guard(dalloc(h, &d.member, (size_t)g.n_alloc * g.kw));
+  d.xf_ld = 2u + 2u * g.kw;
+  guard(dalloc(h, &d.xflags, (size_t)g.n_alloc * d.xf_ld));
   guard(dalloc(h, &d.lambda, 2 * (size_t)g.K));
   guard(dalloc(h, &d.elogbeta, 2 * (size_t)g.K));
   guard(dalloc(h, &d.kvec_a, g.K));
@@ -360,6 +368,142 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   return 0;
 }
 
+// ---------------------------------------------------------------- RCCL, bound at run time
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(SVILS_ERR_UNSUPPORTED, "librccl not found (%s): the multi-GPU driver needs RCCL", dlerror());
+#define BIND(F)                                                                        \
+  do {                                                                                 \
+    *(void **)(&g_rccl.F) = dlsym(lib, "nccl" #F);                                     \
+    if (!g_rccl.F) return fail(SVILS_ERR_UNSUPPORTED, "librccl lacks nccl" #F);        \
+  } while (0)
+  BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather);
+  BIND(GroupStart); BIND(GroupEnd); BIND(GetErrorString);
+#undef BIND
+  g_rccl.lib = lib;
+  return 0;
+}
+
+#define NCCLCHK(expr)                                                                          \
+  do {                                                                                         \
+    ncclResult_t r_ = (expr);                                                                  \
+    if (r_ != ncclSuccess) return fail(SVILS_ERR_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+void comm_destroy(svils_handle *h) {
+  if (h->comm && g_rccl.lib) (void)g_rccl.CommDestroy(h->comm);
+  h->comm = nullptr;
+}
+}  // namespace
+
+int svils_comm_unique_id(void *id128) {
+  if (!id128) return fail(SVILS_ERR_ARG, "svils_comm_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == SVILS_COMM_ID_BYTES, "ncclUniqueId size");
+  int rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SVILS_ERR_ARG, "svils_comm_init: bad argument");
+  if (h->comm) return fail(SVILS_ERR_ARG, "svils_comm_init: communicator already initialised");
+  const Geometry &g = h->geo;
+  const uint32_t B = (g.n + (uint32_t)world - 1) / (uint32_t)world;
+  if (g.n_alloc != B * (uint32_t)world || g.node_begin != std::min(g.n, (uint32_t)rank * B) ||
+      g.node_end != std::min(g.n, ((uint32_t)rank + 1) * B))
+    return fail(SVILS_ERR_ARG, "svils_comm_init: rank %d of %d needs node block [%u,%u) and n_alloc %u (handle has [%u,%u), %u)",
+                rank, world, std::min(g.n, (uint32_t)rank * B), std::min(g.n, ((uint32_t)rank + 1) * B), B * world,
+                g.node_begin, g.node_end, g.n_alloc);
+  if (h->stoch) return fail(SVILS_ERR_UNSUPPORTED, "svils_comm_init: mini-batch steps are exchanged by the caller (svils_step_phase)");
+  int rc = rccl_load();
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  NCCLCHK(g_rccl.CommInitRank(&h->comm, world, id, rank));
+  h->rank = rank;
+  h->world = world;
+  return 0;
+}
+
+namespace {
+// the exchanges of one sharded sweep: K-vector all-reduces are latency-bound, the row
+// gather carries N*ld*8 bytes; both all-gathers are in place (send block = own slice of the receive buffer)
+int exchange_sum(svils_handle *h, double *v, size_t count) {
+  if (!h->comm) return 0;
+  Timed t(h, SVILS_KERNEL_EXCHANGE);
+  NCCLCHK(g_rccl.AllReduce(v, v, count, ncclDouble, ncclSum, h->comm, h->stream));
+  return 0;
+}
+int exchange_rows(svils_handle *h) {
+  if (!h->comm) return 0;
+  Timed t(h, SVILS_KERNEL_EXCHANGE);
+  const Geometry &g = h->geo;
+  const DeviceState &d = h->d;
+  const size_t B = g.n_alloc / (size_t)h->world;
+  NCCLCHK(g_rccl.GroupStart());
+  NCCLCHK(g_rccl.AllGather(d.gamma + (size_t)h->rank * B * g.ld, d.gamma, B * g.ld, ncclDouble, h->comm, h->stream));
+  NCCLCHK(g_rccl.AllGather(d.xflags + (size_t)h->rank * B * d.xf_ld, d.xflags, B * d.xf_ld, ncclUint32, h->comm, h->stream));
+  NCCLCHK(g_rccl.GroupEnd());
+  return 0;
+}
+}  // namespace
+
+int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: null handle");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: set graph and state first");
+  if (!h->comm && h->world != 1) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: call svils_comm_init first");
+  if (!h->comm && !(h->geo.node_begin == 0 && h->geo.node_end == h->geo.n))
+    return fail(SVILS_ERR_ARG, "svils_sweep_sharded: a node-block handle needs svils_comm_init");
+  if (h->stoch) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: the handle is in mini-batch mode");
+  if (nsweeps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
+    return fail(SVILS_ERR_ARG, "svils_sweep_sharded: at most %llu sweeps per call",
+                (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const Geometry &g = h->geo;
+  for (uint32_t i = 0; i < nsweeps; ++i) {
+    int rc;
+    if ((rc = run_phase(h, SVILS_PHASE_A, false))) return rc;
+    if ((rc = exchange_sum(h, h->d.kvec_a, g.K))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_B, false))) return rc;
+    if ((rc = exchange_rows(h))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_EXPAND, false))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
+    if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
+    if ((rc = run_phase(h, SVILS_PHASE_D, false))) return rc;
+  }
+  return 0;
+}
+
+int svils_gather_communities(svils_handle *h) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_gather_communities: null handle");
+  if (!h->comm) return h->world == 1 ? 0 : fail(SVILS_ERR_ARG, "svils_gather_communities: call svils_comm_init first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const Geometry &g = h->geo;
+  const size_t B = g.n_alloc / (size_t)h->world;
+  NCCLCHK(g_rccl.AllGather(h->d.member + (size_t)h->rank * B * g.kw, h->d.member, B * g.kw, ncclUint64, h->comm, h->stream));
+  return 0;
+}
+
 int svils_destroy(svils_handle *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->cfg.device);
@@ -369,6 +513,7 @@ int svils_destroy(svils_handle *h) {
   for (auto &ev : h->freelist) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
   if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
+  comm_destroy(h);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1113,6 +1258,7 @@ int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr, size_t
     case SVILS_BUF_ACTIVE: *dptr = d.active_cnt; *row_bytes = sizeof(uint32_t); *bytes = (size_t)g.n_alloc * sizeof(uint32_t); return 0;
     case SVILS_BUF_AMASK: *dptr = d.amask; *row_bytes = g.kw * sizeof(uint64_t); *bytes = *row_bytes * g.n_alloc; return 0;
     case SVILS_BUF_MEMBER: *dptr = d.member; *row_bytes = g.kw * sizeof(uint64_t); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_XFLAGS: *dptr = d.xflags; *row_bytes = d.xf_ld * sizeof(uint32_t); *bytes = *row_bytes * g.n_alloc; return 0;
     default: return fail(SVILS_ERR_ARG, "svils_device_buffer: unknown buffer %d", (int)which);
   }
 }

@@ -429,10 +429,19 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
 #pragma unroll
     for (int o = 1; o < W; o <<= 1) last_k = max(last_k, __shfl_xor(last_k, o, 64));
     if (lw == 0) {
-      conv_new[p] = (active == 1) ? (uint32_t)last_k + 1u : conv_old[p];
+      const uint32_t cnew = (active == 1) ? (uint32_t)last_k + 1u : conv_old[p];
+      conv_new[p] = cnew;
       d.active_cnt[p] = active;
+      uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;   // the same flags, packed for the node-block exchange
+      xf[0] = cnew;
+      xf[1] = active;
 #pragma unroll
-      for (int v = 0; v < V; ++v) d.amask[(size_t)p * geo.kw + v] = (active <= geo.k10) ? bits[v] : 0ull;
+      for (int v = 0; v < V; ++v) {
+        const unsigned long long am = (active <= geo.k10) ? bits[v] : 0ull;
+        d.amask[(size_t)p * geo.kw + v] = am;
+        xf[2 + 2 * v] = (uint32_t)am;
+        xf[3 + 2 * v] = (uint32_t)(am >> 32);
+      }
     }
   }
   block_reduce_store<W, V, 2>(s12, d.part_b + (size_t)blockIdx.x * 2 * K, K, lds);
@@ -464,6 +473,18 @@ __global__ __launch_bounds__(256) void k_dir_exp(Geometry geo, DeviceState d) {
     for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
   }
+}
+
+// Multi-GPU: the converged / active flags of a row another rank owns, from its packed xflags row
+// (gathered after phase B) into the arrays the kernels read
+template <int V>
+__device__ __forceinline__ void unpack_flags(const Geometry &geo, const DeviceState &d, const DevCtrl *ctrl, uint32_t p) {
+  const uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;
+  d.conv[(size_t)(ctrl->parity ^ 1u) * geo.n_alloc + p] = xf[0];
+  d.active_cnt[p] = xf[1];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    d.amask[(size_t)p * geo.kw + v] = (unsigned long long)xf[2 + 2 * v] | ((unsigned long long)xf[3 + 2 * v] << 32);
 }
 
 // Multi-GPU: Elogpi and mphi of the rows this handle does not own, re-derived from the
@@ -509,6 +530,7 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
     }
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+    if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
   }
 }
 
@@ -674,6 +696,7 @@ __global__ __launch_bounds__(256) void k_expand_window(Geometry geo, DeviceState
 #pragma unroll
     for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
   }
 }
 

@@ -104,6 +104,9 @@ struct DeviceState {
   uint32_t *active_cnt; // [n_alloc]
   uint64_t *amask;      // [n_alloc][kw] lane-layout bitmask of _active_k
   uint64_t *member;     // [n_alloc][kw] lane-layout bitmask of communities
+  uint32_t *xflags;     // [n_alloc][xf_ld] conv (new), active_cnt, amask words of every row, packed: ONE buffer to
+                        // all-gather after phase B; PHASE_EXPAND unpacks the other ranks' rows
+  uint32_t xf_ld;       // 2 + 2 * kw
   double *lambda;       // [K][2]
   double *elogbeta;     // [K][2]
   // K-vectors / partials

@@ -399,9 +399,13 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
     const unsigned long long bits = (__ballot(act) >> (g * W)) & ((1ull << W) - 1ull);
     const uint32_t active = (uint32_t)__popcll(bits);
     if (lw == 0) {
-      conv_new[p] = (active == 1) ? (uint32_t)(63 - __builtin_clzll(bits)) + 1u : conv_old[p];
+      const uint32_t cnew = (active == 1) ? (uint32_t)(63 - __builtin_clzll(bits)) + 1u : conv_old[p];
+      const unsigned long long am = (active <= geo.k10) ? bits : 0ull;
+      conv_new[p] = cnew;
       d.active_cnt[p] = active;
-      d.amask[(size_t)p * geo.kw] = (active <= geo.k10) ? bits : 0ull;
+      d.amask[(size_t)p * geo.kw] = am;
+      uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;   // the same flags, packed for the node-block exchange
+      xf[0] = cnew; xf[1] = active; xf[2] = (uint32_t)am; xf[3] = (uint32_t)(am >> 32);
     }
   }
   STAMP(1, 3);

@@ -45,6 +45,10 @@ class Env {
     uint32_t minibatch = 0;     // nodes per mini-batch
     double tau0 = 1024, kappa = 0.9, nodetau0 = 1024, nodekappa = 0.5;   // src/env.hh:405-408
     int32_t sparse_after = 1000;   // the active-set branch needs _iter > this (src/linksampling.cc:634)
+    // -gpus N: one process per GPU (forked by main), node-block sharding with RCCL exchanges inside
+    // the device library (svils_sweep_sharded); rank 0 writes the files
+    int gpus = 1, rank = 0;
+    std::string comm_file;      // where rank 0 leaves the ncclUniqueId for the others
   };
 
   explicit Env(const Args &a);
@@ -73,6 +77,8 @@ class Env {
   bool nmi;
   std::string ground_truth_fname;
   std::string datfname, label;
+  int gpus, rank;
+  std::string comm_file;
   bool batch_mode, link_sampling;
   bool strid;
   volatile int terminate;

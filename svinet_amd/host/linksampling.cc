@@ -4,6 +4,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <unistd.h>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
@@ -161,7 +162,32 @@ void LinkSampling::attach() {
   cfg.zeros_prob = zeros_prob_;
   cfg.device = env_.device;
   cfg.sparse_after_iter = env_.sparse_after;
+  if (env_.gpus > 1) {   // -gpus N: this process owns the node block of its rank
+    const uint32_t B = (n_ + (uint32_t)env_.gpus - 1) / (uint32_t)env_.gpus;
+    cfg.node_begin = std::min(n_, (uint32_t)env_.rank * B);
+    cfg.node_end = std::min(n_, ((uint32_t)env_.rank + 1) * B);
+    cfg.n_alloc = B * (uint32_t)env_.gpus;
+  }
   if (svils_create(&cfg, &h_)) die_svils("svils_create");
+  if (env_.gpus > 1) {
+    // rank 0 makes the ncclUniqueId and leaves it in comm_file (written aside, then renamed: readers
+    // never see a partial file); the other ranks wait for it.  Then the collective communicator init.
+    unsigned char id[SVILS_COMM_ID_BYTES];
+    if (env_.rank == 0) {
+      if (svils_comm_unique_id(id)) die_svils("svils_comm_unique_id");
+      const std::string tmp = env_.comm_file + ".tmp";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); exit(-1); }
+      fclose(f);
+      if (rename(tmp.c_str(), env_.comm_file.c_str())) { perror("rename"); exit(-1); }
+    } else {
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 6000 && !(f = fopen(env_.comm_file.c_str(), "rb")); ++tries) usleep(10000);
+      if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "rank %d: no communicator id in %s\n", env_.rank, env_.comm_file.c_str()); exit(-1); }
+      fclose(f);
+    }
+    if (svils_comm_init(h_, id, env_.rank, env_.gpus)) die_svils("svils_comm_init");
+  }
   if (env_.minibatch) {
     // random relabelling (own generator: the GSL stream of the samplers / init is not disturbed)
     std::mt19937_64 eng(0x5eed5eedull + (uint64_t)env_.seed);
@@ -479,6 +505,8 @@ void LinkSampling::log_communities() {                     // :839-852, :882-917
 }
 
 void LinkSampling::do_on_stop() {                          // src/linksampling.cc:792-802
+  // -gpus N: every rank takes part in the gather of the community bitmasks, rank 0 writes
+  if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
   if (!env_.write_files) return;
   log_communities();
   save_model();
@@ -547,17 +575,22 @@ int LinkSampling::infer() {
     fflush(stdout);
     if (env_.minibatch) {
       if (svils_step(h_, batch)) die_svils("svils_step");
+    } else if (env_.gpus > 1) {
+      if (svils_sweep_sharded(h_, batch)) die_svils("svils_sweep_sharded");
     } else if (svils_sweep(h_, batch)) {
       die_svils("svils_sweep");
     }
     fetch_and_log_rows();
     if (svils_get_control(h_, &c)) die_svils("svils_get_control");
-    if (env_.write_files && !c.stopped) log_communities();        // :785
+    if (!c.stopped) {                                             // :785 (the control block is replicated: same branch on every rank)
+      if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
+      if (env_.write_files) log_communities();
+    }
     if (c.stopped) {                                              // :1044-1048
       do_on_stop();
       return 1;
     }
-    if (env_.terminate) {                                         // :763-766 (SIGTERM)
+    if (env_.terminate && env_.gpus == 1) {                       // :763-766 (SIGTERM; -gpus N: per-process, would split the ranks)
       do_on_stop();
       env_.terminate = 0;
     }

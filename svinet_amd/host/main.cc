@@ -7,10 +7,13 @@
 // flags that select the reference's other engines are recognised and rejected
 // with a message instead of being silently ignored.
 #include <csignal>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "env.hh"
 #include "linksampling.hh"
@@ -54,6 +57,8 @@ static void usage() {
           "\t-nmi <file>\tground-truth communities (\"node<TAB>community ...\" per line): the normalised mutual\n"
           "\t\t\tinformation of every communities.txt against it is appended to mutual.txt\n\n"
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
+          "\t-gpus <N>\t-link-sampling over N GPUs of this node: one process per GPU (devices d .. d+N-1), node-block\n"
+          "\t\t\tsharding, RCCL all-reduce / all-gather over xGMI between the phases of a sweep\n\n"
           "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
           "\t-sparse-after <i>\tthe active-set branch of the phi pass is used once the iteration count exceeds i\n"
           "\t\t\t(default 1000, the reference's constant)\n\n"
@@ -105,6 +110,7 @@ int main(int argc, char **argv) {
     else if (is("-lt-min-deg")) { need(i); a.lt_min_deg = atof(argv[++i]); }
     else if (is("-strid")) { a.strid = true; }
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
+    else if (is("-gpus")) { need(i); a.gpus = atoi(argv[++i]); }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
     else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
     else if (is("-sparse-after")) { need(i); a.sparse_after = atoi(argv[++i]); }
@@ -139,6 +145,50 @@ int main(int argc, char **argv) {
     return -1;
   }
 
+  // -gpus N: fork one process per GPU before anything touches the HIP runtime.  Every rank reads the
+  // graph and runs the (seeded, deterministic) host-side initialisation itself; rank 0 owns the output
+  // directory and the files, the others compute their node block only.
+  if (a.link_sampling && a.gpus > 1) {
+    if (a.minibatch) {
+      fprintf(stderr, "error: -gpus with -minibatch is not available from the command line\n");
+      return -1;
+    }
+    char tmpl[] = "/tmp/svinet-comm-XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) { perror("mkstemp"); return -1; }
+    close(fd);
+    unlink(tmpl);                      // rank 0 re-creates it atomically once the id is in it
+    a.comm_file = tmpl;
+    std::vector<pid_t> kids;
+    const int dev0 = a.device;
+    for (int r = 0; r < a.gpus; ++r) {
+      const pid_t pid = fork();
+      if (pid < 0) { perror("fork"); return -1; }
+      if (pid == 0) {
+        a.rank = r;
+        a.device = dev0 + r;
+        if (r > 0) a.write_files = false;
+        kids.clear();
+        goto run;
+      }
+      kids.push_back(pid);
+    }
+    {
+      int rc = 0;
+      for (size_t r = 0; r < kids.size(); ++r) {
+        int st = 0;
+        waitpid(kids[r], &st, 0);
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if (code != 0 && rc == 0) {
+          rc = code;
+          for (pid_t k : kids) kill(k, SIGKILL);   // a rank died: the others would wait in a collective for ever
+        }
+      }
+      unlink(tmpl);
+      return rc;
+    }
+  }
+run:
   Env env(a);
   env_global = &env;
   Network network(env);

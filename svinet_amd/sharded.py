@@ -8,16 +8,21 @@ multi-GPU form of the sums inside LinkSampling::infer()
 (src/linksampling.cc:605-761):
 
   phase A  phi pass over owned rows      -> all-reduce(SUM)  `sum[k]`           (K doubles)
-  phase B  mean indicators, new gamma,   -> all-gather by node block of the gamma rows
-           Elogpi, prune over owned rows    + converged / active flags (ONE n-by-k array)
-  EXPAND   Elogpi = psi(gamma)-psi(sum) and m = (gamma/scale - alpha)/(n-1) of the rows owned
-           by other ranks, re-derived locally from the gathered gamma (no exchange)
+  phase B  mean indicators, new gamma,   -> all-gather by node block of the gamma rows (ONE n-by-k
+           Elogpi, prune over owned rows    array) and of the packed flags (converged, active count,
+                                            active-set mask: ONE small buffer, SVILS_BUF_XFLAGS)
+  EXPAND   flags of the other ranks' rows unpacked; their Elogpi = psi(gamma)-psi(sum) and
+           m = (gamma/scale - alpha)/(n-1) re-derived locally from the gathered gamma (no exchange)
   phase C  s3 pass over owned upper rows -> all-reduce(SUM)  s1,s2,s3          (3K doubles)
   phase D  lambda, likelihood, stop rule    (replicated, identical on every rank)
 
-The collectives are `torch.distributed` calls (backend "nccl" == RCCL over
-xGMI on ROCm; "gloo" for the CPU protocol tests) on tensors that alias the
-engine's device buffers, issued on the engine's own HIP stream.
+Two drivers run this protocol.  The native one lives in the library
+(svils_comm_init / svils_sweep_sharded: RCCL calls on the engine's stream, no Python
+between the phases) and is what bench.py and the C++ CLI (`-gpus N`) use.  The one in
+this file issues the same exchanges as `torch.distributed` calls (backend "nccl" ==
+RCCL over xGMI on ROCm; "gloo" for the CPU protocol tests and for several ranks on one
+GPU) on tensors that alias the engine's device buffers, on the engine's own HIP stream;
+it also drives the mini-batch steps.
 """
 import numpy as np
 
@@ -77,28 +82,21 @@ class HipShard:
             self.rows.append(ten.view(self.n_alloc, rb // 8))
         ten, rb = t(_svils.BUF_MPHI, "<f8")   # exchanged only by mini-batch steps
         self.mphi = ten.view(self.n_alloc, rb // 8)
-        conv, _ = t(_svils.BUF_CONV, "<i4")
-        self.conv = conv.view(2, self.n_alloc)
-        act, _ = t(_svils.BUF_ACTIVE, "<i4")
-        self.active = act.view(self.n_alloc, 1)
-        am, rb = t(_svils.BUF_AMASK, "<i8")
-        self.amask = am.view(self.n_alloc, rb // 8)
         mem, rb = t(_svils.BUF_MEMBER, "<i8")
         self.member = mem.view(self.n_alloc, rb // 8)
-        # conv[parity] is the current _converged; parity flips once per completed sweep on the device
-        # (k_tail), so the host mirror starts from the engine's own sweep count
-        self.sweeps = int(self.engine.control().sweeps_done)
+        # converged flag (the half prune() is writing), active count and active-set mask of every row,
+        # packed on the device: the host needs no mirror of the device's buffer parity
+        xf, rb = t(_svils.BUF_XFLAGS, "<i4")
+        self.xflags = xf.view(self.n_alloc, rb // 4)
 
     def phase(self, ph):
         self.engine.sweep_phase(ph)
 
     def gather_list(self):
-        # prune() writes conv[parity ^ 1]; parity flips once per sweep (k_tail)
-        new = (self.sweeps & 1) ^ 1
-        return self.rows + [self.conv[new].view(self.n_alloc, 1), self.active, self.amask]
+        return self.rows + [self.xflags]
 
     def end_sweep(self):
-        self.sweeps += 1
+        pass
 
 
 class ShardedSweep:
@@ -173,8 +171,7 @@ class ShardedStep(ShardedSweep):
                 self._allreduce(s.kvec_a)
                 eng.step_phase(_svils.PHASE_B)
                 b, e = eng.step_window()
-                new = (s.sweeps & 1) ^ 1
-                for t in s.rows + [s.mphi, s.conv[new].view(s.n_alloc, 1), s.active, s.amask]:
+                for t in s.rows + [s.mphi, s.xflags]:
                     self._allgather_window(t, b, e)
                 eng.step_phase(_svils.PHASE_EXPAND)
                 eng.step_phase(_svils.PHASE_C)

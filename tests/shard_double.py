@@ -40,6 +40,7 @@ class NumpyShard:
         self.active = torch.zeros(self.n_alloc, 1, dtype=torch.int32)
         self.amask = torch.zeros(self.n_alloc, 1, dtype=torch.int64)
         self.member = torch.zeros(self.n_alloc, 1, dtype=torch.int64)
+        self.xflags = torch.zeros(self.n_alloc, 4, dtype=torch.int32)   # conv (new), active, amask lo/hi
         self.kvec_a = torch.zeros(k, dtype=torch.float64)
         self.kvec_c = torch.zeros(3 * k, dtype=torch.float64)
         self.lam = np.array(lam, dtype=np.float64)
@@ -50,8 +51,7 @@ class NumpyShard:
 
     # ---- surface shared with HipShard ----
     def gather_list(self):
-        new = (self.sweeps & 1) ^ 1
-        return [self.t_gamma, self.conv[new].view(self.n_alloc, 1), self.active, self.amask]
+        return [self.t_gamma, self.xflags]
 
     def end_sweep(self):
         self.sweeps += 1
@@ -60,10 +60,13 @@ class NumpyShard:
         (self._a, self._b, self._c, self._d, self._expand)[ph]()
 
     def _expand(self):
-        # rows of the other ranks: Elogpi and mphi from the gathered gamma
+        # rows of the other ranks: flags unpacked, Elogpi and mphi from the gathered gamma
         n, lo, hi = self.n, self.lo, self.hi
         oth = np.ones(n, dtype=bool)
         oth[lo:hi] = False
+        xf = self.xflags.numpy()[:n]
+        self.conv[self.parity ^ 1].numpy()[:n][oth] = xf[oth, 0]
+        self.active.numpy()[:n, 0][oth] = xf[oth, 1]
         g = self.t_gamma.numpy()[:n][oth]
         self.t_elogpi.numpy()[:n][oth] = digamma(g) - digamma(g.sum(1, keepdims=True))
         isc = (self.kvec_a.numpy() / self.ones) if self.annealing else 1.0
@@ -107,6 +110,9 @@ class NumpyShard:
         old = self.conv[self.parity].numpy()[lo:hi]
         self.conv[self.parity ^ 1].numpy()[lo:hi] = np.where(cnt == 1, lastk + 1, old)
         self.active.numpy()[lo:hi, 0] = cnt
+        xf = self.xflags.numpy()
+        xf[lo:hi, 0] = self.conv[self.parity ^ 1].numpy()[lo:hi]
+        xf[lo:hi, 1] = cnt
         kc = self.kvec_c.numpy()
         kc[:k] = m[has].sum(0)
         kc[k:2 * k] = (m[has] ** 2).sum(0)

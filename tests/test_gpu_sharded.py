@@ -82,6 +82,43 @@ def test_virtual_ranks_equal_oracle(graph_files, world, k, sweeps):
         assert np.array_equal(s.engine.communities()[lo:hi], want[lo:hi])
 
 
+def test_native_rccl_driver_world1(graph_files):
+    """the library's own multi-GPU driver (svils_comm_init / svils_sweep_sharded: RCCL all-reduce and
+    all-gather on the engine's stream) on a communicator of ONE rank -- the transport this box can
+    run -- equals the caller-driven protocol bit for bit and the plain engine up to summation order."""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    from svinet_amd.sharded import HipShard, ShardedSweep
+    for key, n, k, sweeps in (("lfr", 1000, 28, 40), ("lfr", 1000, 64, 6)):
+        setup = Setup(graph_files[key], n, k)
+        eng = setup.engine(use_validation_stop=False, node_block=(0, n), n_alloc=n)
+        eng.comm_init(_svils.comm_unique_id(), 0, 1)
+        eng.enable_timing(1 << _svils.KERNEL_EXCHANGE)
+        eng.sweep_sharded(sweeps)
+        eng.gather_communities()
+        eng.synchronize()
+        assert eng.timing()["exchange"][1] == 3 * sweeps          # the collectives really ran
+        plain = setup.engine(use_validation_stop=False)
+        plain.sweep(sweeps)
+        a, b = eng.state(), plain.state()
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-10)       # summation order only (fold vs k_colreduce)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-10)
+        assert np.array_equal(a[2], b[2])
+        assert np.array_equal(eng.communities(), plain.communities())
+        np.testing.assert_allclose(eng.rows(), plain.rows(), rtol=1e-10)
+
+        class _NoDist:          # the caller-driven protocol with a world of one: no exchange
+            pass
+        shard = HipShard(setup, 0, 1, 0, use_validation_stop=False)
+        ShardedSweep(shard, _NoDist()).sweep(sweeps)
+        c = shard.engine.state()
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+    # wrong node block for the rank: refused, loudly
+    eng = setup.engine(use_validation_stop=False)
+    with pytest.raises(_svils.SvilsError):
+        eng.comm_init(_svils.comm_unique_id(), 1, 2)
+
+
 def test_sharded_driver_world1(graph_files):
     """ShardedSweep over a real process group of size 1 (nccl == RCCL) equals the plain engine."""
     import os

@@ -90,8 +90,7 @@ class _FakeShard:
         self.engine = _FakeStepEngine(windows)
         mk = lambda c, dt: torch.zeros(self.n_alloc, c, dtype=dt)
         self.rows, self.mphi = [mk(cols, torch.float64)], mk(cols, torch.float64)
-        self.conv = torch.zeros(2, self.n_alloc, dtype=torch.int32)
-        self.active, self.amask = mk(1, torch.int32), mk(1, torch.int64)
+        self.xflags = mk(4, torch.int32)        # packed flags (SVILS_BUF_XFLAGS)
         self.kvec_a, self.kvec_c = torch.zeros(cols, dtype=torch.float64), torch.zeros(3 * cols, dtype=torch.float64)
         self.sweeps = 0
 
@@ -112,13 +111,13 @@ def _step_worker(rank, world, port, B, cols, windows, out):
             lo, hi = rank * B + b, rank * B + e
             sh.rows[0][lo:hi] = 100.0 * (t + 1) + rank
             sh.mphi[lo:hi] = -(100.0 * (t + 1) + rank)
-            sh.conv[(sh.sweeps & 1) ^ 1][lo:hi] = 7 * (t + 1) + rank
+            sh.xflags[lo:hi] = 7 * (t + 1) + rank
             sh.kvec_a[:] = rank + 1.0
             sh.kvec_c[:] = 2.0 * (rank + 1)
             drv.step(1)
             assert sh.kvec_a[0].item() == world * (world + 1) / 2 and sh.kvec_c[0].item() == world * (world + 1)
         assert sh.engine.calls == [0, 1, 4, 2, 3] * len(windows)      # A, B, EXPAND, C, D
-        np.savez(out + ".%d.npz" % rank, gamma=sh.rows[0].numpy(), mphi=sh.mphi.numpy(), conv=sh.conv.numpy())
+        np.savez(out + ".%d.npz" % rank, gamma=sh.rows[0].numpy(), mphi=sh.mphi.numpy(), conv=sh.xflags.numpy())
     finally:
         dist.destroy_process_group()
 
