@@ -260,6 +260,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="N=1: no hipEvents in the timed region (pure hipGraph replay); the roofline then comes from an "
                          "eager pass after it")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="take the N>1 code path (process group, RCCL communicator, sharded driver, side records) with "
+                         "whatever world size there is -- a one-GPU box can exercise it with a world of one")
     ap.add_argument("--no-extra", action="store_true", help="N>1: skip the side records (config 4, HBM-bound size)")
     ap.add_argument("--extra-timeout", type=int, default=240,
                     help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
@@ -276,8 +279,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    multi = world > 1 or args.force_sharded
     dist = None
-    if world > 1:
+    if multi:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -293,7 +297,7 @@ def main():
     # N = 1: the plain engine (hipGraph replay).  N > 1: ONE chain, node-block sharded over the N ranks with
     # the RCCL exchanges inside the timed region -- strong scaling of the metric's own workload, whatever
     # its size (ca-AstroPh K=20 is a ~65 us sweep, four collectives per sweep cannot speed it up).
-    if world == 1:
+    if not multi:
         eng = setup.engine(use_validation_stop=False, device=local_rank)
         runner = eng
     else:
@@ -301,7 +305,7 @@ def main():
         eng = runner.eng
     runner.sweep(args.warmup)
     period = max(1, min(args.event_period, args.steps // 10))   # >= 10 timed launches whenever steps >= 10
-    if world > 1:
+    if multi:
         eng.enable_timing((1 << _svils.KERNEL_PHI) | (1 << _svils.KERNEL_EXCHANGE), 1)
     elif not args.no_kernel_events:
         eng.enable_timing(1 << _svils.KERNEL_PHI, period)
@@ -312,7 +316,7 @@ def main():
     same_window = None
     exch = None
     if rank == 0:
-        if world > 1:
+        if multi:
             exch = eng.timing()["exchange"]
             same_window = _phi_record(eng, k, "every sweep of the timed region (sweeps %d..%d), this rank's node block"
                                       % (args.warmup, args.warmup + args.steps))
@@ -367,13 +371,13 @@ def main():
                        # active-set path (_iter > 1000 only), O(1) shortcut of links with exactly one converged endpoint
                        "links_last_sweep": {"dense": int(ctrl.links_dense), "sparse": int(ctrl.links_sparse),
                                             "shortcut": int(ctrl.links_shortcut),
-                                            "scope": "this rank's node block" if world > 1 else "all links"}},
+                                            "scope": "this rank's node block" if multi else "all links"}},
         }
-        tr = _traffic(args.workload) if world == 1 else None
+        tr = _traffic(args.workload) if not multi else None
         roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 32 else "k_phi (phi pass, A6)"}
         roof.update(same_window)
         roof["timing"] = ("hipEvents around the phi launch on the engine's own stream" +
-                          ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if world == 1 else ""))
+                          ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if not multi else ""))
         roof["traffic"] = tr["phi_hbm_bytes_per_launch"] if tr else None
         roof["traffic_source"] = ({kk: tr.get(kk) for kk in ("source", "commit", "counters")} if tr else None)
         roof["note"] = ("achieved = 32*K bytes x (dense + active-set links of the timed sweeps) / phi time.  The state of this "
@@ -385,23 +389,23 @@ def main():
         if exch is not None:
             out["exchange"] = {"ms_per_sweep": exch[0] / max(args.steps, 1),
                                "note": "hipEvent time of the RCCL collectives on the engine stream (3 event brackets per sweep)"}
-        if world == 1 and n * k * 8 < 256e6:
+        if not multi and n * k * 8 < 256e6:
             try:
                 out["roofline_dense_only"] = dense_only_window(setup, k, local_rank)
             except Exception as exc:
                 out["roofline_dense_only"] = {"error": repr(exc)[:200]}
-        if world == 1 and not args.no_hbm_bound and args.workload != HBM_BOUND_WORKLOAD:
+        if not multi and not args.no_hbm_bound and args.workload != HBM_BOUND_WORKLOAD:
             try:
                 out["hbm_bound"] = hbm_bound_record(local_rank)
             except Exception as exc:
                 out["hbm_bound"] = {"error": repr(exc)[:200]}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
         # The hipEvents around the phi launch force eager launches for the sampled sweeps.  Without per-kernel
         # timing svils_sweep replays whole sweeps as hipGraphs; report that throughput over the SAME sweep
         # window next to `value` (a fresh engine from the same seeded inputs).
-        if world == 1 and not args.no_kernel_events:
+        if not multi and not args.no_kernel_events:
             try:
                 eng2 = setup.engine(use_validation_stop=False, device=local_rank)
                 eng2.sweep(args.warmup)
@@ -438,12 +442,12 @@ def main():
             sys.stderr.flush()
             os._exit(0)
 
-    if world > 1:
+    if multi:
         threading.Thread(target=watchdog, daemon=True).start()
 
     # N > 1 side records: the same sharded driver on the workloads SURVEY 8e expects to scale -- BASELINE
     # config 4 (ca-AstroPh K=200) and the HBM-bound size (n=2e5, k=512) -- one chain over the N ranks each.
-    if world > 1 and not args.no_extra:
+    if multi and not args.no_extra:
         extra = {}
         for name, wl, wsteps in (("config4_astroph_k200", "astroph-k200", 50), ("hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10)):
             try:

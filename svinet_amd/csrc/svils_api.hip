@@ -161,7 +161,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
               bool fused) {
   hipStream_t s = h->stream;
   DeviceState d = d0;
-  d.fold = (fused && d.lpl) ? 1 : 0;
+  d.fold = (fused && d.lpl && g.K <= 32) ? 1 : 0;   // K = 33..64: K-vectors via k_colreduce (2K columns are too wide to fold)
   d.cls_next = (d.lpl && !prm.stoch) ? 1 : 0;
   switch (ph) {
     case SVILS_PHASE_A: {
@@ -350,7 +350,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.sweep_stats, (size_t)d.sweep_stats_cap * 4));
   guard(dalloc(h, &d.stamps, 4 * 1024 * 8));
   guard(dalloc(h, &d.tail_ctl, 4));
-  guard(dalloc(h, &d.tail_part, 128 * 4));
+  guard(dalloc(h, &d.tail_part, 256 * 4));
   d.nb_t = 1;
   if (rc) { svils_destroy(h); return rc; }
   DevCtrl c;
@@ -595,7 +595,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   std::vector<uint32_t> erow;
   if (d.lpl) {
     if (2 * nlinks >= (1ull << 27))
-      return fail(SVILS_ERR_UNSUPPORTED, "k <= 32 supports up to 2^26 training links (got %llu)", (unsigned long long)nlinks);
+      return fail(SVILS_ERR_UNSUPPORTED, "k <= 64 supports up to 2^26 training links (got %llu)", (unsigned long long)nlinks);
     // classification tiles: 1024 entries, more on large graphs so that there are at most ~2048 tiles
     // (the scatter pass adds up the counts of all tiles below its own); erow / col padded to whole tiles
     d.cls_tile = 1024u * (uint32_t)std::max<uint64_t>(1, (2 * nlinks + 1024ull * 2048 - 1) / (1024ull * 2048));
@@ -613,7 +613,8 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     const uint32_t phi_items = d.lpl_nitems;
     d.nb_a = cap((phi_items + nw - 1) / nw, std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_phi_resident_blocks(g.K, h->cfg.device)));
     d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 16 * G - 1) / (16 * G), 256);   // one 16-wave block per CU
-    d.nb_c = cap((d.link_end - d.link_begin + 1023) / 1024, 192);   // + up to 64 count-pass blocks
+    d.s3_threads = lpl_s3_threads(g.K);
+    d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 count-pass blocks
   }
 
   int rc = 0;
@@ -988,7 +989,7 @@ int open_step(svils_handle *h) {
       const uint64_t items = ((d.ent_end - d.ent_begin + 63) >> 6) + 1;
       d.nb_a = fit((items + nw - 1) / nw, h->d.nb_a);
       d.nb_b = fit(((uint64_t)(e - b) + 16 * G - 1) / (16 * G), h->d.nb_b);
-      d.nb_c = fit((d.link_end - d.link_begin + 1023) / 1024, h->d.nb_c);
+      d.nb_c = fit((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, h->d.nb_c);
     } else {
       d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);
       d.nb_c = fit(((uint64_t)d.nitems_s3 + 3) / 4, h->d.nb_c);

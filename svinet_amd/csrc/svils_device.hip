@@ -818,10 +818,36 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
         if (lw == 0) { if (yy[t]) so += u; else { sz += u; kz++; } }
       }
     }
-    for (uint32_t i = i0 + NPRE * istride; i < d.nv; i += istride) {
-      uint32_t y;
-      const double u = pair_loglik<W, V>(d, ld, lw, i, beta, &y);
-      if (lw == 0) { if (y) so += u; else { sz += u; kz++; } }
+    // the remaining pairs, NB at a time per group: all their indices, then all their rows in flight
+    constexpr int NB = V <= 2 ? 4 : (V <= 8 ? 2 : 1);
+    for (uint32_t ib = i0 + NPRE * istride; ib < d.nv; ib += NB * istride) {
+      uint32_t bp[NB], bq[NB], by[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const uint32_t i = ib + t * istride;
+        bp[t] = 0; bq[t] = 0; by[t] = 0;
+        if (i < d.nv) { bp[t] = d.vpairs[3 * (size_t)i]; bq[t] = d.vpairs[3 * (size_t)i + 1]; by[t] = d.vpairs[3 * (size_t)i + 2]; }
+      }
+      double gp[NB][V], gq[NB][V];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        load_row<W, V>(d.gamma + (size_t)bp[t] * ld, lw, ld, gp[t]);
+        load_row<W, V>(d.gamma + (size_t)bq[t] * ld, lw, ld, gq[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        double sp = 0.0, sq = 0.0, dot = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) { sp += gp[t][v]; sq += gq[t][v]; dot += gp[t][v] * gq[t][v] * beta[v]; }
+        sp = group_sum<W>(sp); sq = group_sum<W>(sq); dot = group_sum<W>(dot);
+        if (ib + t * istride < d.nv) {
+          const double pq = dot / (sp * sq);
+          double sv = by[t] ? pq : 1.0 - pq;
+          if (sv < 1e-30) sv = 1e-30;
+          const double u = log(sv);
+          if (lw == 0) { if (by[t]) so += u; else { sz += u; kz++; } }
+        }
+      }
     }
   }
   STAMP(3, 3);
@@ -846,7 +872,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   STAMP(3, 5);
 
   // ---- last block only ----
-  // the blocks' partial sums: one thread per block, then a fixed-order tree (nb_t <= 128)
+  // the blocks' partial sums: one thread per block, then a fixed-order tree (nb_t <= 256)
   sz = 0.0; so = 0.0;
   double kzd = 0.0;
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -1138,7 +1164,7 @@ uint32_t tail_blocks(const Geometry &g, uint32_t nv) {
   const uint32_t per_block = 4u * (uint32_t)(64 / g.W);
   uint32_t nb = (nv + 2 * per_block - 1) / (2 * per_block);
   if (nb < 1) nb = 1;
-  if (nb > 128) nb = 128;
+  if (nb > 256) nb = 256;   // one thread of the last block per block partial
   return nb;
 }
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {

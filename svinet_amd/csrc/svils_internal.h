@@ -82,6 +82,7 @@ struct DeviceState {
   uint32_t cls_tile;              // raw entries per classification tile (a multiple of 1024)
   uint32_t cls_tile0, cls_ntiles; // tiles covering the owned entries
   uint64_t ent_pad;               // erow / col are padded to this many entries (0xffffffff)
+  uint32_t s3_threads;  // block size of k_s3_lpl (1024, or 512 for K > 32)
   int fold;             // 1: consumers sum the producers' per-block partial rows themselves (no k_colreduce)
   int cls_next;         // the s3 / tail launches carry the two classification passes for the NEXT sweep
   unsigned long long *sweep_stats;  // [sweep_stats_cap][4] ring: dense, sparse, shortcut links and index of each sweep
@@ -161,6 +162,7 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 uint32_t tail_blocks(const Geometry &g, uint32_t nv);
 uint32_t lpl_cls_blocks(const DeviceState &d);
+uint32_t lpl_s3_threads(uint32_t K);
 uint32_t lpl_scatter_blocks(const DeviceState &d);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,

@@ -60,14 +60,14 @@ __global__ __launch_bounds__(1024) void k_cls_scatter(Geometry geo, DeviceState 
 
 // ============================================================== phi pass (A6)
 template <int KC, int NW>
-__global__ __launch_bounds__(64 * NW, (KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(0, 0);
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   STAMP(0, 1);
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
   __shared__ __attribute__((aligned(16))) double lds[NW][32 * SROW];
-  __shared__ double red[NW][32];
+  __shared__ double red[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometr
   // per-block partial of `sum` (src/linksampling.cc:625,630,663,700 summed per node): waves in
   // order; block 0 adds the shortcut entries' share (+1 per directed entry at its column, :625,:630)
   STAMP(0, 3);
-  if (lane < 32) red[wave][lane] = csum;
+  red[wave][lane] = csum;
   __syncthreads();
   STAMP(0, 4);
   if (threadIdx.x < K) {
@@ -260,6 +260,9 @@ __global__ __launch_bounds__(64 * NW, (KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometr
 // set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491), one group of W lanes per
 // owned node, lane = community.  gammanext[p] = the pieces k_phi_lpl left for the node in both
 // class lists (item order) + 1.0 per shortcut entry at its column.
+template <int W>
+__device__ __forceinline__ unsigned long long group_mask() { return W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull); }
+
 template <int W, bool STOCH>
 __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(1, 0);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
   STAMP(1, 1);
   constexpr int G = 64 / W;
   __shared__ double2 logtab[128];
-  __shared__ double ksum[32];
+  __shared__ double ksum[64];
   __shared__ double tmp[32 * 32];
   __shared__ double s12l[16][64][2];
   __shared__ uint32_t shh[16][64];   // per-group histogram of shortcut columns (G * W == 64 counters per wave)
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
       fold_rows<32, 1024>(d.part_a, d.nb_a, K, tmp, ksum);
       if (blockIdx.x == 0 && threadIdx.x < K) d.kvec_a[threadIdx.x] = ksum[threadIdx.x];
     }
-  } else if (threadIdx.x < 32) {
+  } else if (threadIdx.x < 64) {
     ksum[threadIdx.x] = threadIdx.x < K ? d.kvec_a[threadIdx.x] : 1.0;
   }
   __syncthreads();
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
       if (d.fcnt) {
         uint32_t c = 0;
         if (kval) { c = d.fcnt[(size_t)p * ld + lw]; d.fcnt[(size_t)p * ld + lw] = 0; }
-        b = (__ballot(kval && c > prm.lt_min_deg) >> (g * W)) & ((1ull << W) - 1ull);
+        b = (__ballot(kval && c > prm.lt_min_deg) >> (g * W)) & group_mask<W>();
       } else {
         b = d.member_acc[p];
       }
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
     if (kval) d.elogpi[(size_t)p * ld + lw] = el;
     // prune / check_and_set_converged, src/linksampling.cc:455-475
     const bool act = kval && (gn - prm.alpha >= 1.0);
-    const unsigned long long bits = (__ballot(act) >> (g * W)) & ((1ull << W) - 1ull);
+    const unsigned long long bits = (__ballot(act) >> (g * W)) & group_mask<W>();
     const uint32_t active = (uint32_t)__popcll(bits);
     if (lw == 0) {
       const uint32_t cnew = (active == 1) ? (uint32_t)(63 - __builtin_clzll(bits)) + 1u : conv_old[p];
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
   s12l[wave][lane][0] = s1;
   s12l[wave][lane][1] = s2;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const uint32_t which = threadIdx.x >> 5, k = threadIdx.x & 31u;
+  if (threadIdx.x < 128) {
+    const uint32_t which = threadIdx.x >> 6, k = threadIdx.x & 63u;
     if (k < K) {
       double t = 0.0;
       for (int w = 0; w < nw; ++w)
@@ -431,17 +434,22 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
 // carries extra blocks after the nb_c s3 blocks: they classify the links for the NEXT sweep at the
 // same time on other CUs (prune() of this sweep is complete: the launch follows k_finalize_lpl);
 // the scatter pass follows on the tail launch.
+// threads per block of k_s3_lpl: up to K = 32 the KR accumulators leave 128 registers for a 16-wave
+// block; beyond that 8 waves (two per SIMD) share the register file
+constexpr int s3_threads(int kc) { return kc >= 18 ? 512 : 1024; }
+
 template <int KC>
-__global__ __launch_bounds__(1024) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
-  __shared__ __attribute__((aligned(16))) double lds[16][32 * SROW];
-  __shared__ double red[16][32];
-  __shared__ ClsWork shw[4];
+  constexpr int NTH = s3_threads(KC), NWV = NTH / 64, NWORK = NTH / 256;
+  __shared__ __attribute__((aligned(16))) double lds[NWV][32 * SROW];
+  __shared__ double red[NWV][64];
+  __shared__ ClsWork shw[NWORK];
   STAMP(2, 0);
   if (blockIdx.x >= d.nb_c) {   // the blocks after the s3 blocks: count pass of the NEXT sweep's link classes
-    cls_count_tiles<4>(geo, d, prm, shw, blockIdx.x - d.nb_c, gridDim.x - d.nb_c, true);
+    cls_count_tiles<NWORK>(geo, d, prm, shw, blockIdx.x - d.nb_c, gridDim.x - d.nb_c, true);
     STAMP(2, 7);
     return;
   }
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(1024) void k_s3_lpl(Geometry geo, DeviceState d, Pa
 #pragma unroll
   for (int k = 0; k < KR; ++k) s3[k] = 0.0;
   const uint64_t nl = d.link_end - d.link_begin;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += (uint64_t)d.nb_c * blockDim.x) {
+  for (uint64_t i = (uint64_t)blockIdx.x * NTH + threadIdx.x; i < nl; i += (uint64_t)d.nb_c * NTH) {
     const uint64_t l = d.link_begin + i;
     const uint32_t p = d.links[2 * l], q = d.links[2 * l + 1];
     const uint32_t pc = conv[p], qc = conv[q];
@@ -466,11 +474,15 @@ __global__ __launch_bounds__(1024) void k_s3_lpl(Geometry geo, DeviceState d, Pa
 #pragma unroll
       for (int k = 0; k < KR; ++k) s3[k] += (k == (int)qc - 1) ? val : 0.0;
     } else {
-      double mp[KR], mq[KR];
-      load_row_lane<KC>(mphi + (size_t)p * ld, mp);
-      load_row_lane<KC>(mphi + (size_t)q * ld, mq);
+      // chunk by chunk: only the accumulators stay live across the row
+      const double *rp = mphi + (size_t)p * ld, *rq = mphi + (size_t)q * ld;
 #pragma unroll
-      for (int k = 0; k < KR; ++k) s3[k] += mp[k] * mq[k];
+      for (int c = 0; c < KC; ++c) {
+        const double2 a = *reinterpret_cast<const double2 *>(rp + 2 * c);
+        const double2 b = *reinterpret_cast<const double2 *>(rq + 2 * c);
+        s3[2 * c] += a.x * b.x;
+        s3[2 * c + 1] += a.y * b.y;
+      }
     }
   }
   STAMP(2, 1);
@@ -508,33 +520,35 @@ __global__ __launch_bounds__(1024) void k_s3_lpl(Geometry geo, DeviceState d, Pa
     double tot = 0.0;
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) tot += __shfl(acc, pp * KR + kcol, 64);
-    if (lane < KR && lane < 32) red[wave][lane] = tot;
+    if (lane < KR) red[wave][lane] = tot;
   }
   __syncthreads();
   if (threadIdx.x < K) {
     double t = 0.0;
-    const int nw = blockDim.x >> 6;
-    for (int w = 0; w < nw; ++w) t += red[w][threadIdx.x];
+    for (int w = 0; w < NWV; ++w) t += red[w][threadIdx.x];
     d.part_c[(size_t)blockIdx.x * K + threadIdx.x] = t;
   }
   STAMP(2, 2);
-  if (d.fold && blockIdx.x == 0) {   // s1, s2 of this sweep for k_tail
-    __syncthreads();
-    double *tmp = &lds[0][0];        // 16 row groups x 64 columns; the staging area is free again
-    __shared__ double out64[64];
-    fold_rows<64, 1024>(d.part_b, d.nb_b, 2 * K, tmp, out64);
-    if (threadIdx.x < 2 * K) d.kvec_c[threadIdx.x] = out64[threadIdx.x];
+  if constexpr (KC <= 16) {
+    if (d.fold && blockIdx.x == 0) {   // s1, s2 of this sweep for k_tail
+      __syncthreads();
+      double *tmp = &lds[0][0];        // 16 row groups x 64 columns; the staging area is free again
+      __shared__ double out64[64];
+      fold_rows<64, 1024>(d.part_b, d.nb_b, 2 * K, tmp, out64);
+      if (threadIdx.x < 2 * K) d.kvec_c[threadIdx.x] = out64[threadIdx.x];
+    }
   }
 }
 
 // ------------------------------------------------------------------ launchers
-bool use_lpl(uint32_t K) { return K <= 32; }
+bool use_lpl(uint32_t K) { return K <= 64; }
 // waves per block of k_phi_lpl.  The register file holds 4 waves per SIMD up to K = 24 and 3 for
 // K = 25..32 (a phi row of more than 128 VGPRs): two blocks per CU fill it, and a grid of two blocks
 // per CU leaves at most SVILS_FOLD_ROWS partial rows of `sum` for the consumers to fold.  (One
 // 16-wave block per CU measured 25 % slower on ca-AstroPh K = 20, 256-thread blocks 2 % faster.)
-constexpr int lpl_waves(int kc) { return kc >= 14 ? 6 : 8; }
-int lpl_phi_waves(uint32_t K) { return K > 24 ? 6 : 8; }
+// K = 33..64: a phi row of up to 128 VGPRs, two waves per SIMD, blocks of four waves.
+constexpr int lpl_waves(int kc) { return kc >= 18 ? 4 : kc >= 14 ? 6 : 8; }
+int lpl_phi_waves(uint32_t K) { return K > 32 ? 4 : K > 24 ? 6 : 8; }
 
 #define LPL_DISPATCH(K_, CALL)                 \
   do {                                         \
@@ -543,7 +557,12 @@ int lpl_phi_waves(uint32_t K) { return K > 24 ? 6 : 8; }
     else if ((K_) <= 20) { CALL(10); }         \
     else if ((K_) <= 24) { CALL(12); }         \
     else if ((K_) <= 28) { CALL(14); }         \
-    else { CALL(16); }                         \
+    else if ((K_) <= 32) { CALL(16); }         \
+    else if ((K_) <= 36) { CALL(18); }         \
+    else if ((K_) <= 40) { CALL(20); }         \
+    else if ((K_) <= 48) { CALL(24); }         \
+    else if ((K_) <= 56) { CALL(28); }         \
+    else { CALL(32); }                         \
   } while (0)
 
 // blocks of k_phi_lpl that fit on the device at once (registers and LDS of the instantiation
@@ -566,11 +585,13 @@ void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, h
   hipLaunchKernelGGL(k_cls_count, dim3(nb), dim3(1024), 0, s, g, d, p);
   hipLaunchKernelGGL(k_cls_scatter, dim3(nb), dim3(1024), 0, s, g, d);
 }
-// count-pass blocks riding on the s3 launch (four workers each): with the <= 192 s3 blocks at most
-// one block per CU
+uint32_t lpl_s3_threads(uint32_t K) { return K > 32 ? 512u : 1024u; }
+// count-pass blocks riding on the s3 launch (one worker per 256 threads): with the <= 192 s3 blocks
+// at most one block per CU
 uint32_t lpl_cls_blocks(const DeviceState &d) {
   if (!d.cls_next) return 0;
-  uint32_t nb = (d.cls_ntiles + 3u) / 4u;
+  const uint32_t wpb = d.s3_threads / 256u;
+  uint32_t nb = (d.cls_ntiles + wpb - 1u) / wpb;
   if (nb > 64u) nb = 64u;
   return nb ? nb : 1u;
 }
@@ -595,11 +616,12 @@ void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &
   } while (0)
   if (g.W == 8) FIN(8);
   else if (g.W == 16) FIN(16);
-  else FIN(32);
+  else if (g.W == 32) FIN(32);
+  else FIN(64);
 #undef FIN
 }
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d)), dim3(1024), 0, s, g, d, p)
+#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d)), dim3(s3_threads(KC_)), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }

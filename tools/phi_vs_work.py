@@ -2,21 +2,18 @@
 """phi-kernel time against the work of the sweep: per-kernel hipEvent times averaged over windows of
 sweeps, next to the dense / sparse / shortcut link counts of those sweeps (ca-AstroPh K=20 by default).
 
-  python tools/phi_vs_work.py [workload] [last_sweep] [window]
+  python tools/phi_vs_work.py [workload] [last_sweep] [window] [sparse_after_iter]
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from svinet_amd.host_api import Setup
-from bench import WORKLOADS, _fixture
+from bench import _load_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "astroph-k20"
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
 win = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-if wl not in WORKLOADS and wl.startswith("astroph-k"):
-    WORKLOADS[wl] = ("ca-AstroPh.csv.gz", 17903, int(wl[len("astroph-k"):]))
-f, n, k = WORKLOADS[wl]
-setup = Setup(_fixture(f), n, k)
-eng = setup.engine(use_validation_stop=False)
+sparse_after = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+setup, _, _, n, k, _ = _load_workload(wl)
+eng = setup.engine(use_validation_stop=False, sparse_after_iter=sparse_after)
 L = setup.nlinks
 print("# %s: %d links; columns: sweeps, dense, sparse, shortcut (mean per sweep), then us per launch" % (wl, L))
 done = 0
