@@ -612,7 +612,8 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     const int nw = lpl_phi_waves(g.K);
     const uint32_t phi_items = d.lpl_nitems;
     d.nb_a = cap((phi_items + nw - 1) / nw, std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_phi_resident_blocks(g.K, h->cfg.device)));
-    d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 16 * G - 1) / (16 * G), 256);   // one 16-wave block per CU
+    const uint32_t fw = lpl_finalize_waves();
+    d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fw * G - 1) / (fw * G), 512);   // two 10-wave blocks per CU
     d.s3_threads = lpl_s3_threads(g.K);
     d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 count-pass blocks
   }
@@ -988,7 +989,7 @@ int open_step(svils_handle *h) {
       const int nw = lpl_phi_waves(g.K);
       const uint64_t items = ((d.ent_end - d.ent_begin + 63) >> 6) + 1;
       d.nb_a = fit((items + nw - 1) / nw, h->d.nb_a);
-      d.nb_b = fit(((uint64_t)(e - b) + 16 * G - 1) / (16 * G), h->d.nb_b);
+      d.nb_b = fit(((uint64_t)(e - b) + lpl_finalize_waves() * G - 1) / (lpl_finalize_waves() * G), h->d.nb_b);
       d.nb_c = fit((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, h->d.nb_c);
     } else {
       d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);

@@ -490,7 +490,7 @@ __device__ __forceinline__ void unpack_flags(const Geometry &geo, const DeviceSt
 // Multi-GPU: Elogpi and mphi of the rows this handle does not own, re-derived from the
 // all-gathered gamma instead of being exchanged.  gamma_new = (alpha + acc (n-1)/tl) * scale with
 // m = acc/tl (compute_mean_indicators, src/linksampling.cc:536-542)  =>  m = (gamma/scale - alpha)/(n-1).
-// Rows without a training link (gamma == alpha) never enter the s3 pass; their mphi is set to 0.
+// Rows without a training link (gamma == alpha, unscaled) never enter the s3 pass; their mphi is written as 0.
 template <int W, int V>
 __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Params prm) {
   const DevCtrl *ctrl = d.ctrl;
@@ -527,6 +527,10 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
     for (int v = 0; v < V; ++v) {
       el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
       m[v] = kval[v] ? (gn[v] * iscale[v] - prm.alpha) * inv_nm1 : 0.0;
+    }
+    if (d.rowptr[p + 1] == d.rowptr[p]) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) m[v] = 0.0;
     }
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);

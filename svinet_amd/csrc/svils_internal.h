@@ -163,6 +163,7 @@ void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipSt
 uint32_t tail_blocks(const Geometry &g, uint32_t nv);
 uint32_t lpl_cls_blocks(const DeviceState &d);
 uint32_t lpl_s3_threads(uint32_t K);
+uint32_t lpl_finalize_waves();
 uint32_t lpl_scatter_blocks(const DeviceState &d);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,

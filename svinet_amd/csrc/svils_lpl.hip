@@ -263,8 +263,13 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
 template <int W>
 __device__ __forceinline__ unsigned long long group_mask() { return W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull); }
 
+// Block size of k_finalize_lpl: 80 VGPRs = 6 waves per SIMD = 24 waves per CU = two blocks of 12
+// waves (a block's waves go to the SIMDs in cyclic order, so only multiples of four waves pack; one
+// 16-wave block per CU meant a third round of node iterations for 47 of 256 blocks on ca-AstroPh).
+constexpr int FIN_THREADS = 768, FIN_WAVES = FIN_THREADS / 64;
+
 template <int W, bool STOCH>
-__global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(FIN_THREADS, 6) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(1, 0);
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
@@ -273,8 +278,8 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
   __shared__ double2 logtab[128];
   __shared__ double ksum[64];
   __shared__ double tmp[32 * 32];
-  __shared__ double s12l[16][64][2];
-  __shared__ uint32_t shh[16][64];   // per-group histogram of shortcut columns (G * W == 64 counters per wave)
+  __shared__ double s12l[FIN_WAVES][64][2];
+  __shared__ uint32_t shh[FIN_WAVES][64];   // per-group histogram of shortcut columns (G * W == 64 counters per wave)
   load_logtab(logtab, d.logtab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int g = lane / W, lw = lane % W;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
   // reduced / all-reduced vector when the caller splits the sweep at its exchange points
   if (d.fold) {
     if (annealing || blockIdx.x == 0) {
-      fold_rows<32, 1024>(d.part_a, d.nb_a, K, tmp, ksum);
+      fold_rows<32, FIN_THREADS>(d.part_a, d.nb_a, K, tmp, ksum);
       if (blockIdx.x == 0 && threadIdx.x < K) d.kvec_a[threadIdx.x] = ksum[threadIdx.x];
     }
   } else if (threadIdx.x < 64) {
@@ -322,9 +327,17 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
                                                            : direct + (size_t)p * ld;
           acc += src[lw];
         } else {
-          for (uint32_t w = w0; w <= w1; ++w) {
-            const double *src = (w == w0 && (r0 & 63u) != 0u) ? sl : sf;
-            acc += src[(size_t)w * ld + lw];
+          // a hub's run spans many items: four pieces in flight at a time, added in item order
+          for (uint32_t wb = w0; wb <= w1; wb += 4) {
+            double pv[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) {
+              const uint32_t w = wb + t;
+              const double *src = (w == w0 && (r0 & 63u) != 0u) ? sl : sf;
+              pv[t] = w <= w1 ? src[(size_t)w * ld + lw] : 0.0;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) acc += pv[t];
           }
         }
       }
@@ -335,7 +348,14 @@ __global__ __launch_bounds__(1024) void k_finalize_lpl(Geometry geo, DeviceState
         // W entries at a time per group, counted with integer LDS atomics (order-free)
         uint32_t *hh = &shh[wave][g * W];
         hh[lw] = 0;
-        for (uint32_t j = c0 + (uint32_t)lw; j < c1; j += W) atomicAdd(&hh[d.scol[j] % W], 1u);
+        for (uint32_t jb = c0 + (uint32_t)lw; jb < c1; jb += 4 * W) {   // four loads in flight per lane
+          uint32_t cv[4];
+#pragma unroll
+          for (uint32_t t = 0; t < 4; ++t) cv[t] = (jb + t * W < c1) ? (uint32_t)d.scol[jb + t * W] : 0xffffu;
+#pragma unroll
+          for (uint32_t t = 0; t < 4; ++t)
+            if (cv[t] != 0xffffu) atomicAdd(&hh[cv[t] % W], 1u);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -586,6 +606,7 @@ void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, h
   hipLaunchKernelGGL(k_cls_scatter, dim3(nb), dim3(1024), 0, s, g, d);
 }
 uint32_t lpl_s3_threads(uint32_t K) { return K > 32 ? 512u : 1024u; }
+uint32_t lpl_finalize_waves() { return FIN_WAVES; }
 // count-pass blocks riding on the s3 launch (one worker per 256 threads): with the <= 192 s3 blocks
 // at most one block per CU
 uint32_t lpl_cls_blocks(const DeviceState &d) {
@@ -611,8 +632,8 @@ void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hi
 void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define FIN(W_)                                                                                     \
   do {                                                                                              \
-    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, true>), dim3(d.nb_b), dim3(1024), 0, s, g, d, p); \
-    else hipLaunchKernelGGL((k_finalize_lpl<W_, false>), dim3(d.nb_b), dim3(1024), 0, s, g, d, p);  \
+    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, true>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p); \
+    else hipLaunchKernelGGL((k_finalize_lpl<W_, false>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p);  \
   } while (0)
   if (g.W == 8) FIN(8);
   else if (g.W == 16) FIN(16);

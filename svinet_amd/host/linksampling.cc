@@ -544,13 +544,16 @@ int LinkSampling::infer() {
     if (dev_of_.empty()) {
       if (svils_set_graph(h_, L.data(), L.size() / 2)) die_svils("svils_set_graph");
     } else {
-      std::vector<std::pair<uint32_t, uint32_t> > R(L.size() / 2);
+      // relabelled links, p < q, sorted by (p, q): packed as p << 32 | q for the sort, then flat [L][2]
+      std::vector<uint64_t> R(L.size() / 2);
       for (size_t i = 0; i < R.size(); ++i) {
         const uint32_t a = dev_of_[L[2 * i]], b = dev_of_[L[2 * i + 1]];
-        R[i] = a < b ? std::make_pair(a, b) : std::make_pair(b, a);
+        R[i] = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
       }
       std::sort(R.begin(), R.end());
-      if (svils_set_graph(h_, &R[0].first, R.size())) die_svils("svils_set_graph");
+      std::vector<uint32_t> flat(2 * R.size() + 2, 0);
+      for (size_t i = 0; i < R.size(); ++i) { flat[2 * i] = (uint32_t)(R[i] >> 32); flat[2 * i + 1] = (uint32_t)R[i]; }
+      if (svils_set_graph(h_, flat.data(), R.size())) die_svils("svils_set_graph");
     }
     graph_sent_ = true;
   }

@@ -22,6 +22,22 @@ def pytest_configure(config):
         build.build_all()
 
 
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` on a box without a HIP device: skip instead of failing one test after the other --
+    except the tests that check that the product fails LOUDLY there (no CPU fallback)."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no HIP device here; there is no CPU fallback to test instead)")
+    for item in items:
+        if "gpu" in item.keywords and "loud" not in item.name:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def graph_files(tmp_path_factory):
     """Decompressed copies of the example graphs the reference ships (tests/golden/graphs)."""
