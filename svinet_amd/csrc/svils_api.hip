@@ -59,6 +59,8 @@ struct svils_handle {
   // lane-per-link layout: the link classes on the device describe the sweep about to run (k_s3_lpl
   // refreshes them for the next sweep); cleared whenever flags / _iter / the window change under them
   bool cls_valid = false;
+  bool v_flush_needed = false;   // a three-launch sweep left its likelihood row / stop rule to the next launch
+  bool v_flush_capture = false;  // ... and so do the sweeps captured in the hipGraphs
   void *cls_zero = nullptr;      // ltot + shist + scan descriptors, one contiguous block
   size_t cls_zero_bytes = 0;
   // native multi-GPU driver (svils_comm_init)
@@ -162,6 +164,14 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   hipStream_t s = h->stream;
   DeviceState d = d0;
   d.fold = (fused && d.lpl && g.K <= 32) ? 1 : 0;   // K = 33..64: K-vectors via k_colreduce (2K columns are too wide to fold)
+  // Three launches per sweep when this library drives whole full sweeps at K <= 32: the work of k_tail is
+  // split between the last s3 block (lambda, loop control) and a role of the NEXT phi launch (likelihood,
+  // stop rule), and the phi pass accumulates beside gamma so that it may run before the stop rule has spoken.
+  d.fused3 = (d.fold && !prm.stoch && d.gacc0) ? 1 : 0;
+  if (d.fused3) {
+    d.gacc = d.gacc0;
+    d.nvb = lpl_validation_blocks(g, d.nv, g.K);
+  }
   d.cls_next = (d.lpl && !prm.stoch) ? 1 : 0;
   switch (ph) {
     case SVILS_PHASE_A: {
@@ -187,8 +197,12 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
       launch_expand(g, d, prm, s);
     } break;
     case SVILS_PHASE_D: {
-      Timed t(h, SVILS_KERNEL_TAIL);
-      launch_tail(g, d, prm, s);
+      if (!d.fused3) {
+        Timed t(h, SVILS_KERNEL_TAIL);
+        launch_tail(g, d, prm, s);
+      } else {
+        h->v_flush_needed = true;   // the sweep's likelihood row is owed by the next phi launch or by flush_validation()
+      }
       if (d.lpl && !d.cls_next) h->cls_valid = false;
       ++h->sweeps_issued;
     } break;
@@ -615,7 +629,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     const uint32_t fw = lpl_finalize_waves();
     d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fw * G - 1) / (fw * G), 512);   // two 10-wave blocks per CU
     d.s3_threads = lpl_s3_threads(g.K);
-    d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 count-pass blocks
+    d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 classification blocks
   }
 
   int rc = 0;
@@ -647,6 +661,10 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     const uint32_t tiles_all = (uint32_t)(d.ent_pad / d.cls_tile);
     guard(dalloc(h, &d.tcnt, tiles_all));
     guard(dalloc(h, &d.cls_args, 4));
+    guard(dalloc(h, &d.s3_ctl, 4));
+    guard(dalloc(h, &d.cls_sync, 4));
+    guard(dalloc(h, &d.tbase, tiles_all));
+    if (g.K <= 32) guard(dalloc(h, &d.gacc0, (size_t)g.n_alloc * g.ld));   // three-launch sweeps accumulate beside gamma
     // ltot [2][8] u32 | shist [2][K] u64, cleared together before a stand-alone classification
     h->cls_zero_bytes = 64 + 2 * (size_t)g.K * sizeof(unsigned long long);
     unsigned char *cz = nullptr;
@@ -803,14 +821,32 @@ hipGraphExec_t capture_sweeps(svils_handle *h, uint32_t nsweeps) {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   const uint64_t issued = h->sweeps_issued;
+  const bool vf = h->v_flush_needed;
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
   const int rc = eager_sweeps(h, nsweeps);
   const hipError_t e = hipStreamEndCapture(h->stream, &graph);
   h->sweeps_issued = issued;   // nothing ran
+  h->v_flush_capture = h->v_flush_needed;
+  h->v_flush_needed = vf;
   if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
   if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
   (void)hipGraphDestroy(graph);
   return exec;
+}
+
+// three-launch sweeps: the held-out likelihood and stop rule of the last sweep enqueued, as a launch of
+// its own (inside a run of sweeps they ride on the next phi launch)
+int flush_validation(svils_handle *h) {
+  if (!h->v_flush_needed) return 0;
+  DeviceState d = h->d;
+  d.nvb = lpl_validation_blocks(h->geo, d.nv, h->geo.K);
+  {
+    Timed t(h, SVILS_KERNEL_TAIL);
+    launch_validate_lpl(h->geo, d, h->prm, h->stream);
+  }
+  HIPCHK(hipGetLastError());
+  h->v_flush_needed = false;
+  return 0;
 }
 
 // the captured sweeps assume valid link classes on entry (each sweep leaves them valid for the next)
@@ -841,6 +877,7 @@ int graph_sweeps(svils_handle *h, uint32_t n) {
     if (!h->gexec1 || !h->gexecN) { drop_graphs(h); h->graphs_ok = false; return eager_sweeps(h, n); }
   }
   h->sweeps_issued += n;
+  if (n) h->v_flush_needed = h->v_flush_capture;   // what a captured sweep leaves behind
   for (; n >= svils_handle::kGraphSweeps; n -= svils_handle::kGraphSweeps) HIPCHK(hipGraphLaunch(h->gexecN, h->stream));
   for (; n > 0; --n) HIPCHK(hipGraphLaunch(h->gexec1, h->stream));
   return 0;
@@ -859,22 +896,25 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   if (nsweeps > max_batch)
     return fail(SVILS_ERR_ARG, "svils_sweep: at most %llu sweeps per call (likelihood-row ring of %u entries)",
                 (unsigned long long)max_batch, h->d.rows_cap);
-  if (!h->graphs_ok || nsweeps < 4) return eager_sweeps(h, nsweeps);   // short calls are not worth a capture
-  if (h->tmask == 0) return graph_sweeps(h, nsweeps);
+  int rc = 0;
+  if (!h->graphs_ok || nsweeps < 4) rc = eager_sweeps(h, nsweeps);   // short calls are not worth a capture
+  else if (h->tmask == 0) rc = graph_sweeps(h, nsweeps);
   // Per-kernel hipEvent timing needs eager launches: events captured as graph nodes cannot be read
   // with hipEventElapsedTime on this runtime.  With a sampling period P > 1 only every P-th sweep is
   // launched eagerly between events; the P-1 sweeps in between replay the untimed graphs.
-  if (h->tperiod <= 1) return eager_sweeps(h, nsweeps);
-  uint32_t left = nsweeps;
-  while (left > 0) {
-    int rc = eager_sweeps(h, 1);
-    if (rc) return rc;
-    --left;
-    const uint32_t n = std::min(left, h->tperiod - 1);
-    if (n && (rc = graph_sweeps(h, n))) return rc;
-    left -= n;
+  else if (h->tperiod <= 1) rc = eager_sweeps(h, nsweeps);
+  else {
+    uint32_t left = nsweeps;
+    while (left > 0 && !rc) {
+      rc = eager_sweeps(h, 1);
+      --left;
+      const uint32_t n = std::min(left, h->tperiod - 1);
+      if (n && !rc) rc = graph_sweeps(h, n);
+      left -= n;
+    }
   }
-  return 0;
+  if (rc) return rc;
+  return flush_validation(h);
 }
 
 int svils_set_timing_period(svils_handle *h, uint32_t period) {

@@ -43,19 +43,33 @@ __device__ __forceinline__ int classify_entry(const uint32_t *__restrict__ conv,
 // Role block `rb` of `nrb`, NWORK workers per block.  Worker 0 also records the arguments for the
 // scatter pass, which must not read the control block: it shares its launch with the kernel that
 // advances it.
-template <int NWORK>
+// what a classification works from: which half of conv[], whether the active-set class exists, and
+// the ltot/shist half it fills.  FROM_ARGS: recorded by the previous launch (cls_record_args), because
+// the launch that carries the passes also advances the control block.
+__device__ __forceinline__ void cls_record_args(const DeviceState &d, const Params &prm, bool next) {
+  const DevCtrl *ctrl = d.ctrl;
+  d.cls_args[0] = next ? (ctrl->parity ^ 1u) : ctrl->parity;
+  d.cls_args[1] = (((long long)ctrl->iter + (next ? 1 : 0)) > (long long)prm.sparse_after) ? 1u : 0u;
+  d.cls_args[2] = next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par;
+  d.cls_args[3] = ctrl->sweeps_done + 1u;   // epoch of the in-launch prefix hand-off
+}
+
+template <int NWORK, bool FROM_ARGS = false>
 __device__ __forceinline__ void cls_count_tiles(const Geometry &geo, const DeviceState &d, const Params &prm,
                                                 ClsWork (&shw)[NWORK], uint32_t rb, uint32_t nrb, bool next) {
-  const DevCtrl *ctrl = d.ctrl;
-  const uint32_t conv_idx = next ? (ctrl->parity ^ 1u) : ctrl->parity;
-  const bool sparse_iter = ((long long)ctrl->iter + (next ? 1 : 0)) > (long long)prm.sparse_after;
-  if (rb == 0 && threadIdx.x == 0) {
-    d.cls_args[0] = conv_idx;
-    d.cls_args[1] = sparse_iter ? 1u : 0u;
-    d.cls_args[2] = next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par;
+  if (!FROM_ARGS && rb == 0 && threadIdx.x == 0) cls_record_args(d, prm, next);
+  uint32_t conv_idx, par;
+  bool sparse_iter;
+  if (FROM_ARGS) {
+    conv_idx = d.cls_args[0]; sparse_iter = d.cls_args[1] != 0u; par = d.cls_args[2];
+  } else {
+    const DevCtrl *ctrl = d.ctrl;
+    conv_idx = next ? (ctrl->parity ^ 1u) : ctrl->parity;
+    sparse_iter = ((long long)ctrl->iter + (next ? 1 : 0)) > (long long)prm.sparse_after;
+    par = next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par;
   }
-  uint32_t *ltot = d.ltot + (next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par) * 8u;
-  unsigned long long *shist = d.shist + (size_t)(next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par) * geo.K;
+  uint32_t *ltot = d.ltot + par * 8u;
+  unsigned long long *shist = d.shist + (size_t)par * geo.K;
   const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
   const uint32_t wk = threadIdx.x >> 8, tid = threadIdx.x & 255u;
   const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
@@ -96,7 +110,11 @@ __device__ __forceinline__ void cls_count_tiles(const Geometry &geo, const Devic
     __syncthreads();
     if (lane == 0) sh.wred[wv] = n01;
     __syncthreads();
-    if (act && tid == 0) d.tcnt[tile] = sh.wred[0] + sh.wred[1] + sh.wred[2] + sh.wred[3];
+    if (act && tid == 0) {
+      const unsigned long long t = sh.wred[0] + sh.wred[1] + sh.wred[2] + sh.wred[3];
+      if (FROM_ARGS) st_agent(&d.tcnt[tile], t);   // read by another workgroup of the SAME launch
+      else d.tcnt[tile] = t;
+    }
   }
   // this block's statistics row: shortcut entries per community column (-> `sum`), then the links
   // (q > p) per class (-> the c, d counters of src/linksampling.cc:726), over all its tiles
@@ -121,7 +139,9 @@ __device__ __forceinline__ void cls_count_tiles(const Geometry &geo, const Devic
   }
 }
 
-template <int NWORK>
+// BASES: the exclusive per-tile prefixes are in tbase[] (cls_prefix_handoff) instead of being added
+// up from tcnt[] by every worker
+template <int NWORK, bool BASES = false>
 __device__ __forceinline__ void cls_scatter_tiles(const Geometry &geo, const DeviceState &d, ClsWork (&shw)[NWORK],
                                                   uint32_t rb, uint32_t nrb) {
   const uint32_t conv_idx = d.cls_args[0];
@@ -152,8 +172,11 @@ __device__ __forceinline__ void cls_scatter_tiles(const Geometry &geo, const Dev
     const bool act = tile < d.cls_ntiles;
     // class-0 / class-1 entries in the tiles below this one
     unsigned long long pre = 0ull;
-    if (act)
+    if (BASES) {
+      if (act && tid == 0) pre = ld_agent(&d.tbase[tile]);
+    } else if (act) {
       for (uint32_t i = tid; i < tile; i += 256u) pre += d.tcnt[i];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) pre += (unsigned long long)__shfl_xor((long long)pre, o, 64);
     __syncthreads();
@@ -225,6 +248,201 @@ __device__ __forceinline__ void cls_scatter_tiles(const Geometry &geo, const Dev
             for (uint32_t x = p + 1u; x <= geo.node_end; ++x) {
               d.npos[0][x] = a0; d.npos[1][x] = a1; d.npos[2][x] = a2;
             }
+          }
+        }
+      }
+    }
+  }
+}
+
+// In-launch hand-off between the two passes (three-launch sweeps): every role block arrives on a
+// ticket after its count pass; the last one scans tcnt[] into exclusive prefixes tbase[] and
+// raises the epoch word; the others wait for it (bounded spin, a few dozen blocks, all of them
+// resident next to the s3 blocks: only role blocks ever wait, never for a block that cannot start).
+template <int NTH>
+__device__ __forceinline__ void cls_prefix_handoff(const DeviceState &d, uint32_t nrb, unsigned long long *scan_lds /*[NTH/64 + 1]*/,
+                                                   uint32_t *flag_lds) {
+  const uint32_t epoch = d.cls_args[3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (last_block_arrives(&d.cls_sync[0], nrb, flag_lds)) {
+    unsigned long long run = 0ull;
+    for (uint32_t base = 0; base < d.cls_ntiles; base += NTH) {
+      const uint32_t i = base + threadIdx.x;
+      const unsigned long long v = i < d.cls_ntiles ? ld_agent(&d.tcnt[i]) : 0ull;
+      unsigned long long inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = (unsigned long long)__shfl_up((long long)inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      __syncthreads();
+      if (lane == 63) scan_lds[wave] = inc;
+      __syncthreads();
+      unsigned long long woff = 0ull, tot = 0ull;
+      for (int w = 0; w < NTH / 64; ++w) {
+        const unsigned long long t = scan_lds[w];
+        if (w < wave) woff += t;
+        tot += t;
+      }
+      if (i < d.cls_ntiles) st_agent(&d.tbase[i], run + woff + inc - v);
+      run += tot;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&d.cls_sync[1], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (threadIdx.x == 0) {
+      uint32_t spins = 0;
+      while (ld_agent(&d.cls_sync[1]) != epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 22)) { d.cls_sync[2] = 1u; break; }   // never spin unbounded: flag the error
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Both passes by the same worker inside ONE launch (three-launch sweeps).  When every worker has at
+// most two 1024-entry tiles -- graphs up to a few hundred thousand links, where each dependent global
+// access is a visible share of the sweep -- the entries and their classes stay in registers across
+// the hand-off, so the scatter half touches no input again; otherwise the two generic passes run
+// back to back.
+template <int NWORK, int NTH>
+__device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, const DeviceState &d, const Params &prm,
+                                                       ClsWork (&shw)[NWORK], uint32_t rb, uint32_t nrb,
+                                                       unsigned long long *scan_lds, uint32_t *flag_lds) {
+  constexpr int T = 2;   // tiles per worker kept in registers
+  const uint32_t nrw = nrb * NWORK;
+  if (d.cls_ntiles > T * nrw || d.cls_tile != 1024u || d.cls_ntiles == 0u) {
+    cls_count_tiles<NWORK, true>(geo, d, prm, shw, rb, nrb, true);
+    cls_prefix_handoff<NTH>(d, nrb, scan_lds, flag_lds);
+    cls_scatter_tiles<NWORK, true>(geo, d, shw, rb, nrb);
+    return;
+  }
+  const uint32_t conv_idx = d.cls_args[0];
+  const bool sparse_iter = d.cls_args[1] != 0u;
+  const uint32_t par = d.cls_args[2];
+  const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
+  uint32_t *ltot = d.ltot + par * 8u;
+  unsigned long long *shist = d.shist + (size_t)par * geo.K;
+  const uint32_t wk = threadIdx.x >> 8, tid = threadIdx.x & 255u;
+  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
+  ClsWork &sh = shw[wk];
+  const uint32_t rw = rb * NWORK + wk;
+  const uint64_t eb = d.ent_begin, ee = d.ent_end;
+  if (tid < 64) sh.hist[tid] = 0;
+  if (tid < 4) sh.upper[tid] = 0;
+  __syncthreads();
+  uint32_t pp[T][4], qq[T][4], pprev[T], n01[T], excl[T];
+  uint32_t cc[T][4];   // class (3 = not an owned entry) | shortcut column << 2
+  uint32_t up[3] = {0, 0, 0};
+  // all inputs of both tiles first (entries, then flags), so that they are one latency, not two
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint32_t tile = rw + t * nrw;
+    const uint64_t e0 = (uint64_t)(d.cls_tile0 + tile) * 1024u + 4u * tid;
+    pprev[t] = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pp[t][j] = 0; qq[t][j] = 0; cc[t][j] = 3u; }
+    if (tile < d.cls_ntiles) {
+      const uint4 pr = *reinterpret_cast<const uint4 *>(d.erow + e0);
+      const uint4 qr = *reinterpret_cast<const uint4 *>(d.col + e0);
+      pp[t][0] = pr.x; pp[t][1] = pr.y; pp[t][2] = pr.z; pp[t][3] = pr.w;
+      qq[t][0] = qr.x; qq[t][1] = qr.y; qq[t][2] = qr.z; qq[t][3] = qr.w;
+      if (e0 > 0) pprev[t] = d.erow[e0 - 1];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint32_t tile = rw + t * nrw;
+    const uint64_t e0 = (uint64_t)(d.cls_tile0 + tile) * 1024u + 4u * tid;
+    n01[t] = 0;
+    if (tile < d.cls_ntiles) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t e = e0 + j;
+        if (e >= eb && e < ee) {
+          uint32_t c2;
+          const int cl = classify_entry(conv, d.active_cnt, geo.k10, sparse_iter, pp[t][j], qq[t][j], &c2);
+          cc[t][j] = (uint32_t)cl | (c2 << 2);
+          n01[t] += (cl == 0 ? 1u : 0u) + (cl == 1 ? 0x10000u : 0u);
+          if (qq[t][j] > pp[t][j]) up[cl]++;
+          if (cl == 2) atomicAdd(&sh.hist[c2 & 63u], 1u);
+        }
+      }
+    }
+  }
+  // exclusive scans over the worker; a tile's total is its count
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    uint32_t inc = n01[t];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    __syncthreads();
+    if (lane == 63) sh.wsum[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, ttot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t v = sh.wsum[w];
+      if (w < wv) woff += v;
+      ttot += v;
+    }
+    excl[t] = woff + inc - n01[t];
+    const uint32_t tile = rw + t * nrw;
+    if (tile < d.cls_ntiles && tid == 0)
+      st_agent(&d.tcnt[tile], ((unsigned long long)(ttot & 0xffffu) << 32) | (unsigned long long)(ttot >> 16));
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uint32_t u = up[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u += (uint32_t)__shfl_xor((int)u, o, 64);
+    if (lane == 0 && u) atomicAdd(&sh.upper[c], u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 + 3) {   // one integer atomic per block and word, nobody waits for them
+    uint32_t v = 0;
+#pragma unroll
+    for (int w = 0; w < NWORK; ++w) v += threadIdx.x < 64 ? shw[w].hist[threadIdx.x] : shw[w].upper[threadIdx.x - 64];
+    if (v) {
+      if (threadIdx.x < 64) { if (threadIdx.x < geo.K) atomicAdd(&shist[threadIdx.x], (unsigned long long)v); }
+      else atomicAdd(&ltot[3 + (threadIdx.x - 64)], v);
+    }
+  }
+  cls_prefix_handoff<NTH>(d, nrb, scan_lds, flag_lds);
+  // (no block barrier below: workers and tiles finish on their own)
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint32_t tile = rw + t * nrw;
+    if (tile >= d.cls_ntiles) continue;
+    const uint64_t e0 = (uint64_t)(d.cls_tile0 + tile) * 1024u + 4u * tid;
+    const unsigned long long pre = ld_agent(&d.tbase[tile]);
+    uint32_t pos0 = (uint32_t)(pre >> 32) + (excl[t] & 0xffffu), pos1 = (uint32_t)pre + (excl[t] >> 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t e = e0 + j;
+      const uint32_t cl = cc[t][j] & 3u;
+      if (cl != 3u) {
+        const uint32_t p = pp[t][j], q = qq[t][j];
+        const uint32_t pos2 = (uint32_t)(e - eb) - pos0 - pos1;
+        const uint32_t prev = j == 0 ? pprev[t] : pp[t][j - 1];
+        if (e == eb || p != prev) {
+          for (uint32_t x = (e == eb) ? geo.node_begin : prev + 1u; x <= p; ++x) {
+            d.npos[0][x] = pos0; d.npos[1][x] = pos1; d.npos[2][x] = pos2;
+          }
+        }
+        uint32_t a0 = pos0, a1 = pos1, a2 = pos2;
+        if (cl == 0u) { d.cp[0][pos0] = p; d.cq[0][pos0] = q; a0 = ++pos0; }
+        else if (cl == 1u) { d.cp[1][pos1] = p; d.cq[1][pos1] = q; a1 = ++pos1; }
+        else { d.scol[pos2] = (uint16_t)(cc[t][j] >> 2); a2 = pos2 + 1u; }
+        if (e == ee - 1) {
+          ltot[0] = a0; ltot[1] = a1; ltot[2] = a2;
+          for (uint32_t x = p + 1u; x <= geo.node_end; ++x) {
+            d.npos[0][x] = a0; d.npos[1][x] = a1; d.npos[2][x] = a2;
           }
         }
       }

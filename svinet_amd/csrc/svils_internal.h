@@ -34,6 +34,9 @@ struct DevCtrl {
   unsigned long long links_dense, links_sparse, links_shortcut;       // of the last sweep
   uint32_t parity;  // conv[parity] is the current _converged, conv[parity^1] receives prune()'s
   uint32_t cls_par; // lane-per-link layout: ltot/shist[cls_par] describe the link classes of the CURRENT sweep
+  // three-launch sweeps (fused small-K path): the held-out likelihood + stop rule of sweep v_iter has
+  // been handed to the next launch (a role of the next phi launch, or k_validate_lpl)
+  uint32_t v_pending, v_iter;
 };
 
 struct Geometry {
@@ -85,6 +88,14 @@ struct DeviceState {
   uint32_t s3_threads;  // block size of k_s3_lpl (1024, or 512 for K > 32)
   int fold;             // 1: consumers sum the producers' per-block partial rows themselves (no k_colreduce)
   int cls_next;         // the s3 / tail launches carry the two classification passes for the NEXT sweep
+  // fused3: a sweep is THREE launches -- phi (+ roles: held-out likelihood and stop rule of the previous sweep),
+  // finalise, s3 (+ roles: both classification passes; last block: lambda, Elogbeta, loop control)
+  int fused3;
+  uint32_t nvb;                   // validation-role blocks appended to the phi launch
+  uint32_t *s3_ctl;               // [4] arrival ticket of the s3 blocks
+  uint32_t *cls_sync;             // [4] [0] arrival ticket of the classification role blocks, [1] prefix-ready epoch
+  unsigned long long *tbase;      // [ntiles] exclusive class-0 << 32 | class-1 prefix per tile (fused3 scatter)
+  double *gacc0;                  // [n_alloc][ld] phi accumulator of the fused3 path (gamma stays intact until finalise)
   unsigned long long *sweep_stats;  // [sweep_stats_cap][4] ring: dense, sparse, shortcut links and index of each sweep
   uint32_t sweep_stats_cap;
   unsigned long long *stamps;   // [4][1024][8] wall-clock stamps of blocks (builds with -DSVILS_STAMPS only)
@@ -162,6 +173,8 @@ void launch_validation(const Geometry &g, const DeviceState &d, const Params &p,
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 uint32_t tail_blocks(const Geometry &g, uint32_t nv);
 uint32_t lpl_cls_blocks(const DeviceState &d);
+void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K);
 uint32_t lpl_s3_threads(uint32_t K);
 uint32_t lpl_finalize_waves();
 uint32_t lpl_scatter_blocks(const DeviceState &d);

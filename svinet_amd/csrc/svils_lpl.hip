@@ -58,16 +58,150 @@ __global__ __launch_bounds__(1024) void k_cls_scatter(Geometry geo, DeviceState 
   cls_scatter_tiles<4>(geo, d, shw, blockIdx.x, gridDim.x);
 }
 
+// =========================== held-out likelihood + stop rule as a role (three-launch sweeps)
+// validation_likelihood() of sweep v_iter (src/linksampling.cc:966-1050) for K <= 32, by `nrb` role
+// blocks of any size: one group of W lanes per held-out pair (W = 8 / 16 / 32, lane = community),
+// block partials published with agent-scope stores, the last block to arrive adds them in block
+// order and runs the stop rule / annealing switch.  lambda and gamma of the finished sweep are in
+// memory (the s3 launch's last block wrote lambda); nothing here touches what the phi blocks of
+// the same launch read, except `stopped`, which they may see either way.
+__device__ __forceinline__ void lpl_validation_role(const Geometry &geo, const DeviceState &d, const Params &prm,
+                                                    uint32_t rb, uint32_t nrb, double (*red)[3], uint32_t *flag_lds) {
+  if (d.ctrl->stopped || !d.ctrl->v_pending) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int W = geo.W, G = 64 / W;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  double beta = 0.0;
+  if ((uint32_t)lw < K) {
+    const double l0 = d.lambda[2 * lw], l1 = d.lambda[2 * lw + 1];
+    beta = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
+  }
+  double sz = 0.0, so = 0.0, kz = 0.0;
+  const uint32_t stride = nrb * nw * G;
+  // two pairs per group in flight: indices first, then the rows
+  for (uint32_t ib = (rb * nw + wave) * G + g; ib < d.nv; ib += 2 * stride) {
+    uint32_t pp[2], qq[2], yy[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t i = ib + t * stride;
+      pp[t] = 0; qq[t] = 0; yy[t] = 0;
+      if (i < d.nv) { pp[t] = d.vpairs[3 * (size_t)i]; qq[t] = d.vpairs[3 * (size_t)i + 1]; yy[t] = d.vpairs[3 * (size_t)i + 2]; }
+    }
+    double gp[2], gq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      gp[t] = (uint32_t)lw < K ? d.gamma[(size_t)pp[t] * ld + lw] : 0.0;
+      gq[t] = (uint32_t)lw < K ? d.gamma[(size_t)qq[t] * ld + lw] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      double sp = gp[t], sq = gq[t], dot = gp[t] * gq[t] * beta;
+      for (int o = 1; o < W; o <<= 1) {   // the group's lanes are contiguous: xor shuffles stay inside it
+        sp += __shfl_xor(sp, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+        dot += __shfl_xor(dot, o, 64);
+      }
+      if (ib + t * stride < d.nv && lw == 0) {
+        // non-links: the K^2 double loop collapses exactly to (sum pi_p)(sum pi_q) - sum pi_p pi_q beta (k_tail)
+        const double pq = dot / (sp * sq);
+        double sv = yy[t] ? pq : 1.0 - pq;
+        if (sv < 1e-30) sv = 1e-30;
+        const double u = log(sv);
+        if (yy[t]) so += u; else { sz += u; kz += 1.0; }
+      }
+    }
+  }
+  // block partial: lanes, then waves, in a fixed order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sz += __shfl_xor(sz, o, 64); so += __shfl_xor(so, o, 64); kz += __shfl_xor(kz, o, 64);
+  }
+  if (lane == 0) { red[wave][0] = sz; red[wave][1] = so; red[wave][2] = kz; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0, cc = 0.0;
+    for (int w = 0; w < nw; ++w) { a += red[w][0]; b += red[w][1]; cc += red[w][2]; }
+    st_agent(d.tail_part + (size_t)rb * 4, a);
+    st_agent(d.tail_part + (size_t)rb * 4 + 1, b);
+    st_agent(d.tail_part + (size_t)rb * 4 + 2, cc);
+  }
+  if (!last_block_arrives(d.tail_ctl, nrb, flag_lds)) return;
+  // the blocks' partials: one lane per block (nrb <= 64), then a fixed butterfly
+  double szeros = 0.0, sones = 0.0, kzd = 0.0;
+  if (threadIdx.x < 64) {
+    if (threadIdx.x < nrb) {
+      szeros = ld_agent(d.tail_part + (size_t)threadIdx.x * 4);
+      sones = ld_agent(d.tail_part + (size_t)threadIdx.x * 4 + 1);
+      kzd = ld_agent(d.tail_part + (size_t)threadIdx.x * 4 + 2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      szeros += __shfl_xor(szeros, o, 64); sones += __shfl_xor(sones, o, 64); kzd += __shfl_xor(kzd, o, 64);
+    }
+  }
+  if (threadIdx.x == 0) {
+    DevCtrl *c = d.ctrl;   // field by field: a whole-struct copy goes through scratch
+    const uint32_t kzeros = (uint32_t)kzd, kones = d.nv - kzeros;
+    const double mean0 = szeros / kzeros, mean1 = sones / kones;
+    const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
+    const uint32_t iter = c->v_iter, nrows = c->rows;
+    double *row = d.rows + (size_t)(nrows % d.rows_cap) * 10;
+    row[0] = (double)iter; row[1] = (szeros + sones) / d.nv; row[2] = (double)d.nv;
+    row[3] = mean0; row[4] = (double)kzeros; row[5] = mean1; row[6] = (double)kones;
+    row[7] = prm.zeros_prob * mean0; row[8] = prm.ones_prob * mean1; row[9] = a;
+    c->rows = nrows + 1u;
+    bool stop = false;
+    int why = -1;
+    int nh = c->nh;
+    const int annealing = c->annealing;
+    if (iter > 10) {     // src/linksampling.cc:1008-1027
+      const double prev = c->prev_h;
+      if (a > prev && prev != 0 && fabs((a - prev) / prev) < 0.00001) { stop = true; why = 100; }
+      else if (a < prev) nh++;
+      else if (a > prev) nh = 0;
+      if (a > c->max_h) c->max_h = a;
+      if (nh > 2) { why = 1; stop = true; }
+    }
+    double prev_new = a;
+    if (annealing && stop) {
+      c->annealing = 0; nh = 0; prev_new = 0;  // max.txt keeps the pre-switch `why`
+    } else if (!annealing && stop && prm.use_validation_stop) {
+      c->stopped = 1;      // do_on_stop(); exit(0): _iter is not advanced (the s3 launch had advanced it)
+      c->iter = iter;
+    }
+    c->nh = nh;
+    c->prev_h = prev_new;
+    c->why = why;
+    c->v_pending = 0;
+  }
+}
+
+// the same as its own launch: after the last sweep of a svils_sweep() call
+__global__ __launch_bounds__(256) void k_validate_lpl(Geometry geo, DeviceState d, Params prm) {
+  __shared__ double red[4][3];
+  __shared__ uint32_t flag;
+  lpl_validation_role(geo, d, prm, blockIdx.x, gridDim.x, red, &flag);
+}
+
 // ============================================================== phi pass (A6)
 template <int KC, int NW>
 __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(0, 0);
   DevCtrl *ctrl = d.ctrl;
-  if (ctrl->stopped) return;
-  STAMP(0, 1);
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
   __shared__ __attribute__((aligned(16))) double lds[NW][32 * SROW];
   __shared__ double red[NW][64];
+  if (blockIdx.x >= d.nb_a) {
+    // extra workgroups of a three-launch sweep: likelihood + stop rule of the PREVIOUS sweep, on CUs the
+    // phi blocks leave idle.  The phi blocks run speculatively next to them: they accumulate into gacc0,
+    // so a stop decided here leaves the state exactly as the previous sweep left it.
+    __shared__ uint32_t vflag;
+    lpl_validation_role(geo, d, prm, blockIdx.x - d.nb_a, gridDim.x - d.nb_a, reinterpret_cast<double (*)[3]>(&red[0][0]), &vflag);
+    return;
+  }
+  if (ctrl->stopped) return;
+  STAMP(0, 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
@@ -86,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
   double csum = 0.0;  // lane k: partial of sum[k]
   STAMP(0, 2);
 
-  for (uint32_t it = blockIdx.x * NW + wave; it < n0 + n1; it += gridDim.x * NW) {
+  for (uint32_t it = blockIdx.x * NW + wave; it < n0 + n1; it += d.nb_a * NW) {
     const uint32_t list = it >= n0 ? 1u : 0u;            // wave-uniform
     const uint32_t w = list ? it - n0 : it;
     const uint32_t g = w * 64u + lane;
@@ -290,6 +424,9 @@ __global__ __launch_bounds__(FIN_THREADS, 6) void k_finalize_lpl(Geometry geo, D
   uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
   const uint32_t cpar = ctrl->cls_par;
   const bool have1 = d.ltot[cpar * 8u + 1u] != 0u, have2 = d.ltot[cpar * 8u + 2u] != 0u;
+  // three-launch sweeps: the s3 launch classifies the next sweep's links AND advances the control block,
+  // so what the classification works from is recorded here, where the control block is at rest
+  if (d.fused3 && blockIdx.x == 0 && threadIdx.x == 0) cls_record_args(d, prm, true);
   // `sum`: folded from the phi pass's per-block partial rows (block 0 also publishes it), or the
   // reduced / all-reduced vector when the caller splits the sweep at its exchange points
   if (d.fold) {
@@ -454,9 +591,9 @@ __global__ __launch_bounds__(FIN_THREADS, 6) void k_finalize_lpl(Geometry geo, D
 // carries extra blocks after the nb_c s3 blocks: they classify the links for the NEXT sweep at the
 // same time on other CUs (prune() of this sweep is complete: the launch follows k_finalize_lpl);
 // the scatter pass follows on the tail launch.
-// threads per block of k_s3_lpl: up to K = 32 the KR accumulators leave 128 registers for a 16-wave
+// threads per block of k_s3_lpl: up to K = 20 the KR accumulators fit the 128 registers of a 16-wave
 // block; beyond that 8 waves (two per SIMD) share the register file
-constexpr int s3_threads(int kc) { return kc >= 18 ? 512 : 1024; }
+constexpr int s3_threads(int kc) { return kc >= 12 ? 512 : 1024; }
 
 template <int KC>
 __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
@@ -468,11 +605,25 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   __shared__ double red[NWV][64];
   __shared__ ClsWork shw[NWORK];
   STAMP(2, 0);
-  if (blockIdx.x >= d.nb_c) {   // the blocks after the s3 blocks: count pass of the NEXT sweep's link classes
-    cls_count_tiles<NWORK>(geo, d, prm, shw, blockIdx.x - d.nb_c, gridDim.x - d.nb_c, true);
+  __shared__ uint32_t hflag;
+  if (blockIdx.x >= d.nb_c) {   // the blocks after the s3 blocks: link classes of the NEXT sweep
+    const uint32_t rb = blockIdx.x - d.nb_c, nrb = gridDim.x - d.nb_c;
+    if (d.fused3) {
+      // three-launch sweeps: both passes here, handed over inside the launch (the scatter pass has no
+      // later launch to ride on before the next phi pass needs its lists)
+      __shared__ unsigned long long scan_lds[NWV + 1];
+      cls_classify_in_launch<NWORK, NTH>(geo, d, prm, shw, rb, nrb, scan_lds, &hflag);
+    } else {
+      cls_count_tiles<NWORK>(geo, d, prm, shw, rb, nrb, true);   // count pass; the scatter pass rides on k_tail
+    }
     STAMP(2, 7);
     return;
   }
+  // the log table for the serial stage of a three-launch sweep: fetched now, used by the last block only
+  double2 ltv = make_double2(0.0, 0.0);
+  double suma = 0.0;   // sum[k] of this sweep (k_finalize_lpl's block 0 left it in kvec_a)
+  if (d.fused3 && threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
+  if (d.fused3 && threadIdx.x < geo.K) suma = d.kvec_a[threadIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
@@ -546,16 +697,89 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   if (threadIdx.x < K) {
     double t = 0.0;
     for (int w = 0; w < NWV; ++w) t += red[w][threadIdx.x];
-    d.part_c[(size_t)blockIdx.x * K + threadIdx.x] = t;
+    if (d.fused3) st_agent(&d.part_c[(size_t)blockIdx.x * K + threadIdx.x], t);   // read by the last block of THIS launch
+    else d.part_c[(size_t)blockIdx.x * K + threadIdx.x] = t;
   }
   STAMP(2, 2);
   if constexpr (KC <= 16) {
-    if (d.fold && blockIdx.x == 0) {   // s1, s2 of this sweep for k_tail
+    if (d.fold && blockIdx.x == 0) {   // s1, s2 of this sweep (folded from k_finalize_lpl's partial rows)
       __syncthreads();
       double *tmp = &lds[0][0];        // 16 row groups x 64 columns; the staging area is free again
       __shared__ double out64[64];
-      fold_rows<64, 1024>(d.part_b, d.nb_b, 2 * K, tmp, out64);
-      if (threadIdx.x < 2 * K) d.kvec_c[threadIdx.x] = out64[threadIdx.x];
+      fold_rows<64, NTH>(d.part_b, d.nb_b, 2 * K, tmp, out64);
+      if (threadIdx.x < 2 * K) {
+        if (d.fused3) st_agent(&d.kvec_c[threadIdx.x], out64[threadIdx.x]);
+        else d.kvec_c[threadIdx.x] = out64[threadIdx.x];
+      }
+    }
+    if (d.fused3) {
+      // ---- three-launch sweeps: the last s3 block to arrive closes the sweep -------------------------
+      // s3 = its blocks' partial rows in block order; lambda update + set_dir_exp(lambda)
+      // (src/linksampling.cc:748-759); write_comm for the next sweep (:768-774), _iter++ (:787).  The
+      // likelihood row, stop rule and annealing switch of this sweep follow as a role of the next launch.
+      if (!last_block_arrives(d.s3_ctl, d.nb_c, &hflag)) return;
+      __shared__ double2 logtab[128];
+      __shared__ double s3tot[32];
+      double *tmp = &lds[0][0];
+      if (threadIdx.x < 128) logtab[threadIdx.x] = ltv;
+      {
+        constexpr uint32_t RG = NTH / 32, NL = 256 / RG;   // row groups x 32 columns; nb_c <= 192 rows
+        const uint32_t c = threadIdx.x & 31u, r0 = threadIdx.x >> 5;
+        double v[NL];
+#pragma unroll
+        for (uint32_t i = 0; i < NL; ++i) {
+          const uint32_t r = r0 + RG * i;
+          v[i] = (c < K && r < d.nb_c) ? ld_agent(&d.part_c[(size_t)r * K + c]) : 0.0;
+        }
+        double t = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < NL; ++i) t += v[i];
+        tmp[r0 * 32 + c] = t;
+      }
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < NTH / 32; ++i) t += tmp[i * 32 + threadIdx.x];
+        s3tot[threadIdx.x] = t;
+      }
+      __syncthreads();
+      if (threadIdx.x < K) {
+        const uint32_t k = threadIdx.x;
+        const double s1 = ld_agent(&d.kvec_c[k]), s2 = ld_agent(&d.kvec_c[K + k]);
+        const double l0 = prm.eta0 + suma;
+        const double l1 = prm.eta1 + (s1 * s1 - s2 - s3tot[k]);
+        d.lambda[2 * k] = l0;
+        d.lambda[2 * k + 1] = l1;
+        d.kvec_c[2 * K + k] = s3tot[k];
+        const double ps = digamma(l0 + l1, logtab);
+        d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
+        d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
+      }
+      DevCtrl *c = d.ctrl;   // field by field: a whole-struct copy goes through scratch
+      const uint32_t cpar0 = c->cls_par;
+      uint32_t *ltot = d.ltot + cpar0 * 8u;
+      if (threadIdx.x == 0) {
+        const uint32_t iter = c->iter, sd = c->sweeps_done;
+        const unsigned long long ld0 = ltot[3], ld1 = ltot[4], ld2 = ltot[5];
+        c->parity ^= 1u;  // prune()'s flags become current
+        c->links_dense = ld0; c->links_sparse = ld1; c->links_shortcut = ld2;
+        if (d.sweep_stats) {
+          unsigned long long *st = d.sweep_stats + (size_t)(sd % d.sweep_stats_cap) * 4;
+          st[0] = ld0; st[1] = ld1; st[2] = ld2; st[3] = sd;
+        }
+        c->sweeps_done = sd + 1u;
+        c->write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+        c->v_pending = (d.nv > 0 && iter % prm.reportfreq == 0) ? 1u : 0u;
+        c->v_iter = iter;
+        c->iter = iter + 1;
+        c->cls_par = cpar0 ^ 1u;   // the classes this launch's roles computed for the next sweep become current
+      }
+      // the link counts / shortcut histogram of the finished sweep are consumed: clear them for the
+      // classification two sweeps ahead
+      __syncthreads();
+      if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
+      if (threadIdx.x < K) d.shist[(size_t)cpar0 * K + threadIdx.x] = 0ull;
     }
   }
 }
@@ -605,15 +829,26 @@ void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, h
   hipLaunchKernelGGL(k_cls_count, dim3(nb), dim3(1024), 0, s, g, d, p);
   hipLaunchKernelGGL(k_cls_scatter, dim3(nb), dim3(1024), 0, s, g, d);
 }
-uint32_t lpl_s3_threads(uint32_t K) { return K > 32 ? 512u : 1024u; }
+uint32_t lpl_s3_threads(uint32_t K) { return K > 20 ? 512u : 1024u; }
+// validation-role blocks: two pairs per group and pass, at most 64 blocks (the last one adds the
+// partials serially)
+uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K) {
+  if (nv == 0) return 1;
+  const uint32_t per_block = (uint32_t)lpl_phi_waves(K) * (uint32_t)(64 / g.W) * 2u;
+  uint32_t nb = (nv + per_block - 1) / per_block;
+  return nb > 64u ? 64u : nb;
+}
+void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  hipLaunchKernelGGL(k_validate_lpl, dim3(d.nvb ? d.nvb : 1u), dim3(256), 0, s, g, d, p);
+}
 uint32_t lpl_finalize_waves() { return FIN_WAVES; }
-// count-pass blocks riding on the s3 launch (one worker per 256 threads): with the <= 192 s3 blocks
-// at most one block per CU
+// classification blocks riding on the s3 launch (one worker per 256 threads, ideally one tile each)
 uint32_t lpl_cls_blocks(const DeviceState &d) {
   if (!d.cls_next) return 0;
   const uint32_t wpb = d.s3_threads / 256u;
-  uint32_t nb = (d.cls_ntiles + wpb - 1u) / wpb;
-  if (nb > 64u) nb = 64u;
+  const uint32_t tpw = d.fused3 ? 2u : 1u;   // three-launch sweeps: two tiles per worker stay in registers
+  uint32_t nb = (d.cls_ntiles + tpw * wpb - 1u) / (tpw * wpb);
+  if (nb > 64u) nb = 64u;      // with the <= 192 s3 blocks: one block per CU, all resident together
   return nb ? nb : 1u;
 }
 // scatter-pass blocks (one worker each) riding on the tail launch
@@ -624,8 +859,8 @@ uint32_t lpl_scatter_blocks(const DeviceState &d) {
 }
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define CALL(KC_)                                                                                   \
-  hipLaunchKernelGGL((k_phi_lpl<KC_, lpl_waves(KC_)>), dim3(d.nb_a), dim3(64 * lpl_waves(KC_)), 0, s, \
-                     g, d, p)
+  hipLaunchKernelGGL((k_phi_lpl<KC_, lpl_waves(KC_)>), dim3(d.nb_a + (d.fused3 ? d.nvb : 0u)),      \
+                     dim3(64 * lpl_waves(KC_)), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }
