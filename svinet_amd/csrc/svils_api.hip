@@ -664,6 +664,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     guard(dalloc(h, &d.s3_ctl, 4));
     guard(dalloc(h, &d.cls_sync, 4));
     guard(dalloc(h, &d.tbase, tiles_all));
+    guard(dalloc(h, &d.tpoll, tiles_all));
     if (g.K <= 32) guard(dalloc(h, &d.gacc0, (size_t)g.n_alloc * g.ld));   // three-launch sweeps accumulate beside gamma
     // ltot [2][8] u32 | shist [2][K] u64, cleared together before a stand-alone classification
     h->cls_zero_bytes = 64 + 2 * (size_t)g.K * sizeof(unsigned long long);

@@ -305,8 +305,11 @@ __device__ __forceinline__ void cls_prefix_handoff(const DeviceState &d, uint32_
 // Both passes by the same worker inside ONE launch (three-launch sweeps).  When every worker has at
 // most two 1024-entry tiles -- graphs up to a few hundred thousand links, where each dependent global
 // access is a visible share of the sweep -- the entries and their classes stay in registers across
-// the hand-off, so the scatter half touches no input again; otherwise the two generic passes run
-// back to back.
+// the hand-off, so the scatter half touches no input again, and the hand-off itself is ticket-free:
+// a worker publishes {epoch, class-0 count, class-1 count} of its tiles with agent-scope stores and
+// every worker adds up the entries below its own tiles, re-reading an entry until it carries this
+// launch's epoch (only role blocks ever wait, all of them resident next to the s3 blocks; bounded
+// spin).  Otherwise the two generic passes run back to back around cls_prefix_handoff.
 template <int NWORK, int NTH>
 __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, const DeviceState &d, const Params &prm,
                                                        ClsWork (&shw)[NWORK], uint32_t rb, uint32_t nrb,
@@ -321,7 +324,7 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
   }
   const uint32_t conv_idx = d.cls_args[0];
   const bool sparse_iter = d.cls_args[1] != 0u;
-  const uint32_t par = d.cls_args[2];
+  const uint32_t par = d.cls_args[2], epoch = d.cls_args[3];
   const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
   uint32_t *ltot = d.ltot + par * 8u;
   unsigned long long *shist = d.shist + (size_t)par * geo.K;
@@ -394,7 +397,7 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
     excl[t] = woff + inc - n01[t];
     const uint32_t tile = rw + t * nrw;
     if (tile < d.cls_ntiles && tid == 0)
-      st_agent(&d.tcnt[tile], ((unsigned long long)(ttot & 0xffffu) << 32) | (unsigned long long)(ttot >> 16));
+      st_agent(&d.tpoll[tile], ((unsigned long long)epoch << 32) | (unsigned long long)ttot);   // n0 | n1 << 16, <= 1024 each
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -413,15 +416,43 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
       else atomicAdd(&ltot[3 + (threadIdx.x - 64)], v);
     }
   }
-  cls_prefix_handoff<NTH>(d, nrb, scan_lds, flag_lds);
+  // ---- hand-off: class-0 / class-1 entries in the tiles below this worker's tiles ----
+  unsigned long long pre[T];
+  {
+    uint32_t acc0[T], acc1[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) { acc0[t] = 0; acc1[t] = 0; }
+    const uint32_t top = rw + (T - 1) * nrw < d.cls_ntiles ? rw + (T - 1) * nrw : (rw < d.cls_ntiles ? rw : 0u);
+    for (uint32_t i = tid; i < top; i += 256u) {
+      unsigned long long v;
+      uint32_t spins = 0;
+      while ((uint32_t)((v = ld_agent(&d.tpoll[i])) >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 20)) { d.cls_sync[2] = 1u; break; }   // never spin unbounded: flag the error
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (i < rw + t * nrw) { acc0[t] += (uint32_t)v & 0xffffu; acc1[t] += ((uint32_t)v >> 16) & 0xffffu; }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      unsigned long long w = ((unsigned long long)acc0[t] << 32) | acc1[t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) w += (unsigned long long)__shfl_xor((long long)w, o, 64);
+      __syncthreads();
+      if (lane == 0) sh.wred[wv] = w;
+      __syncthreads();
+      pre[t] = sh.wred[0] + sh.wred[1] + sh.wred[2] + sh.wred[3];
+    }
+  }
+  (void)scan_lds; (void)flag_lds;
   // (no block barrier below: workers and tiles finish on their own)
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const uint32_t tile = rw + t * nrw;
     if (tile >= d.cls_ntiles) continue;
     const uint64_t e0 = (uint64_t)(d.cls_tile0 + tile) * 1024u + 4u * tid;
-    const unsigned long long pre = ld_agent(&d.tbase[tile]);
-    uint32_t pos0 = (uint32_t)(pre >> 32) + (excl[t] & 0xffffu), pos1 = (uint32_t)pre + (excl[t] >> 16);
+    uint32_t pos0 = (uint32_t)(pre[t] >> 32) + (excl[t] & 0xffffu), pos1 = (uint32_t)pre[t] + (excl[t] >> 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint64_t e = e0 + j;

@@ -95,6 +95,7 @@ struct DeviceState {
   uint32_t *s3_ctl;               // [4] arrival ticket of the s3 blocks
   uint32_t *cls_sync;             // [4] [0] arrival ticket of the classification role blocks, [1] prefix-ready epoch
   unsigned long long *tbase;      // [ntiles] exclusive class-0 << 32 | class-1 prefix per tile (fused3 scatter)
+  unsigned long long *tpoll;      // [ntiles] epoch << 32 | class-1 << 16 | class-0 counts of 1024-entry tiles (ticket-free hand-off)
   double *gacc0;                  // [n_alloc][ld] phi accumulator of the fused3 path (gamma stays intact until finalise)
   unsigned long long *sweep_stats;  // [sweep_stats_cap][4] ring: dense, sparse, shortcut links and index of each sweep
   uint32_t sweep_stats_cap;

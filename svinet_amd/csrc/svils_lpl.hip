@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
 #pragma unroll
       for (int k = 0; k < KR; ++k) m = max_f64(m, phi[k]);   // padding columns are -inf via eb[]
       if (m != NEG_INF) {
+        STAMP(0, 5);
         int best = 0;
 #pragma unroll
         for (int k = KR - 1; k >= 0; --k) best = (phi[k] == m) ? k : best;   // first strict maximum
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
         for (int k = 0; k < KR; ++k) phi[k] *= inv;
         // community tagging: the first strict maximum of phi is 1/s
         if (write_comm && inv > prm.link_thresh) tagk = best;
+        STAMP(0, 6);
       } else {
         dense_row = false;  // empty active-set union (:642-664): the row is zero
       }
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
       __builtin_amdgcn_wave_barrier();
     }
 #undef LPL_FLUSH
+    STAMP(0, 7);
   }
 
   // per-block partial of `sum` (src/linksampling.cc:625,630,663,700 summed per node): waves in
@@ -606,8 +609,11 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   __shared__ ClsWork shw[NWORK];
   STAMP(2, 0);
   __shared__ uint32_t hflag;
-  if (blockIdx.x >= d.nb_c) {   // the blocks after the s3 blocks: link classes of the NEXT sweep
-    const uint32_t rb = blockIdx.x - d.nb_c, nrb = gridDim.x - d.nb_c;
+  // three-launch sweeps: the very last block only folds s1, s2 from k_finalize_lpl's partial rows, from the
+  // start of the launch, so that nobody on the critical path has to (it arrives on the s3 ticket like an s3 block)
+  const bool fold_role = d.fused3 && blockIdx.x == gridDim.x - 1u;
+  if (blockIdx.x >= d.nb_c && !fold_role) {   // the blocks after the s3 blocks: link classes of the NEXT sweep
+    const uint32_t rb = blockIdx.x - d.nb_c, nrb = gridDim.x - d.nb_c - (d.fused3 ? 1u : 0u);
     if (d.fused3) {
       // three-launch sweeps: both passes here, handed over inside the launch (the scatter pass has no
       // later launch to ride on before the next phi pass needs its lists)
@@ -622,8 +628,20 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   // the log table for the serial stage of a three-launch sweep: fetched now, used by the last block only
   double2 ltv = make_double2(0.0, 0.0);
   double suma = 0.0;   // sum[k] of this sweep (k_finalize_lpl's block 0 left it in kvec_a)
-  if (d.fused3 && threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
-  if (d.fused3 && threadIdx.x < geo.K) suma = d.kvec_a[threadIdx.x];
+  // ... and what its thread 0 needs from the control block and the class totals: all of it is at rest
+  // until that block itself writes, so every block fetches it up front and only the last one uses it
+  uint32_t c_iter = 0, c_sd = 0, c_cpar = 0, c_par = 0;
+  unsigned long long c_l0 = 0, c_l1 = 0, c_l2 = 0;
+  if (d.fused3) {
+    if (threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
+    if (threadIdx.x < geo.K) suma = d.kvec_a[threadIdx.x];
+    c_cpar = ctrl->cls_par;
+    if (threadIdx.x == 0) {
+      c_iter = ctrl->iter; c_sd = ctrl->sweeps_done; c_par = ctrl->parity;
+      const uint32_t *lt = d.ltot + c_cpar * 8u;
+      c_l0 = lt[3]; c_l1 = lt[4]; c_l2 = lt[5];
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   double s3[KR];
 #pragma unroll
   for (int k = 0; k < KR; ++k) s3[k] = 0.0;
-  const uint64_t nl = d.link_end - d.link_begin;
+  const uint64_t nl = fold_role ? 0 : d.link_end - d.link_begin;
   for (uint64_t i = (uint64_t)blockIdx.x * NTH + threadIdx.x; i < nl; i += (uint64_t)d.nb_c * NTH) {
     const uint64_t l = d.link_begin + i;
     const uint32_t p = d.links[2 * l], q = d.links[2 * l + 1];
@@ -694,7 +712,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
     if (lane < KR) red[wave][lane] = tot;
   }
   __syncthreads();
-  if (threadIdx.x < K) {
+  if (threadIdx.x < K && !fold_role) {
     double t = 0.0;
     for (int w = 0; w < NWV; ++w) t += red[w][threadIdx.x];
     if (d.fused3) st_agent(&d.part_c[(size_t)blockIdx.x * K + threadIdx.x], t);   // read by the last block of THIS launch
@@ -702,7 +720,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   }
   STAMP(2, 2);
   if constexpr (KC <= 16) {
-    if (d.fold && blockIdx.x == 0) {   // s1, s2 of this sweep (folded from k_finalize_lpl's partial rows)
+    if (d.fold && (d.fused3 ? fold_role : blockIdx.x == 0)) {   // s1, s2 of this sweep (folded from k_finalize_lpl's partial rows)
       __syncthreads();
       double *tmp = &lds[0][0];        // 16 row groups x 64 columns; the staging area is free again
       __shared__ double out64[64];
@@ -717,11 +735,14 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
       // s3 = its blocks' partial rows in block order; lambda update + set_dir_exp(lambda)
       // (src/linksampling.cc:748-759); write_comm for the next sweep (:768-774), _iter++ (:787).  The
       // likelihood row, stop rule and annealing switch of this sweep follow as a role of the next launch.
-      if (!last_block_arrives(d.s3_ctl, d.nb_c, &hflag)) return;
+      STAMP(2, 3);
+      if (!last_block_arrives(d.s3_ctl, d.nb_c + 1u, &hflag)) return;
+      STAMP(2, 4);
       __shared__ double2 logtab[128];
       __shared__ double s3tot[32];
       double *tmp = &lds[0][0];
       if (threadIdx.x < 128) logtab[threadIdx.x] = ltv;
+      double s1 = 0.0, s2 = 0.0;
       {
         constexpr uint32_t RG = NTH / 32, NL = 256 / RG;   // row groups x 32 columns; nb_c <= 192 rows
         const uint32_t c = threadIdx.x & 31u, r0 = threadIdx.x >> 5;
@@ -731,6 +752,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
           const uint32_t r = r0 + RG * i;
           v[i] = (c < K && r < d.nb_c) ? ld_agent(&d.part_c[(size_t)r * K + c]) : 0.0;
         }
+        if (threadIdx.x < K) { s1 = ld_agent(&d.kvec_c[threadIdx.x]); s2 = ld_agent(&d.kvec_c[K + threadIdx.x]); }   // same wait
         double t = 0.0;
 #pragma unroll
         for (uint32_t i = 0; i < NL; ++i) t += v[i];
@@ -746,7 +768,6 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
       __syncthreads();
       if (threadIdx.x < K) {
         const uint32_t k = threadIdx.x;
-        const double s1 = ld_agent(&d.kvec_c[k]), s2 = ld_agent(&d.kvec_c[K + k]);
         const double l0 = prm.eta0 + suma;
         const double l1 = prm.eta1 + (s1 * s1 - s2 - s3tot[k]);
         d.lambda[2 * k] = l0;
@@ -757,16 +778,15 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
         d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
       }
       DevCtrl *c = d.ctrl;   // field by field: a whole-struct copy goes through scratch
-      const uint32_t cpar0 = c->cls_par;
+      const uint32_t cpar0 = c_cpar;
       uint32_t *ltot = d.ltot + cpar0 * 8u;
       if (threadIdx.x == 0) {
-        const uint32_t iter = c->iter, sd = c->sweeps_done;
-        const unsigned long long ld0 = ltot[3], ld1 = ltot[4], ld2 = ltot[5];
-        c->parity ^= 1u;  // prune()'s flags become current
-        c->links_dense = ld0; c->links_sparse = ld1; c->links_shortcut = ld2;
+        const uint32_t iter = c_iter, sd = c_sd;
+        c->parity = c_par ^ 1u;  // prune()'s flags become current
+        c->links_dense = c_l0; c->links_sparse = c_l1; c->links_shortcut = c_l2;
         if (d.sweep_stats) {
           unsigned long long *st = d.sweep_stats + (size_t)(sd % d.sweep_stats_cap) * 4;
-          st[0] = ld0; st[1] = ld1; st[2] = ld2; st[3] = sd;
+          st[0] = c_l0; st[1] = c_l1; st[2] = c_l2; st[3] = sd;
         }
         c->sweeps_done = sd + 1u;
         c->write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
@@ -780,6 +800,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
       __syncthreads();
       if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
       if (threadIdx.x < K) d.shist[(size_t)cpar0 * K + threadIdx.x] = 0ull;
+      STAMP(2, 5);
     }
   }
 }
@@ -846,9 +867,11 @@ uint32_t lpl_finalize_waves() { return FIN_WAVES; }
 uint32_t lpl_cls_blocks(const DeviceState &d) {
   if (!d.cls_next) return 0;
   const uint32_t wpb = d.s3_threads / 256u;
-  const uint32_t tpw = d.fused3 ? 2u : 1u;   // three-launch sweeps: two tiles per worker stay in registers
-  uint32_t nb = (d.cls_ntiles + tpw * wpb - 1u) / (tpw * wpb);
-  if (nb > 64u) nb = 64u;      // with the <= 192 s3 blocks: one block per CU, all resident together
+  // one tile per worker when the s3 blocks leave enough CUs for that many blocks, else two (three-launch
+  // sweeps keep up to two tiles per worker in registers), never more than 64 blocks
+  uint32_t nb = (d.cls_ntiles + wpb - 1u) / wpb;
+  if (nb + d.nb_c > 240u) nb = (d.cls_ntiles + 2u * wpb - 1u) / (2u * wpb);
+  if (nb > 64u) nb = 64u;
   return nb ? nb : 1u;
 }
 // scatter-pass blocks (one worker each) riding on the tail launch
@@ -877,7 +900,7 @@ void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &
 #undef FIN
 }
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d)), dim3(s3_threads(KC_)), 0, s, g, d, p)
+#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d) + (d.fused3 ? 1u : 0u)), dim3(s3_threads(KC_)), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }
