@@ -185,12 +185,20 @@ __global__ __launch_bounds__(256) void k_validate_lpl(Geometry geo, DeviceState 
 }
 
 // ============================================================== phi pass (A6)
-template <int KC, int NW>
-__global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+// PIPE (K <= 32): few fat waves (two per SIMD) walk several wave-items each, software-pipelined --
+// the index pair of item i+2 and the 2*KC row chunks of item i+1 are in flight while item i runs its
+// exps, its LDS staging and its column walk, so the gather latency (every row is an L2 miss: the
+// finalise launch has just rewritten Elogpi) is paid once per wave, not once per item, and the time
+// of the launch follows the number of items.  All 64 phi rows go through LDS in one pass.
+// !PIPE (K = 33..64): the row pair no longer fits beside the phi row; one item at a time, the 64
+// rows staged in two passes of 32 (half the LDS per wavefront).
+template <int KC, int NW, bool PIPE>
+__global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(0, 0);
   DevCtrl *ctrl = d.ctrl;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
-  __shared__ __attribute__((aligned(16))) double lds[NW][32 * SROW];
+  constexpr int NPASS = PIPE ? 1 : 2, RP = 64 / NPASS;   // staging passes, rows per pass
+  __shared__ __attribute__((aligned(16))) double lds[NW][RP * SROW];
   __shared__ double red[NW][64];
   if (blockIdx.x >= d.nb_a) {
     // extra workgroups of a three-launch sweep: likelihood + stop rule of the PREVIOUS sweep, on CUs the
@@ -200,44 +208,77 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
     lpl_validation_role(geo, d, prm, blockIdx.x - d.nb_a, gridDim.x - d.nb_a, reinterpret_cast<double (*)[3]>(&red[0][0]), &vflag);
     return;
   }
-  if (ctrl->stopped) return;
-  STAMP(0, 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t K = geo.K, ld = geo.ld;
-  const bool write_comm = ctrl->write_comm != 0;
-  const uint32_t cpar = ctrl->cls_par;
-  const uint32_t tot0 = d.ltot[cpar * 8u], tot1 = d.ltot[cpar * 8u + 1u];
-  const uint32_t n0 = (tot0 + 63u) >> 6, n1 = (tot1 + 63u) >> 6;
-  const double *__restrict__ elogpi = d.elogpi;
-  double *mylds = lds[wave];
-
+  // everything the first item needs from memory is at rest during this launch: fetch it in one go
+  // (both parities of the class totals, so that nothing waits for cls_par first)
+  const uint32_t stopped = ctrl->stopped, wcomm = ctrl->write_comm, cpar = ctrl->cls_par;
+  const uint32_t t00 = d.ltot[0], t01 = d.ltot[1], t10 = d.ltot[8], t11 = d.ltot[9];
   // Elogbeta[.][0], wave-uniform but kept in LDS/VGPRs on purpose: as KR scalar pairs it made the
   // SGPR file spill through v_writelane/v_readlane inside the hot loop.  Padding columns
   // (k >= K) get -inf, which masks them in the softmax without any select.
   __shared__ double eb[KR];
-  if (threadIdx.x < KR) eb[threadIdx.x] = (threadIdx.x < K) ? d.elogbeta[2 * threadIdx.x] : NEG_INF;
+  const uint32_t K = geo.K, ld = geo.ld;
+  double ebv = NEG_INF;
+  if (threadIdx.x < K) ebv = d.elogbeta[2 * threadIdx.x];
+  if (stopped) return;
+  STAMP(0, 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool write_comm = wcomm != 0;
+  const uint32_t tot0 = cpar ? t10 : t00, tot1 = cpar ? t11 : t01;
+  const uint32_t n0 = (tot0 + 63u) >> 6, n1 = (tot1 + 63u) >> 6, nit = n0 + n1;
+  const double *__restrict__ elogpi = d.elogpi;
+  double *mylds = lds[wave];
+  const uint32_t step = d.nb_a * NW;
+  uint32_t it = blockIdx.x * NW + wave;
+
+  // index pair of this lane's entry of wave-item i (p = ~0: none)
+  auto fetch_idx = [&](uint32_t i, uint32_t &pp, uint32_t &qq) {
+    pp = 0xffffffffu; qq = 0;
+    if (i < nit) {
+      const uint32_t l = i >= n0 ? 1u : 0u;
+      const uint32_t g = (l ? i - n0 : i) * 64u + lane;
+      if (g < (l ? tot1 : tot0)) { pp = d.cp[l][g]; qq = d.cq[l][g]; }
+    }
+  };
+  auto fetch_rows = [&](uint32_t pp, uint32_t qq, double2 (&ra)[PIPE ? KC : 1], double2 (&rb)[PIPE ? KC : 1]) {
+    if (PIPE && pp != 0xffffffffu) {
+      const double *rp = elogpi + (size_t)pp * ld, *rq = elogpi + (size_t)qq * ld;
+#pragma unroll
+      for (int c = 0; c < (PIPE ? KC : 1); ++c) {
+        ra[c] = *reinterpret_cast<const double2 *>(rp + 2 * c);
+        rb[c] = *reinterpret_cast<const double2 *>(rq + 2 * c);
+      }
+    }
+  };
+  uint32_t p, q, pn = 0xffffffffu, qn = 0;
+  double2 ra[PIPE ? KC : 1], rb[PIPE ? KC : 1];
+  fetch_idx(it, p, q);
+  if constexpr (PIPE) {
+    fetch_rows(p, q, ra, rb);
+    fetch_idx(it + step, pn, qn);
+  }
+  if (threadIdx.x < KR) eb[threadIdx.x] = ebv;
   __syncthreads();
   double csum = 0.0;  // lane k: partial of sum[k]
   STAMP(0, 2);
 
-  for (uint32_t it = blockIdx.x * NW + wave; it < n0 + n1; it += d.nb_a * NW) {
+#pragma unroll 1
+  for (; it < nit; it += step) {
     const uint32_t list = it >= n0 ? 1u : 0u;            // wave-uniform
     const uint32_t w = list ? it - n0 : it;
-    const uint32_t g = w * 64u + lane;
-    const bool valid = g < (list ? tot1 : tot0);
-    uint32_t p = 0xffffffffu, q = 0;
-    if (valid) {
-      p = d.cp[list][g];
-      q = d.cq[list][g];
-    }
+    const bool valid = p != 0xffffffffu;
     double phi[KR];
-    double *mine = mylds + (lane & 31) * SROW;   // this lane's staged phi row (two passes of 32 rows)
+    double *mine = mylds + (lane % RP) * SROW;   // this lane's staged phi row
     int tagk = -1;   // community this link tags (src/linksampling.cc:668-681,704-717), -1: none
     bool dense_row = false;
     if (valid) {
-      dense_row = true;
       // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686)
-      {
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          phi[2 * c] = (ra[c].x + rb[c].x) + eb[2 * c];
+          phi[2 * c + 1] = (ra[c].y + rb[c].y) + eb[2 * c + 1];
+        }
+      } else {
         const double *rp = elogpi + (size_t)p * ld, *rq = elogpi + (size_t)q * ld;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
@@ -247,8 +288,18 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
           phi[2 * c + 1] = (a.y + b.y) + eb[2 * c + 1];
         }
       }
+    }
+    unsigned long long inmask = ~0ull;
+    if (list && valid) inmask = d.amask[p] | d.amask[q];   // kw == 1 for K <= 64
+    if constexpr (PIPE) {
+      // the row registers are free again: rows of the next item, index pair of the one after it
+      fetch_rows(pn, qn, ra, rb);
+    }
+    uint32_t pnn = 0xffffffffu, qnn = 0;
+    if constexpr (PIPE) fetch_idx(it + 2 * step, pnn, qnn);
+    if (valid) {
+      dense_row = true;
       if (list) {   // active-set path (:634-681): columns outside the union of the two active sets drop out
-        const unsigned long long inmask = d.amask[p] | d.amask[q];   // kw == 1 for K <= 64
 #pragma unroll
         for (int k = 0; k < KR; ++k) phi[k] = ((inmask >> k) & 1ull) ? phi[k] : NEG_INF;
       }
@@ -287,8 +338,7 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
       }
     }
     // Stage the phi rows in LDS and let lane k sum column k over them in entry order, flushing at
-    // node boundaries.  The 64 rows go through LDS in two passes of 32 (lanes 0-31, then 32-63):
-    // half the LDS per wavefront, so that the register file, not LDS, sets the occupancy.
+    // node boundaries.
     // heads of the node runs: bit r set <=> row r starts a new node
     const uint32_t pprev = __shfl_up((int)p, 1, 64);
     const unsigned long long heads = __ballot(lane == 0 || p != pprev);
@@ -330,8 +380,8 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
       acc = 0.0;                                                                            \
     } while (0)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if ((lane >> 5) == half) {
+    for (int pass = 0; pass < NPASS; ++pass) {
+      if (NPASS == 1 || (lane >> 5) == pass) {
         if (dense_row) {
 #pragma unroll
           for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(phi[2 * c], phi[2 * c + 1]);
@@ -345,20 +395,20 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if ((uint32_t)lane < K) {
 #pragma unroll 1
-        for (int rb = 0; rb < 32; rb += 16) {
+        for (int rb0 = 0; rb0 < RP; rb0 += 16) {
           double v[16];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = mylds[(rb + j) * SROW + lane];
+          for (int j = 0; j < 16; ++j) v[j] = mylds[(rb0 + j) * SROW + lane];
           // a chunk without a run boundary (about half of them at an average degree of 22) is 16 plain adds
-          uint32_t hb = (uint32_t)(heads >> (half * 32 + rb)) & 0xffffu;
-          if (half * 32 + rb == 0) hb &= ~1u;
+          uint32_t hb = (uint32_t)(heads >> (pass * RP + rb0)) & 0xffffu;
+          if (pass * RP + rb0 == 0) hb &= ~1u;
           if (hb == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc += v[j];
           } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-              const int r = half * 32 + rb + j;
+              const int r = pass * RP + rb0 + j;
               if (r > 0 && ((heads >> r) & 1ull)) {      // run [a, r-1] ends (wave-uniform branch)
                 LPL_FLUSH((a == 0) ? slotf : direct + (size_t)cur * ld, r - 1);
                 a = r;
@@ -368,13 +418,15 @@ __global__ __launch_bounds__(64 * NW, (KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_
           }
         }
         // last run ends at lane 63
-        if (half == 1) LPL_FLUSH((a == 0) ? slotf : slotl, 63);
+        if (pass == NPASS - 1) LPL_FLUSH((a == 0) ? slotf : slotl, 63);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
 #undef LPL_FLUSH
     STAMP(0, 7);
+    if constexpr (PIPE) { p = pn; q = qn; pn = pnn; qn = qnn; }
+    else fetch_idx(it + step, p, q);
   }
 
   // per-block partial of `sum` (src/linksampling.cc:625,630,663,700 summed per node): waves in
@@ -807,13 +859,19 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
 
 // ------------------------------------------------------------------ launchers
 bool use_lpl(uint32_t K) { return K <= 64; }
-// waves per block of k_phi_lpl.  The register file holds 4 waves per SIMD up to K = 24 and 3 for
-// K = 25..32 (a phi row of more than 128 VGPRs): two blocks per CU fill it, and a grid of two blocks
-// per CU leaves at most SVILS_FOLD_ROWS partial rows of `sum` for the consumers to fold.  (One
-// 16-wave block per CU measured 25 % slower on ca-AstroPh K = 20, 256-thread blocks 2 % faster.)
-// K = 33..64: a phi row of up to 128 VGPRs, two waves per SIMD, blocks of four waves.
-constexpr int lpl_waves(int kc) { return kc >= 18 ? 4 : kc >= 14 ? 6 : 8; }
-int lpl_phi_waves(uint32_t K) { return K > 32 ? 4 : K > 24 ? 6 : 8; }
+// waves per block of k_phi_lpl, two blocks per CU either way (a grid of two blocks per CU leaves at
+// most SVILS_FOLD_ROWS partial rows of `sum` for the consumers to fold).  K <= 32: the pipelined
+// kernel, LPL_PIPE_WAVES / 2 waves per SIMD with up to 256 VGPRs each.  K = 33..64: a phi row of up
+// to 128 VGPRs, two waves per SIMD, blocks of four waves.
+#ifndef LPL_PIPE_WAVES
+#define LPL_PIPE_WAVES 4
+#endif
+#ifndef LPL_PIPE
+#define LPL_PIPE 0
+#endif
+constexpr bool lpl_pipe(int kc) { return LPL_PIPE && kc <= 16; }
+constexpr int lpl_waves(int kc) { return lpl_pipe(kc) ? LPL_PIPE_WAVES : kc >= 18 ? 4 : kc >= 14 ? 6 : 8; }
+int lpl_phi_waves(uint32_t K) { return LPL_PIPE && K <= 32 ? LPL_PIPE_WAVES : K > 32 ? 4 : K > 24 ? 6 : 8; }
 
 #define LPL_DISPATCH(K_, CALL)                 \
   do {                                         \
@@ -835,7 +893,7 @@ int lpl_phi_waves(uint32_t K) { return K > 32 ? 4 : K > 24 ? 6 : 8; }
 uint32_t lpl_phi_resident_blocks(uint32_t K, int device) {
   int per_cu = 0, cus = 0;
 #define CALL(KC_) \
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_phi_lpl<KC_, lpl_waves(KC_)>, 64 * lpl_waves(KC_), 0)
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_phi_lpl<KC_, lpl_waves(KC_), lpl_pipe(KC_)>, 64 * lpl_waves(KC_), 0)
   LPL_DISPATCH(K, CALL);
 #undef CALL
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -882,7 +940,7 @@ uint32_t lpl_scatter_blocks(const DeviceState &d) {
 }
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define CALL(KC_)                                                                                   \
-  hipLaunchKernelGGL((k_phi_lpl<KC_, lpl_waves(KC_)>), dim3(d.nb_a + (d.fused3 ? d.nvb : 0u)),      \
+  hipLaunchKernelGGL((k_phi_lpl<KC_, lpl_waves(KC_), lpl_pipe(KC_)>), dim3(d.nb_a + (d.fused3 ? d.nvb : 0u)),      \
                      dim3(64 * lpl_waves(KC_)), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
