@@ -757,6 +757,7 @@ int svils_get_control(svils_handle *h, svils_control *out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
   out->iter = c.iter; out->annealing = c.annealing; out->write_comm = c.write_comm; out->nh = c.nh;
   out->prev_h = c.prev_h; out->max_h = c.max_h; out->stopped = c.stopped; out->why = c.why;
   out->sweeps_done = c.sweeps_done; out->rows = c.rows;
@@ -770,6 +771,7 @@ int svils_set_control(svils_handle *h, const svils_control *in) {
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
   c.iter = in->iter; c.annealing = in->annealing; c.write_comm = in->write_comm; c.nh = in->nh;
   c.prev_h = in->prev_h; c.max_h = in->max_h;
   HIPCHK(hipMemcpy(h->d.ctrl, &c, sizeof c, hipMemcpyHostToDevice));
@@ -1121,6 +1123,9 @@ int svils_synchronize(svils_handle *h) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_synchronize: null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  uint32_t fault = 0;
+  HIPCHK(hipMemcpy(&fault, &h->d.ctrl->fault, sizeof fault, hipMemcpyDeviceToHost));
+  if (fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
   return 0;
 }
 
@@ -1130,6 +1135,7 @@ int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
   if ((uint64_t)first + count > c.rows) return fail(SVILS_ERR_ARG, "rows [%u,%u) not recorded yet (have %u)", first, first + count, c.rows);
   if (c.rows - first > h->d.rows_cap) return fail(SVILS_ERR_ARG, "row %u already overwritten in the ring", first);
   // the ring wraps at rows_cap: at most two contiguous copies
@@ -1154,6 +1160,7 @@ int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *co
   if (converged) {
     DevCtrl c;
     HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
     HIPCHK(hipMemcpy(converged, h->d.conv + (size_t)c.parity * g.n_alloc, g.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   return 0;
@@ -1257,6 +1264,7 @@ int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint6
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
   if ((uint64_t)first + count > c.sweeps_done)
     return fail(SVILS_ERR_ARG, "sweeps [%u,%u) not run yet (have %u)", first, first + count, c.sweeps_done);
   if (c.sweeps_done - first > h->d.sweep_stats_cap) return fail(SVILS_ERR_ARG, "sweep %u is no longer in the ring", first);

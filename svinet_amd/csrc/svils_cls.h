@@ -295,7 +295,7 @@ __device__ __forceinline__ void cls_prefix_handoff(const DeviceState &d, uint32_
       uint32_t spins = 0;
       while (ld_agent(&d.cls_sync[1]) != epoch) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 22)) { d.cls_sync[2] = 1u; break; }   // never spin unbounded: flag the error
+        if (++spins > (1u << 22)) { d.ctrl->fault = 1u; d.ctrl->stopped = 1; break; }   // never spin unbounded: flag the error
       }
     }
     __syncthreads();
@@ -428,7 +428,7 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
       uint32_t spins = 0;
       while ((uint32_t)((v = ld_agent(&d.tpoll[i])) >> 32) != epoch) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 20)) { d.cls_sync[2] = 1u; break; }   // never spin unbounded: flag the error
+        if (++spins > (1u << 20)) { d.ctrl->fault = 1u; d.ctrl->stopped = 1; break; }   // never spin unbounded: flag the error
       }
 #pragma unroll
       for (int t = 0; t < T; ++t)

@@ -37,6 +37,10 @@ struct DevCtrl {
   // three-launch sweeps (fused small-K path): the held-out likelihood + stop rule of sweep v_iter has
   // been handed to the next launch (a role of the next phi launch, or k_validate_lpl)
   uint32_t v_pending, v_iter;
+  // set (with `stopped`) by a kernel whose bounded in-launch wait ran out -- only possible if the role
+  // blocks of a launch are not co-resident (a partitioned or masked device); every host entry that reads
+  // the control block turns it into SVILS_ERR_DEVICE
+  uint32_t fault;
 };
 
 struct Geometry {
