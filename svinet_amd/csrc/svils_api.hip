@@ -330,6 +330,11 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.gamma, nk));
   d.gacc = d.gamma;   // full sweeps accumulate gammanext in place
   guard(dalloc(h, &d.elogpi, nk));
+  // exp(Elogpi) for the product form of k_phi (K > 64) while an n-by-k array stays below 1.5 GB: there the phi
+  // pass is bound by fp64 issue and trades its exps for multiplies (ca-AstroPh K=200: 174 -> 120 us, n=2e5 K=512:
+  // 3.45 -> 3.02 ms); beyond that it runs at the HBM gather ceiling either way and the extra n-by-k write of the
+  // finalise pass would cost more than the exps (n=1e6 K=512: phi -0.6 ms, finalise +0.75 ms)
+  if (!use_lpl(g.K) && nk * sizeof(double) <= 1536ull << 20) guard(dalloc(h, &d.epi, nk));
   guard(dalloc(h, &d.mphi, nk));
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
   guard(dalloc(h, &d.active_cnt, g.n_alloc));

@@ -54,15 +54,30 @@ __device__ __forceinline__ void block_reduce_store(double (&part)[NV][V], double
   }
 }
 
+// exp(Elogpi) next to Elogpi for the row-per-wavefront phi kernel (K > 64): exp(a + b + c) = e^a e^b e^c
+// turns the K exps of every (link, direction) into K multiplies of per-node values; all three exponents
+// are <= 0, so the factors lie in (0, 1] and the product underflows exactly when the exp of the sum would.
+// Padding columns hold 0.  (Null for K <= 64: the lane-per-link kernels do not use it.)
+template <int W, int V>
+__device__ __forceinline__ void store_epi(const DeviceState &d, uint32_t p, int lw, uint32_t ld, uint32_t K,
+                                          const double (&el)[V]) {
+  if (!d.epi) return;
+  double e[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) e[v] = (uint32_t)kmap<W, V>(lw, v) < K ? exp_neg(el[v]) : 0.0;
+  store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, e);
+}
+
 // ============================================================== phi pass (A6)
 // src/linksampling.cc:605-725, pull-style, K > 32 (K <= 32 uses k_phi_lpl).  One
 // wavefront per Item (a chunk of <= 32 neighbours of one node), all 64 lanes on one
 // row, V doubles per lane.  The chunk's column indices and converged flags are
 // fetched with one coalesced load each, and the next neighbour's Elogpi row is in
 // flight while the current one is reduced (two rows per wave in flight).
-template <int V, bool LOWT>
+template <int V, bool LOWT, bool EPI>
 __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
   constexpr int W = 64;
+  constexpr bool PROD = EPI && !LOWT;   // product form on exp(Elogpi) rows, else exps of sums of Elogpi rows
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double lds[V * 64];
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
   const bool write_comm = ctrl->write_comm != 0;
   const bool sparse_iter = (long long)ctrl->iter > (long long)prm.sparse_after;  // _iter > 1000, src/linksampling.cc:634
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
-  const double *__restrict__ elogpi = d.elogpi;
+  const double *__restrict__ elogpi = PROD ? d.epi : d.elogpi;
 
   int kidx[V];
   bool kval[V];
@@ -82,6 +97,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
     kidx[v] = kmap<W, V>(lw, v);
     kval[v] = (uint32_t)kidx[v] < K;
     eb[v] = kval[v] ? d.elogbeta[2 * kidx[v]] : NEG_INF;   // -inf masks the padding columns
+    if constexpr (PROD) eb[v] = exp_neg(eb[v]);             // ... 0 in the product form
   }
   double csum[1][V];
 #pragma unroll
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
     double ap[V];
     load_row<W, V>(elogpi + (size_t)p * ld, lw, ld, ap);
 #pragma unroll
-    for (int v = 0; v < V; ++v) ap[v] += eb[v];   // padding columns -> -inf
+    for (int v = 0; v < V; ++v) ap[v] = PROD ? ap[v] * eb[v] : ap[v] + eb[v];   // padding columns -> 0 / -inf
     double acc[V];
     uint32_t cnt[V];
 #pragma unroll
@@ -149,7 +165,64 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
           }
           return t;
         };
-        if constexpr (!LOWT) {
+        if constexpr (PROD) {
+          // exp(x_k) = e^Elogpi[p][k] e^Elogbeta[k][0] * e^Elogpi[q][k]: one multiply per column (every
+          // exponent is <= 0, so nothing overflows and no max shift is needed): exp(x_k) / sum_j exp(x_j)
+          // with one cross-lane reduction.  Only when the whole row underflows (sum below 1e-280; also the
+          // empty active-set union) is it redone in the log domain with the shift.
+          double s = 0.0;
+          double e[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            e[v] = ap[v] * rcur[v];
+            if (sparse) {
+              const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
+              e[v] = ((um >> lw) & 1ull) ? e[v] : 0.0;
+            }
+            s += e[v];
+          }
+          s = group_sum<W>(s);
+          bool live = true;
+          if (s < 1e-280) {   // wave-uniform, rare: the log-domain rows from Elogpi, column by column to
+                              // keep the registers of the common path (two passes: max, then exp)
+            auto xlog = [&](int v) {
+              double t = NEG_INF;
+              if (kval[v]) t = (d.elogpi[(size_t)p * ld + kidx[v]] + d.elogbeta[2 * kidx[v]]) + d.elogpi[(size_t)q * ld + kidx[v]];
+              if (sparse) {
+                const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
+                t = ((um >> lw) & 1ull) ? t : NEG_INF;
+              }
+              return t;
+            };
+            double m = NEG_INF;
+#pragma unroll 1
+            for (int v = 0; v < V; ++v) m = fmax(m, xlog(v));
+            m = group_max<W>(m);
+            live = (m != NEG_INF);   // an empty active-set union contributes nothing (:642-664)
+            s = 0.0;
+            if (live) {
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                e[v] = exp_neg(xlog(v) - m);
+                s += e[v];
+              }
+              s = group_sum<W>(s);
+            }
+          }
+          if (live) {
+            const double inv = fast_rcp(s);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fma(e[v], inv, acc[v]);
+            // community tagging, src/linksampling.cc:668-681,704-717: tag the first strict maximum
+            // of phi if it exceeds link_thresh.  With link_thresh >= 1/2 (this instantiation) a phi
+            // above the threshold IS the strict maximum and is unique, so no argmax is needed.
+            if (write_comm) {
+              const double ts = prm.link_thresh * s;
+#pragma unroll
+              for (int v = 0; v < V; ++v) cnt[v] += (e[v] > ts) ? 1u : 0u;
+            }
+          }
+        } else if constexpr (!LOWT) {
           // Every x_k is <= 0 (Elogpi and Elogbeta are expectations of logs of probabilities), so the
           // softmax needs no max shift to stay finite: exp(x_k) / sum_j exp(x_j) directly -- one
           // cross-lane reduction instead of two.  Only when the whole row underflows (sum below
@@ -413,6 +486,7 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
       for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
     }
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_epi<W, V>(d, p, lw, ld, K, el);
     // prune / check_and_set_converged, src/linksampling.cc:455-475
     uint32_t active = 0;
     int last_k = -1;
@@ -472,6 +546,7 @@ __global__ __launch_bounds__(256) void k_dir_exp(Geometry geo, DeviceState d) {
 #pragma unroll
     for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_epi<W, V>(d, p, lw, ld, K, el);
   }
 }
 
@@ -533,6 +608,7 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
       for (int v = 0; v < V; ++v) m[v] = 0.0;
     }
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_epi<W, V>(d, p, lw, ld, K, el);
     store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
   }
@@ -700,6 +776,7 @@ __global__ __launch_bounds__(256) void k_expand_window(Geometry geo, DeviceState
 #pragma unroll
     for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
     store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_epi<W, V>(d, p, lw, ld, K, el);
     if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
   }
 }
@@ -1073,8 +1150,9 @@ void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStr
   // link_thresh < 1/2 needs the argmax form of the tagging rule (k_phi<V, true>)
 #define PHI(V_)                                                                                    \
   do {                                                                                             \
-    if (p.link_thresh < 0.5) hipLaunchKernelGGL((k_phi<V_, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); \
-    else hipLaunchKernelGGL((k_phi<V_, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);          \
+    if (p.link_thresh < 0.5) hipLaunchKernelGGL((k_phi<V_, true, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); \
+    else if (d.epi) hipLaunchKernelGGL((k_phi<V_, false, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);       \
+    else hipLaunchKernelGGL((k_phi<V_, false, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);                  \
   } while (0)
   switch (g.V) {   // K > 32 => W == 64
     case 1: PHI(1); break;
@@ -1095,12 +1173,12 @@ uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
 #define OCC(KERNEL) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0)
   if (which == 0) {
     switch (g.V) {
-      case 1: OCC((k_phi<1, false>)); break;
-      case 2: OCC((k_phi<2, false>)); break;
-      case 4: OCC((k_phi<4, false>)); break;
-      case 8: OCC((k_phi<8, false>)); break;
-      case 16: OCC((k_phi<16, false>)); break;
-      default: OCC((k_phi<32, false>)); break;
+      case 1: OCC((k_phi<1, false, false>)); break;
+      case 2: OCC((k_phi<2, false, false>)); break;
+      case 4: OCC((k_phi<4, false, false>)); break;
+      case 8: OCC((k_phi<8, false, false>)); break;
+      case 16: OCC((k_phi<16, false, false>)); break;
+      default: OCC((k_phi<32, false, false>)); break;
     }
   } else if (which == 2) {
 #define CALL(W_, V_) OCC((k_finalize<W_, V_, false>))
