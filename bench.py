@@ -149,7 +149,7 @@ def hbm_bound_record(device, sweeps=10):
     rec.update({"workload": "%s: n=%d k=%d links/sweep=%d, state %.2f GB per n-by-k array (3 resident)"
                             % (HBM_BOUND_WORKLOAD, n, k, L, n * 512 * 8 / 1e9),
                 "ms_per_sweep_eager": el / sweeps * 1e3, "edge_updates_per_s_eager": L * sweeps / el,
-                "setup_s": setup_s, "kernel": "k_phi<8,false>"})
+                "setup_s": setup_s, "kernel": "k_phi<8,false,true> (row-per-wavefront, product form on exp(Elogpi) rows)"})
     rec["frac_algorithmic"] = rec.pop("frac")
     tr = _traffic(HBM_BOUND_WORKLOAD)
     if tr:
@@ -385,7 +385,7 @@ def main():
                                             "scope": "this rank's node block" if multi else "all links"}},
         }
         tr = _traffic(args.workload) if not multi else None
-        roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 32 else "k_phi (phi pass, A6)"}
+        roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 64 else "k_phi (phi pass, A6)"}
         roof.update(same_window)
         roof["timing"] = ("hipEvents around the phi launch on the engine's own stream" +
                           ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if not multi else ""))
