@@ -592,7 +592,14 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   d.nslots = (uint32_t)next_slot;
   auto cap = [](uint64_t x, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(x, lim)); };
   // grids of the row-per-wavefront kernels: whole multiples of the resident block count
-  d.nb_a = cap((d.nitems_phi + 3) / 4, 4 * rpw_resident_blocks(g, 0, h->cfg.device));
+  {
+    // every phi block leaves a partial row of `sum` for k_colreduce / k_tail: one resident round of blocks on
+    // graphs of a few rounds of work (ca-AstroPh K=200: sweep 254 -> 241 us, K=100: 198 -> 185), four rounds
+    // (better balance of the last round: phi 3085 -> 2951 us at n=2e5, K=512) on large ones
+    const uint32_t res = rpw_resident_blocks(g, 0, h->cfg.device);
+    const uint64_t want = ((uint64_t)d.nitems_phi + 3) / 4;
+    d.nb_a = cap(want, (want < 16ull * res ? 1u : 4u) * res);
+  }
   d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), rpw_resident_blocks(g, 2, h->cfg.device));
   d.nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
   // lane-per-link layout for small K: wave-items of 64 consecutive entries of a class list
