@@ -167,7 +167,11 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   // Three launches per sweep when this library drives whole full sweeps at K <= 32: the work of k_tail is
   // split between the last s3 block (lambda, loop control) and a role of the NEXT phi launch (likelihood,
   // stop rule), and the phi pass accumulates beside gamma so that it may run before the stop rule has spoken.
-  d.fused3 = (d.fold && !prm.stoch && d.gacc0) ? 1 : 0;
+  // ... on graphs of up to 512 classification tiles (half a million CSR entries): there the whole next-sweep
+  // classification fits the <= 64 co-resident role blocks of the s3 launch with at most two tiles per worker.
+  // Larger graphs keep four launches, where the two classification passes ride spin-free on the s3 and tail
+  // launches with as many blocks as they need (n=1e6, K=20: s3 launch 1740 -> see profiles/r02h).
+  d.fused3 = (d.fold && !prm.stoch && d.gacc0 && d.cls_ntiles <= 512u) ? 1 : 0;
   if (d.fused3) {
     d.gacc = d.gacc0;
     d.nvb = lpl_validation_blocks(g, d.nv, g.K);

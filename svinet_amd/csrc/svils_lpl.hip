@@ -928,6 +928,10 @@ uint32_t lpl_cls_blocks(const DeviceState &d) {
   // one tile per worker when the s3 blocks leave enough CUs for that many blocks, else two (three-launch
   // sweeps keep up to two tiles per worker in registers), never more than 64 blocks
   uint32_t nb = (d.cls_ntiles + wpb - 1u) / wpb;
+  if (!d.fused3) {   // spin-free count pass (the scatter pass rides on the tail launch): no co-residency to respect
+    if (nb > 512u) nb = 512u;
+    return nb ? nb : 1u;
+  }
   if (nb + d.nb_c > 240u) nb = (d.cls_ntiles + 2u * wpb - 1u) / (2u * wpb);
   if (nb > 64u) nb = 64u;
   return nb ? nb : 1u;

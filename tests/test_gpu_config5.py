@@ -74,3 +74,38 @@ def test_hbm_bound_sweep_against_oracle():
     c = eng.control()
     assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
     np.testing.assert_allclose(eng.rows()[0, 1:], ref.rows[1, 1:], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("k", [20, 28])
+def test_large_small_k_graph_against_oracle(k):
+    """K <= 32 on a graph of more than 512 classification tiles (n = 60 000, ~1.4 M CSR entries): full sweeps
+    keep four launches there, with the next sweep's classification riding spin-free on the s3 and tail
+    launches in as many blocks as it needs.  Twelve sweeps (shortcut links appear, the link classes change from
+    sweep to sweep) against the oracle: state, flags, per-sweep link counts and likelihood rows."""
+    from oracle import oracle as O
+    from svinet_amd import mmsbgen_sparse as G
+    from svinet_amd.host_api import Setup
+    n = 60_000
+    pairs = G.generate(n, k, 24)
+    s = Setup(n=n, k=k, pairs=pairs)
+    assert 2 * int(s.nlinks) > 512 * 1024
+    ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, use_validation_stop=False)
+    eng = s.engine(use_validation_stop=False)
+    counts = []
+    for _ in range(12):
+        ref.sweep()
+        counts.append(ref.link_counts())
+    eng.sweep(12)
+    g, lam, conv = eng.state()
+    assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    assert np.array_equal(conv, ref.converged)
+    st = eng.sweep_stats(0, 12)
+    assert [tuple(int(x) for x in r[:3]) for r in st] == counts
+    np.testing.assert_allclose(eng.rows()[:, 1:], np.asarray(ref.rows)[1:13, 1:], rtol=1e-9, atol=1e-13)
+    # the same through eager phase-by-phase launches of a second engine (bitwise: one code path per kernel)
+    e2 = s.engine(use_validation_stop=False)
+    for _ in range(12):
+        e2.sweep(1)
+    g2, l2, c2 = e2.state()
+    assert np.array_equal(g, g2) and np.array_equal(lam, l2) and np.array_equal(conv, c2)
