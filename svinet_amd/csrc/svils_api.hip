@@ -334,7 +334,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.gamma, nk));
   d.gacc = d.gamma;   // full sweeps accumulate gammanext in place
   guard(dalloc(h, &d.elogpi, nk));
-  // exp(Elogpi) for the product form of k_phi (K > 64) while an n-by-k array stays below 1.5 GB: there the phi
+  // exp(Elogpi) for the product form of k_phi (K > 56) while an n-by-k array stays below 1.5 GB: there the phi
   // pass is bound by fp64 issue and trades its exps for multiplies (ca-AstroPh K=200: 174 -> 120 us, n=2e5 K=512:
   // 3.45 -> 3.02 ms); beyond that it runs at the HBM gather ceiling either way and the extra n-by-k write of the
   // finalise pass would cost more than the exps (n=1e6 K=512: phi -0.6 ms, finalise +0.75 ms)
@@ -625,7 +625,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   std::vector<uint32_t> erow;
   if (d.lpl) {
     if (2 * nlinks >= (1ull << 27))
-      return fail(SVILS_ERR_UNSUPPORTED, "k <= 64 supports up to 2^26 training links (got %llu)", (unsigned long long)nlinks);
+      return fail(SVILS_ERR_UNSUPPORTED, "k <= 56 supports up to 2^26 training links (got %llu)", (unsigned long long)nlinks);
     // classification tiles: 1024 entries, more on large graphs so that there are at most ~2048 tiles
     // (the scatter pass adds up the counts of all tiles below its own); erow / col padded to whole tiles
     d.cls_tile = 1024u * (uint32_t)std::max<uint64_t>(1, (2 * nlinks + 1024ull * 2048 - 1) / (1024ull * 2048));

@@ -54,10 +54,10 @@ __device__ __forceinline__ void block_reduce_store(double (&part)[NV][V], double
   }
 }
 
-// exp(Elogpi) next to Elogpi for the row-per-wavefront phi kernel (K > 64): exp(a + b + c) = e^a e^b e^c
+// exp(Elogpi) next to Elogpi for the row-per-wavefront phi kernel (K > 56): exp(a + b + c) = e^a e^b e^c
 // turns the K exps of every (link, direction) into K multiplies of per-node values; all three exponents
 // are <= 0, so the factors lie in (0, 1] and the product underflows exactly when the exp of the sum would.
-// Padding columns hold 0.  (Null for K <= 64: the lane-per-link kernels do not use it.)
+// Padding columns hold 0.  (Null for K <= 56: the lane-per-link kernels do not use it.)
 template <int W, int V>
 __device__ __forceinline__ void store_epi(const DeviceState &d, uint32_t p, int lw, uint32_t ld, uint32_t K,
                                           const double (&el)[V]) {

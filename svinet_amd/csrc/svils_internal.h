@@ -116,7 +116,7 @@ struct DeviceState {
   uint32_t *ncnt;       // [n_alloc] mini-batch mode: number of updates each node has received
   double *s12run;       // [2K]     mini-batch mode: running s1, s2 over the stored mphi rows
   double *elogpi;       // [n_alloc][ld]
-  double *epi;          // [n_alloc][ld] exp(Elogpi), K > 64 only (k_phi<V, false>); null otherwise
+  double *epi;          // [n_alloc][ld] exp(Elogpi), K > 56 only (k_phi<V, false, true>); null otherwise
   double *mphi;         // [n_alloc][ld]
   uint32_t *conv;       // [2][n_alloc]
   uint32_t *active_cnt; // [n_alloc]

@@ -1,4 +1,4 @@
-// svils_lpl.hip -- lane-per-link kernels for small K (K <= 32) on gfx950.
+// svils_lpl.hip -- lane-per-link kernels for small K (K <= 56) on gfx950.
 //
 // With K = 20..28 a group-per-row layout leaves 37 % of a wavefront's lanes idle
 // and spends more time in cross-lane softmax reductions than in exp().  Here one
@@ -858,7 +858,10 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
 }
 
 // ------------------------------------------------------------------ launchers
-bool use_lpl(uint32_t K) { return K <= 64; }
+// K = 57..64 would need a phi row of 64 doubles per lane (256 VGPRs and ~1 KB of scratch per lane): measured slower than
+// the row-per-wavefront kernels on every size (ca-AstroPh K=64: 0.161 vs 0.156 ms per sweep, n=1e6: 9.2 vs 6.5 ms), so the
+// lane-per-link layout ends at K = 56 (there it still wins: 0.124 vs 0.156 ms, 6.0 vs 6.6 ms)
+bool use_lpl(uint32_t K) { return K <= 56; }
 // waves per block of k_phi_lpl, two blocks per CU either way (a grid of two blocks per CU leaves at
 // most SVILS_FOLD_ROWS partial rows of `sum` for the consumers to fold).  K <= 32: the pipelined
 // kernel, LPL_PIPE_WAVES / 2 waves per SIMD with up to 256 VGPRs each.  K = 33..64: a phi row of up
@@ -884,8 +887,7 @@ int lpl_phi_waves(uint32_t K) { return LPL_PIPE && K <= 32 ? LPL_PIPE_WAVES : K 
     else if ((K_) <= 36) { CALL(18); }         \
     else if ((K_) <= 40) { CALL(20); }         \
     else if ((K_) <= 48) { CALL(24); }         \
-    else if ((K_) <= 56) { CALL(28); }         \
-    else { CALL(32); }                         \
+    else { CALL(28); }                         \
   } while (0)
 
 // blocks of k_phi_lpl that fit on the device at once (registers and LDS of the instantiation
