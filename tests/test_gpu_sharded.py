@@ -18,14 +18,15 @@ def _exchange_sum(ts):
         t.copy_(tot)
 
 
-@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 70), (3, 28, 12), (2, 100, 5)])
-def test_virtual_ranks_equal_oracle(graph_files, world, k, sweeps):
+@pytest.mark.parametrize("graph,world,k,sweeps", [("lfr", 2, 28, 70), ("lfr", 3, 28, 12), ("lfr", 2, 100, 5),
+                                                   ("astroph", 4, 200, 3)])   # BASELINE config 4's shape, sharded
+def test_virtual_ranks_equal_oracle(graph_files, graph, world, k, sweeps):
     import torch
     from svinet_amd import _svils
     from svinet_amd.host_api import Setup
     from svinet_amd.sharded import HipShard
 
-    path, n = graph_files["lfr"], 1000
+    path, n = graph_files[graph], {"lfr": 1000, "astroph": 17903}[graph]
     setup = Setup(path, n, k)
     shards = [HipShard(setup, r, world, 0, use_validation_stop=False) for r in range(world)]
     B = shards[0].B
