@@ -47,21 +47,41 @@ __device__ __forceinline__ double swz16_f64(double x) {   // lane i <-> i ^ 16
   hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
   return __hiloint2double(hi, lo);
 }
-#define SVILS_GROUP_REDUCE(NAME, OP)                                            \
+// row_bcast15 / row_bcast31 under a row mask: the masked-out rows receive `ident`
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_rows_f64(double x, double ident) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(x), CTRL, ROWMASK, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(x), CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// W == 64: after the four steps inside the 16-lane rows every lane holds its row's partial; rows 1 and 3 then
+// take lane 15 of the row below (row_bcast15), rows 2 and 3 take lane 31 (row_bcast31), and lane 63's total comes
+// back to everybody through two v_readlane -- no LDS round trip (ds_swizzle / ds_bpermute cost ~100 cycles each on
+// the dependent chain of every neighbour row), and the result is wave-uniform.
+#define SVILS_GROUP_REDUCE(NAME, OP, IDENT)                                     \
   template <int W>                                                              \
   __device__ __forceinline__ double NAME(double x) {                            \
     if (W >= 2) { const double t = dpp_f64<0xB1>(x); x = OP(x, t); }            \
     if (W >= 4) { const double t = dpp_f64<0x4E>(x); x = OP(x, t); }            \
     if (W >= 8) { const double t = dpp_f64<0x141>(x); x = OP(x, t); }           \
     if (W >= 16) { const double t = dpp_f64<0x140>(x); x = OP(x, t); }          \
+    if constexpr (W == 64 && SVILS_ROW_BCAST) {                                 \
+      { const double t = dpp_rows_f64<0x142, 0xa>(x, IDENT); x = OP(x, t); }    \
+      { const double t = dpp_rows_f64<0x143, 0xc>(x, IDENT); x = OP(x, t); }    \
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), \
+                              __builtin_amdgcn_readlane(__double2loint(x), 63)); \
+    }                                                                           \
     if (W >= 32) { const double t = swz16_f64(x); x = OP(x, t); }               \
     if (W >= 64) { const double t = __shfl_xor(x, 32, 64); x = OP(x, t); }      \
     return x;                                                                   \
   }
+#ifndef SVILS_ROW_BCAST
+#define SVILS_ROW_BCAST 1
+#endif
 __device__ __forceinline__ double svils_add(double a, double b) { return a + b; }
 __device__ __forceinline__ double svils_max(double a, double b) { return fmax(a, b); }
-SVILS_GROUP_REDUCE(group_sum, svils_add)
-SVILS_GROUP_REDUCE(group_max, svils_max)
+SVILS_GROUP_REDUCE(group_sum, svils_add, 0.0)
+SVILS_GROUP_REDUCE(group_max, svils_max, NEG_INF)
 // sum across the 64/W groups of a wavefront (lane lw of every group ends with the total)
 template <int W>
 __device__ __forceinline__ double cross_group_sum(double x) {
