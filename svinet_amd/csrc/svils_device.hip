@@ -75,13 +75,18 @@ __device__ __forceinline__ void store_epi(const DeviceState &d, uint32_t p, int 
 // fetched with one coalesced load each, and the next neighbour's Elogpi row is in
 // flight while the current one is reduced (two rows per wave in flight).
 template <int V, bool LOWT, bool EPI>
-__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
   constexpr int W = 64;
   constexpr bool PROD = EPI && !LOWT;   // product form on exp(Elogpi) rows, else exps of sums of Elogpi rows
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double lds[V * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave-uniform by construction; said so explicitly, or the compiler keeps the item loop and the neighbour loop
+  // under exec masks with vector compares (it cannot see that threadIdx.x >> 6 is the same in all 64 lanes)
+  // (measured: V = 4: phi -10 % and 96 instead of 111 VGPRs; V = 8: neutral; V <= 2: +7 %, left alone)
+  constexpr bool UNI = V >= 4;
+  auto uni = [](int x) { return UNI ? __builtin_amdgcn_readfirstlane(x) : x; };
+  const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
   const int lw = lane;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool write_comm = ctrl->write_comm != 0;
@@ -105,7 +110,12 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
   unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
 
   for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_phi; it += gridDim.x * 4) {
-    const Item item = d.items_phi[d.item0_phi + it];
+    const Item item_ = d.items_phi[d.item0_phi + it];
+    Item item;   // scalar registers
+    item.node = (uint32_t)uni((int)item_.node);
+    item.off = (uint32_t)uni((int)item_.off);
+    item.len = (uint32_t)uni((int)item_.len);
+    item.slot = uni(item_.slot);
     const uint32_t p = item.node;
     const uint64_t base = d.rowptr[p] + item.off;
     const uint32_t len = item.len;   // <= 64 (chunk limit 32)
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 4 : V == 8 ? 3 : 1)) vo
       mycol = d.col[base + lane];
       myconv = conv[mycol];
     }
-    const uint32_t pc = conv[p];
+    const uint32_t pc = (uint32_t)uni((int)conv[p]);
     // Elogpi[p][k] + Elogbeta[k][0], once per item; x_k = this + Elogpi[q][k] (the reference adds the
     // two Elogpi terms first, :686 -- a different rounding of the same sum, one add per column saved)
     double ap[V];
@@ -623,7 +633,10 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
   __shared__ double lds[V * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave-uniform values said to be so (see k_phi): scalar loop control instead of exec masks
+  constexpr bool UNI = (W == 64);
+  auto uni = [](int x) { return UNI ? __builtin_amdgcn_readfirstlane(x) : x; };
+  const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
@@ -636,10 +649,15 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
   for (int v = 0; v < V; ++v) s3[0][v] = 0.0;
 
   for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_s3; it += gridDim.x * 4) {
-    const Item item = d.items_s3[d.item0_s3 + it];
+    const Item item_ = d.items_s3[d.item0_s3 + it];
+    Item item;
+    item.node = (uint32_t)uni((int)item_.node);
+    item.off = (uint32_t)uni((int)item_.off);
+    item.len = (uint32_t)uni((int)item_.len);
+    item.slot = item_.slot;
     const uint32_t p = item.node;
     const uint64_t base = d.rowptr[p] + item.off;
-    const uint32_t pc = conv[p];
+    const uint32_t pc = (uint32_t)uni((int)conv[p]);
     double mp[V];
     load_row<W, V>(mphi + (size_t)p * ld, lw, ld, mp);
     for (uint32_t j = g; j < item.len; j += G) {
