@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, P
   __shared__ double2 logtab[128];
   load_logtab(logtab, d.logtab);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // W == 64: one node per wavefront, its index is wave-uniform (said so: scalar loop control, see k_phi)
+  const int lane = threadIdx.x & 63, wave = (W == 64) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool annealing = ctrl->annealing != 0;
