@@ -275,6 +275,9 @@ def main():
                     help="take the N>1 code path (process group, RCCL communicator, sharded driver, side records) with "
                          "whatever world size there is -- a one-GPU box can exercise it with a world of one")
     ap.add_argument("--no-extra", action="store_true", help="N>1: skip the side records (config 4, HBM-bound size)")
+    ap.add_argument("--main-timeout", type=int, default=420,
+                    help="N>1: seconds the communicator set-up + warm-up + timed sweeps may take before rank 0 prints "
+                         "an error line and every rank exits")
     ap.add_argument("--extra-timeout", type=int, default=240,
                     help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
     args = ap.parse_args()
@@ -300,6 +303,28 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600),
                                 device_id=torch.device("cuda", local_rank))
 
+    # N > 1: RCCL has never carried more than one rank of this code on the hardware available to its builders.
+    # If the communicator set-up or the timed sharded sweeps ever block, rank 0 still owes the driver a JSON
+    # line: it says so (value null, the reason in "error") and every rank leaves instead of hanging the node.
+    main_done = None
+    if multi:
+        import threading
+        main_done = threading.Event()
+
+        def main_watchdog():
+            if not main_done.wait(timeout=args.main_timeout):
+                if rank == 0:
+                    print(json.dumps({"metric": "edge-updates/sec (link-sampling SVI step)", "value": None, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps,
+                                      "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                                      "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                                      "error": "the sharded run did not finish within %d s (communicator set-up or a "
+                                               "collective blocked); nothing was measured" % args.main_timeout}), flush=True)
+                sys.stderr.write("bench.py: rank %d left on the main watchdog\n" % rank)
+                sys.stderr.flush()
+                os._exit(3)
+
+        threading.Thread(target=main_watchdog, daemon=True).start()
+
     # ---- inputs: product host side (C++), resident in HBM before timing ----
     setup, path, pairs, n, k, data = _load_workload(args.workload)
     L = int(setup.nlinks)
@@ -322,6 +347,8 @@ def main():
         eng.enable_timing(1 << _svils.KERNEL_PHI, period)
     elapsed = _timed(runner, eng, args.steps, dist, torch)
     ctrl = eng.control()
+    if main_done is not None:
+        main_done.set()
     assert ctrl.sweeps_done >= args.warmup + args.steps, "sweeps were skipped"
 
     same_window = None
