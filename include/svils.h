@@ -74,6 +74,10 @@ typedef struct {
    * src/linksampling.cc:634 (svils_config_default).  The revision that produced the runs shipped
    * under example/ behaved like 0, which is how the tests reproduce them. */
   int32_t sparse_after_iter;
+  /* K-sharded handles (multi-GPU layout of DESIGN.md section 8): k_total != 0 means this handle holds the
+   * columns [k_begin, k_begin + k) of k_total communities for ALL n nodes; alpha stays 1/k_total,
+   * gamma / lambda are passed and returned as that column slice.  0: the handle holds every column. */
+  uint32_t k_begin, k_total;
 } svils_config;
 
 /* fills the reference's defaults for a given n,k (alpha=1/k, eta=1,1, ...) */
@@ -274,6 +278,25 @@ int svils_comm_init(svils_handle *h, const void *id128, int rank, int world);
 int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps);
 /* all-gather of the community bitmasks before svils_get_communities on a sharded handle.  Collective. */
 int svils_gather_communities(svils_handle *h);
+
+/* ---- K-sharded sweeps: one process per GPU, every rank holds a column slice of all rows --------
+ * The columns of a row are coupled in four places; each is a buffer of partials
+ * that must be SUMmed over the ranks between two phases (tests/test_ksharded_protocol.py is the protocol):
+ *   svils_set_state (slices) -> phase KINIT_ROWS -> SUM KSH_ROWX -> phase KINIT_EXPAND        (once)
+ *   per sweep: phase KDEN -> SUM KSH_DEN -> phase KPHI -> SUM KSH_ROWX -> phase KFIN -> SUM KSH_Q2
+ *              -> phase KLAMBDA -> SUM KSH_VDOT -> phase KSTOP
+ * svils_sweep_ksharded does exactly that with RCCL all-reduces on the handle's stream (svils_comm_init
+ * first; the node block of a K-sharded handle is [0, n)). */
+typedef enum {
+  SVILS_KPHASE_DEN = 0, SVILS_KPHASE_PHI = 1, SVILS_KPHASE_FIN = 2, SVILS_KPHASE_LAMBDA = 3, SVILS_KPHASE_STOP = 4,
+  SVILS_KPHASE_INIT_ROWS = 5, SVILS_KPHASE_INIT_EXPAND = 6
+} svils_kphase;
+typedef enum { SVILS_KSH_DEN = 0, SVILS_KSH_ROWX = 1, SVILS_KSH_Q2 = 2, SVILS_KSH_VDOT = 3 } svils_ksh_buffer;
+int svils_ksweep_phase(svils_handle *h, svils_kphase phase);
+/* device pointer and length (doubles) of an exchange buffer */
+int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, size_t *ndoubles);
+int svils_ksh_init_state(svils_handle *h);           /* collective: the two INIT phases around their all-reduce */
+int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps);   /* collective, asynchronous */
 
 const char *svils_last_error(void);
 int svils_abi_version(void);

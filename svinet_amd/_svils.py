@@ -27,6 +27,7 @@ EXPORTS = (
     "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default", "svils_step_phase", "svils_step_window",
     "svils_get_sweep_stats", "svils_get_timed_links",
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
+    "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded",
 )
 
 
@@ -51,6 +52,7 @@ class Config(C.Structure):
         ("ones_prob", C.c_double), ("zeros_prob", C.c_double),
         ("device", C.c_int32), ("node_begin", C.c_uint32), ("node_end", C.c_uint32),
         ("n_alloc", C.c_uint32), ("sparse_after_iter", C.c_int32),
+        ("k_begin", C.c_uint32), ("k_total", C.c_uint32),
     ]
 
 
@@ -140,6 +142,8 @@ def comm_unique_id():
     _chk(load().svils_comm_unique_id(buf))
     return buf.raw
 PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND = range(5)
+KPHASE_DEN, KPHASE_PHI, KPHASE_FIN, KPHASE_LAMBDA, KPHASE_STOP, KPHASE_INIT_ROWS, KPHASE_INIT_EXPAND = range(7)
+KSH_DEN, KSH_ROWX, KSH_Q2, KSH_VDOT = range(4)
 
 
 class Engine:
@@ -147,7 +151,9 @@ class Engine:
 
     def __init__(self, n, k, ones, ones_prob, eta=(1.0, 1.0), link_thresh=0.5, lt_min_deg=0,
                  reportfreq=1, use_validation_stop=True, device=0, node_block=None, n_alloc=0,
-                 sparse_after_iter=1000):
+                 sparse_after_iter=1000, k_slice=None):
+        """k_slice = (k_begin, k_end): a K-sharded handle holding those columns of the `k` communities
+        (gamma / lambda go in and out as that slice; alpha stays 1/k)."""
         L = load()
         cfg = Config()
         _chk(L.svils_config_default(C.byref(cfg), n, k))
@@ -164,6 +170,11 @@ class Engine:
             cfg.node_begin, cfg.node_end = node_block
         cfg.n_alloc = n_alloc
         cfg.sparse_after_iter = sparse_after_iter
+        self.k_total = k
+        if k_slice is not None:
+            cfg.k_begin, cfg.k_total = int(k_slice[0]), int(k)
+            cfg.k = int(k_slice[1]) - int(k_slice[0])
+            k = cfg.k
         self.n, self.k = n, k
         self._h = C.c_void_p()
         _chk(L.svils_create(C.byref(cfg), C.byref(self._h)))
@@ -180,6 +191,21 @@ class Engine:
         assert links.ndim == 2 and links.shape[1] == 2
         self.nlinks = links.shape[0]
         _chk(load().svils_set_graph(self._h, links.ctypes.data, links.shape[0]))
+
+    def ksweep_phase(self, phase):
+        _chk(load().svils_ksweep_phase(self._h, int(phase)))
+
+    def ksh_buffer(self, which):
+        """-> (device pointer, number of doubles) of a K-sharded exchange buffer"""
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(load().svils_ksh_buffer_ptr(self._h, int(which), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def ksh_init_state(self):
+        _chk(load().svils_ksh_init_state(self._h))
+
+    def sweep_ksharded(self, nsweeps=1):
+        _chk(load().svils_sweep_ksharded(self._h, int(nsweeps)))
 
     def set_validation(self, pairs_y):
         pairs_y = np.ascontiguousarray(pairs_y, dtype=np.uint32).reshape(-1, 3)

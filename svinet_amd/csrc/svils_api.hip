@@ -148,6 +148,13 @@ struct Timed {
   }
 };
 
+int fault_error(uint32_t code) {
+  if (code == 2u)
+    return fail(SVILS_ERR_DEVICE, "K-sharded sweep: the softmax denominator of a link underflowed (rows of disjoint support); "
+                                  "this layout has no log-domain detour across ranks -- use node-block sharding for this model");
+  return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+}
+
 // (re)classify the links of the sweep about to run from the flags as they stand
 int classify_now(svils_handle *h, const Geometry &g, const DeviceState &d, const Params &prm) {
   Timed t(h, SVILS_KERNEL_CLASSIFY);
@@ -313,7 +320,19 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   g.k10 = cfg->k / 10;           // integer division, src/linksampling.cc:465,634
   g.node_begin = nb;
   g.node_end = ne;
+  g.K0 = 0;
+  g.Kt = cfg->k;
+  if (cfg->k_total) {   // K-sharded handle: a column slice of every row
+    if ((uint64_t)cfg->k_begin + cfg->k > cfg->k_total || cfg->k_total > SVILS_MAX_K || nb != 0 || ne != cfg->n) {
+      delete h;
+      return fail(SVILS_ERR_ARG, "K-sharded handle: need k_begin + k <= k_total <= %d and the node block [0, n)", SVILS_MAX_K);
+    }
+    g.K0 = cfg->k_begin;
+    g.Kt = cfg->k_total;
+    g.k10 = cfg->k_total / 10;
+  }
   if (!pick_layout(cfg->k, &g.W, &g.V)) { delete h; return fail(SVILS_ERR_UNSUPPORTED, "unsupported k"); }
+  if (cfg->k_total) g.W = 64;    // the K-sharded kernels are row-per-wavefront whatever the slice width
   g.kw = (uint32_t)g.V;
   Params &p = h->prm;
   p.ones = cfg->ones; p.alpha = cfg->alpha; p.eta0 = cfg->eta0; p.eta1 = cfg->eta1;
@@ -338,7 +357,12 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   // pass is bound by fp64 issue and trades its exps for multiplies (ca-AstroPh K=200: 174 -> 120 us, n=2e5 K=512:
   // 3.45 -> 3.02 ms); beyond that it runs at the HBM gather ceiling either way and the extra n-by-k write of the
   // finalise pass would cost more than the exps (n=1e6 K=512: phi -0.6 ms, finalise +0.75 ms)
-  if (!use_lpl(g.K) && nk * sizeof(double) <= 1536ull << 20) guard(dalloc(h, &d.epi, nk));
+  d.ksh = cfg->k_total ? 1 : 0;
+  if (d.ksh || (!use_lpl(g.K) && nk * sizeof(double) <= 1536ull << 20)) guard(dalloc(h, &d.epi, nk));
+  if (d.ksh) {
+    guard(dalloc(h, &d.rowx, 3 * (size_t)g.n));
+    guard(dalloc(h, &d.q2v, g.Kt));
+  }
   guard(dalloc(h, &d.mphi, nk));
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
   guard(dalloc(h, &d.active_cnt, g.n_alloc));
@@ -451,8 +475,8 @@ int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
   if (h->comm) return fail(SVILS_ERR_ARG, "svils_comm_init: communicator already initialised");
   const Geometry &g = h->geo;
   const uint32_t B = (g.n + (uint32_t)world - 1) / (uint32_t)world;
-  if (g.n_alloc != B * (uint32_t)world || g.node_begin != std::min(g.n, (uint32_t)rank * B) ||
-      g.node_end != std::min(g.n, ((uint32_t)rank + 1) * B))
+  if (!h->d.ksh && (g.n_alloc != B * (uint32_t)world || g.node_begin != std::min(g.n, (uint32_t)rank * B) ||
+      g.node_end != std::min(g.n, ((uint32_t)rank + 1) * B)))
     return fail(SVILS_ERR_ARG, "svils_comm_init: rank %d of %d needs node block [%u,%u) and n_alloc %u (handle has [%u,%u), %u)",
                 rank, world, std::min(g.n, (uint32_t)rank * B), std::min(g.n, ((uint32_t)rank + 1) * B), B * world,
                 g.node_begin, g.node_end, g.n_alloc);
@@ -498,6 +522,7 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
   if (!h->comm && !(h->geo.node_begin == 0 && h->geo.node_end == h->geo.n))
     return fail(SVILS_ERR_ARG, "svils_sweep_sharded: a node-block handle needs svils_comm_init");
   if (h->stoch) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: the handle is in mini-batch mode");
+  if (h->d.ksh) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: a K-sharded handle is driven by svils_sweep_ksharded");
   if (nsweeps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
     return fail(SVILS_ERR_ARG, "svils_sweep_sharded: at most %llu sweeps per call",
                 (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
@@ -513,6 +538,74 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
     if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
     if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_D, false))) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- K-sharded sweeps (svils_ksh.h)
+int svils_ksweep_phase(svils_handle *h, svils_kphase phase) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: null handle");
+  if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: not a K-sharded handle (svils_config.k_total)");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: set graph and state first");
+  if ((int)phase < 0 || (int)phase > 6) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: unknown phase %d", (int)phase);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  launch_ksh_phase(h->geo, h->d, h->prm, (int)phase, h->stream);
+  HIPCHK(hipGetLastError());
+  if (phase == SVILS_KPHASE_STOP) ++h->sweeps_issued;
+  return 0;
+}
+
+int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, size_t *ndoubles) {
+  if (!h || !dptr || !ndoubles) return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: null argument");
+  if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: not a K-sharded handle");
+  const DeviceState &d = h->d;
+  switch (which) {
+    case SVILS_KSH_DEN: *dptr = d.den; *ndoubles = (size_t)d.nlinks; return 0;
+    case SVILS_KSH_ROWX: *dptr = d.rowx; *ndoubles = 3 * (size_t)h->geo.n; return 0;
+    case SVILS_KSH_Q2: *dptr = d.q2v; *ndoubles = h->geo.Kt; return 0;
+    case SVILS_KSH_VDOT: *dptr = d.vdot; *ndoubles = d.nv; return 0;
+  }
+  return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: unknown buffer %d", (int)which);
+}
+
+namespace {
+int ksh_sum(svils_handle *h, svils_ksh_buffer which) {
+  if (!h->comm) return 0;
+  void *p = nullptr;
+  size_t n = 0;
+  int rc = svils_ksh_buffer_ptr(h, which, &p, &n);
+  if (rc || n == 0) return rc;
+  Timed t(h, SVILS_KERNEL_EXCHANGE);
+  NCCLCHK(g_rccl.AllReduce(p, p, n, ncclDouble, ncclSum, h->comm, h->stream));
+  return 0;
+}
+}  // namespace
+
+int svils_ksh_init_state(svils_handle *h) {
+  int rc;
+  if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_INIT_ROWS))) return rc;
+  if ((rc = ksh_sum(h, SVILS_KSH_ROWX))) return rc;
+  return svils_ksweep_phase(h, SVILS_KPHASE_INIT_EXPAND);
+}
+
+int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: null handle");
+  if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: not a K-sharded handle");
+  if (!h->comm && h->geo.K != h->geo.Kt) return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: call svils_comm_init first");
+  if (nsweeps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
+    return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: at most %llu sweeps per call",
+                (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
+  for (uint32_t i = 0; i < nsweeps; ++i) {
+    int rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DEN))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_DEN))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_PHI))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_ROWX))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_FIN))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_Q2))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_LAMBDA))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_VDOT))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_STOP))) return rc;
   }
   return 0;
 }
@@ -562,12 +655,20 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   for (uint32_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
   std::vector<uint32_t> col(std::max<uint64_t>(2 * nlinks, 1));
   std::vector<uint32_t> upper(n, 0);
+  std::vector<uint32_t> elink;   // K-sharded handles: training-link index of every CSR entry
   {
     std::vector<uint64_t> fill(rowptr.begin(), rowptr.end() - 1);
     // lower parts: links arrive sorted by p, so appending p to row q keeps ascending order
-    for (uint64_t l = 0; l < nlinks; ++l) col[fill[links[2 * l + 1]]++] = links[2 * l];
+    if (h->d.ksh) elink.assign(std::max<uint64_t>(2 * nlinks, 1), 0);
+    for (uint64_t l = 0; l < nlinks; ++l) {
+      if (h->d.ksh) elink[fill[links[2 * l + 1]]] = (uint32_t)l;
+      col[fill[links[2 * l + 1]]++] = links[2 * l];
+    }
     for (uint32_t i = 0; i < n; ++i) upper[i] = (uint32_t)(fill[i] - rowptr[i]);
-    for (uint64_t l = 0; l < nlinks; ++l) col[fill[links[2 * l]]++] = links[2 * l + 1];
+    for (uint64_t l = 0; l < nlinks; ++l) {
+      if (h->d.ksh) elink[fill[links[2 * l]]] = (uint32_t)l;
+      col[fill[links[2 * l]]++] = links[2 * l + 1];
+    }
   }
   // work items over the owned node block
   const int G = 64 / g.W;
@@ -607,7 +708,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), rpw_resident_blocks(g, 2, h->cfg.device));
   d.nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
   // lane-per-link layout for small K: wave-items of 64 consecutive entries of a class list
-  d.lpl = use_lpl(g.K) ? 1 : 0;
+  d.lpl = (use_lpl(g.K) && !d.ksh) ? 1 : 0;
   d.nlinks = nlinks;
   d.ent_begin = rowptr[g.node_begin];
   d.ent_end = rowptr[g.node_end];
@@ -696,7 +797,14 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   guard(dalloc(h, &d.part_links, (size_t)d.nb_a * 3));
   guard(dalloc(h, &d.part_b, (size_t)d.nb_b * 2 * g.K));
   guard(dalloc(h, &d.part_c, (size_t)d.nb_c * g.K));
+  if (d.ksh) {
+    if (nlinks >= (1ull << 32)) return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handles index links with 32 bits");
+    guard(dalloc(h, &d.elink, elink.size(), false));
+    guard(dalloc(h, &d.den, std::max<uint64_t>(nlinks, 1)));
+    guard(dalloc(h, &d.part_q2, d.nb_c));
+  }
   if (rc) return rc;
+  if (d.ksh) HIPCHK(hipMemcpyAsync(d.elink, elink.data(), elink.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.rowptr, rowptr.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.col, col.data(), col.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d.upper, upper.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
@@ -734,6 +842,7 @@ int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) 
   DeviceState &d = h->d;
   int rc = dalloc(h, &d.vpairs, 3 * (size_t)nv, false);
   if (!rc) rc = dalloc(h, &d.uval, nv);
+  if (!rc && d.ksh) rc = dalloc(h, &d.vdot, std::max<uint64_t>(nv, 1));
   if (rc) return rc;
   if (nv) HIPCHK(hipMemcpyAsync(d.vpairs, pairs_y, 3 * nv * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -758,7 +867,7 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
   uint32_t *cur = d.conv + (size_t)c.parity * g.n_alloc;
   if (converged) HIPCHK(hipMemcpyAsync(cur, converged, g.n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   else HIPCHK(hipMemsetAsync(cur, 0, g.n * sizeof(uint32_t), h->stream));
-  launch_dir_exp(g, d, h->stream);
+  if (!d.ksh) launch_dir_exp(g, d, h->stream);   // K-sharded: the row sums cross ranks (svils_ksh_init_state)
   launch_lambda_exp(g, d, h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -773,7 +882,7 @@ int svils_get_control(svils_handle *h, svils_control *out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
-  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+  if (c.fault) return fault_error(c.fault);
   out->iter = c.iter; out->annealing = c.annealing; out->write_comm = c.write_comm; out->nh = c.nh;
   out->prev_h = c.prev_h; out->max_h = c.max_h; out->stopped = c.stopped; out->why = c.why;
   out->sweeps_done = c.sweeps_done; out->rows = c.rows;
@@ -787,7 +896,7 @@ int svils_set_control(svils_handle *h, const svils_control *in) {
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
-  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+  if (c.fault) return fault_error(c.fault);
   c.iter = in->iter; c.annealing = in->annealing; c.write_comm = in->write_comm; c.nh = in->nh;
   c.prev_h = in->prev_h; c.max_h = in->max_h;
   HIPCHK(hipMemcpy(h->d.ctrl, &c, sizeof c, hipMemcpyHostToDevice));
@@ -811,6 +920,7 @@ int svils_validation_row(svils_handle *h, double *row10) {
 int svils_sweep_phase(svils_handle *h, svils_phase phase) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_phase: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep_phase: set graph and state first");
+  if (h->d.ksh) return fail(SVILS_ERR_ARG, "svils_sweep_phase: a K-sharded handle is driven by svils_ksweep_phase");
   HIPCHK(hipSetDevice(h->cfg.device));
   return run_phase(h, phase, false);
 }
@@ -908,6 +1018,7 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
   if (h->stoch) return fail(SVILS_ERR_ARG, "svils_sweep: the handle is in mini-batch mode, use svils_step");
+  if (h->d.ksh) return fail(SVILS_ERR_ARG, "svils_sweep: a K-sharded handle is driven by svils_ksweep_phase / svils_sweep_ksharded");
   HIPCHK(hipSetDevice(h->cfg.device));
   // likelihood rows go to a ring of rows_cap entries: never enqueue more reports than it holds
   // between two host polls (svils_get_rows)
@@ -1141,7 +1252,7 @@ int svils_synchronize(svils_handle *h) {
   HIPCHK(hipStreamSynchronize(h->stream));
   uint32_t fault = 0;
   HIPCHK(hipMemcpy(&fault, &h->d.ctrl->fault, sizeof fault, hipMemcpyDeviceToHost));
-  if (fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+  if (fault) return fault_error(fault);
   return 0;
 }
 
@@ -1151,7 +1262,7 @@ int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
-  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+  if (c.fault) return fault_error(c.fault);
   if ((uint64_t)first + count > c.rows) return fail(SVILS_ERR_ARG, "rows [%u,%u) not recorded yet (have %u)", first, first + count, c.rows);
   if (c.rows - first > h->d.rows_cap) return fail(SVILS_ERR_ARG, "row %u already overwritten in the ring", first);
   // the ring wraps at rows_cap: at most two contiguous copies
@@ -1176,7 +1287,7 @@ int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *co
   if (converged) {
     DevCtrl c;
     HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
-  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+  if (c.fault) return fault_error(c.fault);
     HIPCHK(hipMemcpy(converged, h->d.conv + (size_t)c.parity * g.n_alloc, g.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   return 0;
@@ -1280,7 +1391,7 @@ int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint6
   HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
-  if (c.fault) return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
+  if (c.fault) return fault_error(c.fault);
   if ((uint64_t)first + count > c.sweeps_done)
     return fail(SVILS_ERR_ARG, "sweeps [%u,%u) not run yet (have %u)", first, first + count, c.sweeps_done);
   if (c.sweeps_done - first > h->d.sweep_stats_cap) return fail(SVILS_ERR_ARG, "sweep %u is no longer in the ring", first);

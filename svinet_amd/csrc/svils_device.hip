@@ -1325,3 +1325,5 @@ void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, d
 }
 
 }  // namespace svils
+
+#include "svils_ksh.h"

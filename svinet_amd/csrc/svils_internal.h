@@ -45,6 +45,7 @@ struct DevCtrl {
 
 struct Geometry {
   uint32_t n, n_alloc, K, ld, kw, k10;
+  uint32_t K0, Kt;   // K-sharded handles: this rank holds columns [K0, K0 + K) of Kt; otherwise 0, K
   uint32_t node_begin, node_end;
   int W, V;  // lanes per row group, doubles per lane (K <= W*V)
 };
@@ -117,6 +118,14 @@ struct DeviceState {
   double *s12run;       // [2K]     mini-batch mode: running s1, s2 over the stored mphi rows
   double *elogpi;       // [n_alloc][ld]
   double *epi;          // [n_alloc][ld] exp(Elogpi), K > 56 only (k_phi<V, false, true>); null otherwise
+  // K-sharded sweeps (svils_ksh.h): what crosses ranks, each buffer summed over the ranks between two phases
+  int ksh;              // 1: the handle holds a column slice
+  uint32_t *elink;      // [2L]  training-link index of every CSR entry
+  double *den;          // [L]   softmax denominators of the links (partial -> SUM -> total)
+  double *rowx;         // [n][3] row sum of the new gamma, active-community count, sum of (community + 1) over them
+  double *q2v;          // [Kt]  quirk Q2 contributions that belong to another rank's column
+  double *vdot;         // [nv]  partial sum_k gamma_p gamma_q beta_k of the held-out pairs
+  double *part_q2;      // [nb_c] per-block partial of this rank's outgoing Q2 contribution
   double *mphi;         // [n_alloc][ld]
   uint32_t *conv;       // [2][n_alloc]
   uint32_t *active_cnt; // [n_alloc]
@@ -194,6 +203,7 @@ void launch_debug_eval(const DeviceState &d, int which, const double *in, double
 void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
                      hipStream_t s);
 bool pick_layout(uint32_t K, int *W, int *V);
+void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, int phase, hipStream_t s);   // svils_ksh.h
 // k owned by (lane-in-group lw, register v) for layout (W,V); host copy of the device mapping
 inline uint32_t kmap_host(int W, int V, int lw, int v) {
   return V == 1 ? (uint32_t)lw : (uint32_t)(2 * ((v >> 1) * W + lw) + (v & 1));

@@ -1,0 +1,554 @@
+// svils_ksh.h -- K-sharded sweeps (included once, at the end of svils_device.hip, whose helpers it uses): every rank keeps the columns [K0, K0 + K) of all n rows.
+//
+// The sweep of src/linksampling.cc:556-790 couples the columns of a row in four places only: the softmax
+// denominator of a link, the row sum inside Elogpi = psi(gamma) - psi(sum_k gamma), the active-community
+// count of prune(), and the dot products of the held-out likelihood (plus quirk Q2, where mphi[q][pc] feeds
+// s3[pc - 1]).  Each becomes a buffer of partials that the caller (or svils_sweep_ksharded over RCCL) SUMs
+// over the ranks between two phases; everything else runs on the rank's own columns with the row-per-
+// wavefront layout and the product form of the phi pass (exp(Elogpi) rows).  tests/test_ksharded_protocol.py
+// is the same protocol in numpy against the oracle.
+//
+//   DEN   k_phi_ksh<V,1>   den[link] = sum over own columns of e^x_k             -> SUM den        (L doubles)
+//   PHI   k_phi_ksh<V,2>   gammanext rows from e^x_k / den, `sum`, tags; k_colreduce; k_fin1_ksh:
+//                          mean indicators, gamma, partial row sums / active counts -> SUM rowx    (3n doubles)
+//   FIN2  k_fin2_ksh       Elogpi, exp(Elogpi), flags; k_s3_ksh + k_colreduce (Q2 across the slice edge)
+//                                                                                 -> SUM q2v       (Kt doubles)
+//   LAM   k_lam_ksh        lambda, Elogbeta of own columns; k_vdot_ksh partial dot products -> SUM vdot (nv doubles)
+//   STOP  k_stop_ksh       likelihood row, stop rule, annealing switch, loop control (replicated)
+namespace svils {
+
+// ---------------------------------------------------------------- phi pass, K-sharded
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Params prm) {
+  constexpr int W = 64;
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double lds[V * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lw = lane;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool write_comm = ctrl->write_comm != 0;
+  const bool sparse_iter = (long long)ctrl->iter > (long long)prm.sparse_after;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const double *__restrict__ epi = d.epi;
+  int kidx[V];
+  bool kval[V];
+  double eb[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)kidx[v] < K;
+    eb[v] = kval[v] ? exp_neg(d.elogbeta[2 * kidx[v]]) : 0.0;
+  }
+  double csum[1][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) csum[0][v] = 0.0;
+  unsigned long long n_dense = 0, n_sparse = 0, n_short = 0;
+
+  for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_phi; it += gridDim.x * 4) {
+    const Item item_ = d.items_phi[d.item0_phi + it];
+    const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.node);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.off);
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.len);
+    const int32_t slot = __builtin_amdgcn_readfirstlane(item_.slot);
+    const uint64_t base = d.rowptr[p] + off;
+    uint32_t mycol = 0, myconv = 0, myel = 0;
+    if ((uint32_t)lane < len) {
+      mycol = d.col[base + lane];
+      myconv = conv[mycol];
+      myel = d.elink[base + lane];
+    }
+    const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)conv[p]);
+    double ap[V];
+    load_row<W, V>(epi + (size_t)p * ld, lw, ld, ap);
+#pragma unroll
+    for (int v = 0; v < V; ++v) ap[v] *= eb[v];
+    double acc[V];
+    uint32_t cnt[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { acc[v] = 0.0; cnt[v] = 0; }
+    uint32_t p_active = 0;
+    if (sparse_iter) p_active = d.active_cnt[p];
+
+    for (uint32_t j = 0; j < len; ++j) {
+      const uint32_t q = __builtin_amdgcn_readlane(mycol, j);
+      const uint32_t qc = __builtin_amdgcn_readlane(myconv, j);
+      const uint32_t el = __builtin_amdgcn_readlane(myel, j);
+      const bool count_me = q > p;
+      if ((pc != 0) != (qc != 0)) {
+        if constexpr (MODE == 2) {
+          // exactly one endpoint converged: +1 at the converged community, on the rank that holds it (:622-631)
+          const int c = (int)(pc ? pc : qc) - 1 - (int)geo.K0;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kidx[v] == c) acc[v] += 1.0;
+          if (count_me && lane == 0) n_short++;
+        }
+        continue;
+      }
+      if (MODE == 1 && !count_me) continue;   // one denominator per undirected link
+      bool sparse = false;
+      if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
+      double r[V];
+      load_row<W, V>(epi + (size_t)q * ld, lw, ld, r);
+      double e[V];
+      double s = 0.0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        double t = ap[v] * r[v];
+        if (sparse) {
+          const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
+          t = ((um >> lw) & 1ull) ? t : 0.0;
+        }
+        e[v] = t;
+        s += t;
+      }
+      if constexpr (MODE == 1) {
+        s = group_sum<W>(s);
+        if (lane == 0) d.den[el] = s;
+      } else {
+        s = d.den[el];   // the link's denominator over ALL columns
+        // a denominator that underflowed (possible only for rows of disjoint support at very large K): this layout has
+        // no log-domain detour across ranks yet -- say so instead of dropping the link
+        if (s < 1e-280 && !(sparse && s == 0.0)) ctrl->fault = 2u;
+        if (s > 0.0) {   // 0: empty active-set union, contributes nothing (:642-664)
+          const double inv = fast_rcp(s);
+          const double ts = prm.link_thresh * s;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            acc[v] = fma(e[v], inv, acc[v]);
+            if (write_comm) cnt[v] += (e[v] > ts) ? 1u : 0u;
+          }
+        }
+        if (count_me && lane == 0) { if (sparse) n_sparse++; else n_dense++; }
+      }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) csum[0][v] += acc[v];
+      if (slot < 0) {
+        store_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
+        if (write_comm) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const unsigned long long b = __ballot(kval[v] && cnt[v] > prm.lt_min_deg);
+            if (lane == 0) d.member[(size_t)p * geo.kw + v] = b;
+          }
+        }
+      } else {
+        store_row<W, V>(d.parts + (size_t)slot * ld, lw, ld, acc);
+        if (write_comm) {
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kval[v]) d.part_cnt[(size_t)slot * ld + kidx[v]] = cnt[v];
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 2) {
+    block_reduce_store<W, V, 1>(csum, d.part_a + (size_t)blockIdx.x * K, K, lds);
+    __shared__ unsigned long long lcnt[3 * 4];
+    block_store_link_counts(n_dense, n_sparse, n_short, d.part_links, lcnt, 4);
+  }
+}
+
+// ---------------------------------------------- node finalise, first half: up to the new gamma
+// compute_mean_indicators + swap (src/linksampling.cc:526-545,751-755) on the own columns; what set_dir_exp and
+// prune need from the WHOLE row goes to rowx[p] as this rank's partial: sum_k gamma, |{k: gamma - alpha >= 1}|,
+// sum of (community + 1) over that set (the community itself when the set has one element).
+template <int V>
+__global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, Params prm, int init) {
+  constexpr int W = 64;
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double lds[2 * V * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lw = lane;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool annealing = ctrl->annealing != 0;
+  const bool write_comm = ctrl->write_comm != 0;
+  int kidx[V];
+  bool kval[V];
+  double scale[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)kidx[v] < K;
+    scale[v] = (!init && annealing && kval[v]) ? (double)prm.ones / d.kvec_a[kidx[v]] : 1.0;
+  }
+  double s12[2][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
+  for (uint32_t p = blockIdx.x * 4 + wave; p < geo.n; p += gridDim.x * 4) {
+    double gn[V];
+    if (init) {
+      load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+#pragma unroll
+      for (int v = 0; v < V; ++v) if (!kval[v]) gn[v] = 0.0;
+    } else {
+      const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
+      double acc[V];
+      const int32_t sf = d.split_first[p];
+      if (sf < 0) {
+        load_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = 0.0;
+        const uint32_t sc = d.split_cnt[p];
+        for (uint32_t t = 0; t < sc; ++t) {
+          double part[V];
+          load_row<W, V>(d.parts + (size_t)(sf + t) * ld, lw, ld, part);
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[v] += part[v];
+        }
+        if (write_comm) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            uint32_t c = 0;
+            if (kval[v])
+              for (uint32_t t = 0; t < sc; ++t) c += d.part_cnt[(size_t)(sf + t) * ld + kidx[v]];
+            const unsigned long long b = __ballot(kval[v] && c > prm.lt_min_deg);
+            if (lw == 0) d.member[(size_t)p * geo.kw + v] = b;
+          }
+        }
+      }
+      if (tl > 0.0) {
+        double m[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const double g0 = prm.alpha + acc[v];
+          m[v] = (g0 - prm.alpha) / tl;
+          gn[v] = g0 + ((double)geo.n - tl - 1.0) * m[v];
+          if (annealing) gn[v] *= scale[v];
+          if (kval[v]) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; }
+          else { m[v] = 0.0; gn[v] = 0.0; }
+        }
+        store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) gn[v] = kval[v] ? prm.alpha : 0.0;
+      }
+      store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    }
+    double rs = 0.0, na = 0.0, ix = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      rs += gn[v];
+      const bool act = kval[v] && (gn[v] - prm.alpha >= 1.0);
+      na += act ? 1.0 : 0.0;
+      ix += act ? (double)(geo.K0 + (uint32_t)kidx[v] + 1u) : 0.0;
+    }
+    rs = group_sum<W>(rs); na = group_sum<W>(na); ix = group_sum<W>(ix);
+    if (lane == 0) { d.rowx[3 * (size_t)p] = rs; d.rowx[3 * (size_t)p + 1] = na; d.rowx[3 * (size_t)p + 2] = ix; }
+  }
+  if (!init) block_reduce_store<W, V, 2>(s12, d.part_b + (size_t)blockIdx.x * 2 * K, K, lds);
+}
+
+// ---------------------------------------------- node finalise, second half: from the summed rowx
+// set_dir_exp (src/linksampling.hh:170-187) and prune (src/linksampling.cc:455-491) with the row sum and
+// the active set of the whole row; the flags come out identical on every rank.
+template <int V>
+__global__ __launch_bounds__(256) void k_fin2_ksh(Geometry geo, DeviceState d, Params prm, int init) {
+  constexpr int W = 64;
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lw = lane;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
+  for (uint32_t p = blockIdx.x * 4 + wave; p < geo.n; p += gridDim.x * 4) {
+    double gn[V];
+    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    const double rs = d.rowx[3 * (size_t)p];
+    const double psi_rs = digamma(rs, logtab);
+    double el[V], ep[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const bool kv = (uint32_t)kmap<W, V>(lw, v) < K;
+      el[v] = kv ? digamma(gn[v], logtab) - psi_rs : 0.0;
+      ep[v] = kv ? exp_neg(el[v]) : 0.0;
+    }
+    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, ep);
+    if (init) continue;
+    const uint32_t active = (uint32_t)d.rowx[3 * (size_t)p + 1];
+    const uint32_t idx = (uint32_t)d.rowx[3 * (size_t)p + 2];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const bool act = (uint32_t)kmap<W, V>(lw, v) < K && (gn[v] - prm.alpha >= 1.0);
+      const unsigned long long bits = __ballot(act);
+      if (lane == 0) d.amask[(size_t)p * geo.kw + v] = (active <= geo.k10) ? bits : 0ull;
+    }
+    if (lane == 0) {
+      conv_new[p] = (active == 1u) ? idx : conv_old[p];
+      d.active_cnt[p] = active;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- s3 pass, K-sharded
+// src/linksampling.cc:731-746 on the own columns.  Quirk Q2 reads column pc (one past the converged community
+// pc - 1) and adds into column pc - 1: the rank that holds column pc does it; when pc is its first column the
+// target belongs to the rank on its left and travels through q2v[K0 - 1].
+template <int V>
+__global__ __launch_bounds__(256) void k_s3_ksh(Geometry geo, DeviceState d) {
+  constexpr int W = 64;
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double lds[V * 64];
+  __shared__ double xq[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lw = lane;
+  const uint32_t K = geo.K, ld = geo.ld, K0 = geo.K0;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const double *__restrict__ mphi = d.mphi;
+  int kidx[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) kidx[v] = kmap<W, V>(lw, v);
+  double s3[1][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s3[0][v] = 0.0;
+  double out = 0.0;   // wave-uniform: this rank's contribution to column K0 - 1
+  for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_s3; it += gridDim.x * 4) {
+    const Item item_ = d.items_s3[d.item0_s3 + it];
+    const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.node);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.off);
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.len);
+    const uint64_t base = d.rowptr[p] + off;
+    const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)conv[p]);
+    double mp[V];
+    load_row<W, V>(mphi + (size_t)p * ld, lw, ld, mp);
+    for (uint32_t j = 0; j < len; ++j) {
+      const uint32_t q = d.col[base + j];
+      const uint32_t qc = conv[q];
+      if ((pc != 0) != (qc != 0)) {
+        const uint32_t cc = pc ? pc : qc;           // column read (global), target cc - 1
+        const uint32_t other = pc ? q : p;
+        if (cc < geo.Kt && cc >= K0 && cc < K0 + K) {
+          const double val = mphi[(size_t)other * ld + (cc - K0)];
+          if (cc == K0) out += val;
+          else {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+              if (kidx[v] == (int)(cc - K0) - 1) s3[0][v] += val;
+          }
+        }
+      } else {
+        double mq[V];
+        load_row<W, V>(mphi + (size_t)q * ld, lw, ld, mq);
+#pragma unroll
+        for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
+      }
+    }
+  }
+  block_reduce_store<W, V, 1>(s3, d.part_c + (size_t)blockIdx.x * K, K, lds);
+  if (lane == 0) xq[wave] = out;
+  __syncthreads();
+  if (threadIdx.x == 0) d.part_q2[blockIdx.x] = ((xq[0] + xq[1]) + xq[2]) + xq[3];
+}
+// this rank's outgoing Q2 share, summed over the s3 blocks in block order, into q2v (zero elsewhere)
+__global__ __launch_bounds__(256) void k_q2_ksh(Geometry geo, DeviceState d) {
+  if (d.ctrl->stopped) return;
+  for (uint32_t k = threadIdx.x; k < geo.Kt; k += blockDim.x) d.q2v[k] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0 && geo.K0 > 0) {
+    double t = 0.0;
+    for (uint32_t b = 0; b < d.nb_c; ++b) t += d.part_q2[b];
+    d.q2v[geo.K0 - 1] = t;
+  }
+}
+
+// ---------------------------------------------------------------- lambda of the own columns (one block)
+__global__ __launch_bounds__(256) void k_lam_ksh(Geometry geo, DeviceState d, Params prm) {
+  if (d.ctrl->stopped) return;
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
+  const uint32_t K = geo.K;
+  for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
+    const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k];
+    const double s3 = d.kvec_c[2 * (size_t)K + k] + d.q2v[geo.K0 + k];   // the summed q2v: what the other ranks found for this column
+    const double l0 = prm.eta0 + d.kvec_a[k];
+    const double l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+    d.lambda[2 * k] = l0;
+    d.lambda[2 * k + 1] = l1;
+    const double ps = digamma(l0 + l1, logtab);
+    d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
+    d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
+  }
+}
+
+// ---------------------------------------------------------------- held-out pairs: partial dot products
+template <int V>
+__global__ __launch_bounds__(256) void k_vdot_ksh(Geometry geo, DeviceState d) {
+  constexpr int W = 64;
+  if (d.ctrl->stopped) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lw = lane;
+  const uint32_t K = geo.K, ld = geo.ld;
+  double beta[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int k = kmap<W, V>(lw, v);
+    beta[v] = 0.0;
+    if ((uint32_t)k < K) {
+      const double l0 = d.lambda[2 * k], l1 = d.lambda[2 * k + 1];
+      beta[v] = l0 / (l0 + l1);
+    }
+  }
+  for (uint32_t i = blockIdx.x * 4 + wave; i < d.nv; i += gridDim.x * 4) {
+    const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1];
+    double gp[V], gq[V];
+    load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gp);
+    load_row<W, V>(d.gamma + (size_t)q * ld, lw, ld, gq);
+    double dot = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) dot += gp[v] * gq[v] * beta[v];
+    dot = group_sum<W>(dot);
+    if (lane == 0) d.vdot[i] = dot;
+  }
+}
+
+// ---------------------------------------------------------------- likelihood row, stop rule, loop control
+// validation_likelihood + the tail of the loop body (src/linksampling.cc:966-1050,763-787) from the summed
+// vdot and rowx: one block, fixed-order sums, the same on every rank.
+__global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, Params prm) {
+  DevCtrl c = *d.ctrl;
+  if (c.stopped) return;
+  __shared__ double red[3][256];
+  __shared__ unsigned long long cred[3][256];
+  const uint32_t iter = c.iter;
+  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
+  double sz = 0.0, so = 0.0, kz = 0.0;
+  if (do_val)
+    for (uint32_t i = threadIdx.x; i < d.nv; i += blockDim.x) {
+      const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1], y = d.vpairs[3 * (size_t)i + 2];
+      const double pq = d.vdot[i] / (d.rowx[3 * (size_t)p] * d.rowx[3 * (size_t)q]);
+      double sv = y ? pq : 1.0 - pq;
+      if (sv < 1e-30) sv = 1e-30;
+      const double u = log(sv);
+      if (y) so += u; else { sz += u; kz += 1.0; }
+    }
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {
+    t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+  }
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; red[2][threadIdx.x] = kz;
+  cred[0][threadIdx.x] = t0; cred[1][threadIdx.x] = t1; cred[2][threadIdx.x] = t2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int a = 0; a < 3; ++a) {
+        red[a][threadIdx.x] += red[a][threadIdx.x + o];
+        cred[a][threadIdx.x] += cred[a][threadIdx.x + o];
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  c.parity ^= 1u;
+  c.links_dense = cred[0][0]; c.links_sparse = cred[1][0]; c.links_shortcut = cred[2][0];
+  if (d.sweep_stats) {
+    unsigned long long *st = d.sweep_stats + (size_t)(c.sweeps_done % d.sweep_stats_cap) * 4;
+    st[0] = c.links_dense; st[1] = c.links_sparse; st[2] = c.links_shortcut; st[3] = c.sweeps_done;
+  }
+  c.sweeps_done++;
+  c.write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+  bool exit_now = false;
+  if (do_val) {
+    const double szeros = red[0][0], sones = red[1][0];
+    const uint32_t kzeros = (uint32_t)red[2][0], kones = d.nv - kzeros;
+    const double mean0 = szeros / kzeros, mean1 = sones / kones;
+    const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
+    double *row = d.rows + (size_t)(c.rows % d.rows_cap) * 10;
+    row[0] = (double)iter; row[1] = (szeros + sones) / d.nv; row[2] = (double)d.nv;
+    row[3] = mean0; row[4] = (double)kzeros; row[5] = mean1; row[6] = (double)kones;
+    row[7] = prm.zeros_prob * mean0; row[8] = prm.ones_prob * mean1; row[9] = a;
+    c.rows++;
+    bool stop = false;
+    int why = -1;
+    if (iter > 10) {     // src/linksampling.cc:1008-1027
+      if (a > c.prev_h && c.prev_h != 0 && fabs((a - c.prev_h) / c.prev_h) < 0.00001) { stop = true; why = 100; }
+      else if (a < c.prev_h) c.nh++;
+      else if (a > c.prev_h) c.nh = 0;
+      if (a > c.max_h) c.max_h = a;
+      if (c.nh > 2) { why = 1; stop = true; }
+    }
+    c.prev_h = a;
+    if (c.annealing && stop) { c.annealing = 0; c.nh = 0; c.prev_h = 0; }
+    else if (!c.annealing && stop && prm.use_validation_stop) exit_now = true;
+    c.why = why;
+  }
+  if (exit_now) c.stopped = 1;
+  else c.iter = iter + 1;
+  *d.ctrl = c;
+}
+
+// ------------------------------------------------------------------ launchers
+#define KSH_DISPATCH(g, CALL)                   \
+  do {                                          \
+    if ((g).V == 1) { CALL(1); }                \
+    else if ((g).V == 2) { CALL(2); }           \
+    else if ((g).V == 4) { CALL(4); }           \
+    else if ((g).V == 8) { CALL(8); }           \
+    else if ((g).V == 16) { CALL(16); }         \
+    else { CALL(32); }                          \
+  } while (0)
+
+void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, int phase, hipStream_t s) {
+  const uint32_t nbn = (g.n + 3) / 4 > 2048 ? 2048 : (g.n + 3) / 4;   // node loops: one node per wavefront
+  switch (phase) {
+    case 0: {   // DEN
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+    } break;
+    case 1: {   // PHI + sum + first half of the finalise pass
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+      launch_reduce_a(g, d, s);
+#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+    } break;
+    case 2: {   // second half of the finalise pass, s3
+#define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 0)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+#define CALL(V_) hipLaunchKernelGGL((k_s3_ksh<V_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+      launch_reduce_c(g, d, s);
+      hipLaunchKernelGGL(k_q2_ksh, dim3(1), dim3(256), 0, s, g, d);
+    } break;
+    case 3: {   // lambda, partial dot products
+      hipLaunchKernelGGL(k_lam_ksh, dim3(1), dim3(256), 0, s, g, d, p);
+      if (d.nv) {
+        const uint32_t nb = (d.nv + 3) / 4 > 1024 ? 1024 : (d.nv + 3) / 4;
+#define CALL(V_) hipLaunchKernelGGL((k_vdot_ksh<V_>), dim3(nb), dim3(256), 0, s, g, d)
+        KSH_DISPATCH(g, CALL);
+#undef CALL
+      }
+    } break;
+    case 4:     // likelihood row, stop rule, loop control
+      hipLaunchKernelGGL(k_stop_ksh, dim3(1), dim3(256), 0, s, g, d, p);
+      break;
+    case 5: {   // initial state: partial row sums of the gamma just set
+#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+    } break;
+    case 6: {   // initial state: Elogpi from the summed row sums
+#define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+    } break;
+    default: break;
+  }
+}
+
+}  // namespace svils

@@ -1,0 +1,117 @@
+"""K-sharded sweeps over the GPUs of one node: every rank keeps the columns [k0, k1) of ALL rows.
+
+The node-block layout (sharded.py) replicates the n-by-k state and all-gathers the gamma rows every sweep
+(n*k*8 bytes).  Here the state is split by columns instead; the columns of a row are coupled in four places
+only, each a buffer of partials SUMmed over the ranks between two phases (DESIGN.md section 8,
+svinet_amd/csrc/svils_ksh.h, tests/test_ksharded_protocol.py):
+
+    DEN -> SUM den[L] -> PHI -> SUM rowx[3n] -> FIN -> SUM q2v[K] -> LAMBDA -> SUM vdot[V] -> STOP
+
+The native driver is svils_comm_init + svils_ksh_init_state + svils_sweep_ksharded (RCCL all-reduces on the
+engine's stream).  This module is the caller-driven form: `KShard` wraps one engine and exposes its exchange
+buffers as torch tensors, `sweep_virtual` runs several of them in one process (tests), `KShardedSweep` runs
+one per process over torch.distributed.
+"""
+import numpy as np
+
+from . import _svils
+from .sharded import _as_tensor
+
+
+def column_slices(k, world):
+    """contiguous, as even as possible: rank r holds [b[r], b[r+1])"""
+    b = [(k * r) // world for r in range(world + 1)]
+    return [(b[r], b[r + 1]) for r in range(world)]
+
+
+class KShard:
+    def __init__(self, setup, rank, world, device_index=0, **engine_kw):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank, world
+        self.k0, self.k1 = column_slices(setup.k, world)[rank]
+        from ._svils import Engine
+        args = dict(ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta,
+                    link_thresh=setup.link_thresh, lt_min_deg=setup.lt_min_deg, device=device_index,
+                    k_slice=(self.k0, self.k1))
+        args.update(engine_kw)
+        self.engine = e = Engine(setup.n, setup.k, **args)
+        e.set_graph(setup.links)
+        e.set_validation(setup.validation_sorted)
+        e.set_state(np.ascontiguousarray(setup.gamma[:, self.k0:self.k1]), np.ascontiguousarray(setup.lam[self.k0:self.k1]))
+        dev = torch.device("cuda", device_index)
+        self.stream = torch.cuda.ExternalStream(e.stream(), device=dev)
+        self.buf = {}
+        for which in (_svils.KSH_DEN, _svils.KSH_ROWX, _svils.KSH_Q2, _svils.KSH_VDOT):
+            p, n = e.ksh_buffer(which)
+            self.buf[which] = _as_tensor(torch, p, 8 * n, "<f8", dev) if n else None
+
+
+_ORDER = ((_svils.KPHASE_DEN, _svils.KSH_DEN), (_svils.KPHASE_PHI, _svils.KSH_ROWX), (_svils.KPHASE_FIN, _svils.KSH_Q2),
+          (_svils.KPHASE_LAMBDA, _svils.KSH_VDOT), (_svils.KPHASE_STOP, None))
+
+
+def _sum_virtual(shards, which):
+    ts = [s.buf[which] for s in shards]
+    if ts[0] is None:
+        return
+    for s in shards:
+        s.engine.synchronize()
+    tot = ts[0].clone()
+    for t in ts[1:]:
+        tot += t
+    for t in ts:
+        t.copy_(tot)
+    shards[0].torch.cuda.synchronize()
+
+
+def init_virtual(shards):
+    for s in shards:
+        s.engine.ksweep_phase(_svils.KPHASE_INIT_ROWS)
+    _sum_virtual(shards, _svils.KSH_ROWX)
+    for s in shards:
+        s.engine.ksweep_phase(_svils.KPHASE_INIT_EXPAND)
+
+
+def sweep_virtual(shards, nsweeps=1):
+    """all ranks in ONE process (tests): the exchanges are plain tensor sums in rank order"""
+    for _ in range(nsweeps):
+        for phase, which in _ORDER:
+            for s in shards:
+                s.engine.ksweep_phase(phase)
+            if which is not None:
+                _sum_virtual(shards, which)
+
+
+class KShardedSweep:
+    """one rank per process: the exchanges are torch.distributed all-reduces on the engine's stream"""
+
+    def __init__(self, shard, dist, group=None):
+        self.s, self.dist, self.group = shard, dist, group
+
+    def _sum(self, which):
+        t = self.s.buf[which]
+        if t is None:
+            return
+        torch = self.s.torch
+        if self.dist.get_backend(self.group) == "gloo":
+            self.s.engine.synchronize()
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+            torch.cuda.synchronize()
+        else:
+            with torch.cuda.stream(self.s.stream):
+                self.dist.all_reduce(t, group=self.group)
+
+    def init(self):
+        self.s.engine.ksweep_phase(_svils.KPHASE_INIT_ROWS)
+        self._sum(_svils.KSH_ROWX)
+        self.s.engine.ksweep_phase(_svils.KPHASE_INIT_EXPAND)
+
+    def sweep(self, nsweeps=1):
+        for _ in range(nsweeps):
+            for phase, which in _ORDER:
+                self.s.engine.ksweep_phase(phase)
+                if which is not None:
+                    self._sum(which)
