@@ -23,6 +23,21 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     setup = Setup(path, n, k)
+    if mode == "kshard":   # every rank a column slice of all rows (svinet_amd/ksharded.py)
+        from svinet_amd.ksharded import KShard, KShardedSweep
+        ks = KShard(setup, rank, world, 0, use_validation_stop=False)
+        run = KShardedSweep(ks, dist)
+        run.init()
+        run.sweep(sweeps)
+        ks.engine.synchronize()
+        torch.cuda.synchronize()
+        g, lam, conv = ks.engine.state()
+        c = ks.engine.control()
+        np.savez(out + ".%d.npz" % rank, gamma=g, lam=lam, conv=conv, member=ks.engine.communities(), k0=ks.k0, k1=ks.k1,
+                 iter=c.iter, annealing=c.annealing, rows=ks.engine.rows())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     shard = HipShard(setup, rank, world, 0, use_validation_stop=False)
     if mode.startswith("step"):
         _, nwin, kappa = mode.split(":")

@@ -35,3 +35,60 @@ def test_ksharded_virtual_ranks_equal_oracle(graph_files, graph, world, k, sweep
         assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
         np.testing.assert_allclose(s.engine.rows()[:, 1:], np.asarray(ref.rows)[1:sweeps + 1, 1:], rtol=1e-9, atol=1e-13)
         assert np.array_equal(s.engine.aux(3), ref.active_comms)
+
+
+@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 40), (3, 100, 5)])
+def test_ksharded_processes_one_gpu(graph_files, tmp_path, world, k, sweeps):
+    """svinet_amd/ksharded.py end to end in separate processes (one per rank, as on a multi-GPU node), all on
+    GPU 0 with a gloo group: the column slices put together equal the oracle's state, the replicated flags,
+    likelihood rows and community tags agree on every rank."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py")
+    out = str(tmp_path / "kstate")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29650 + world), worker,
+                        graph_files["lfr"], "1000", str(k), str(sweeps), out, "kshard"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    states = [np.load(out + ".%d.npz" % rk) for rk in range(world)]
+    g = np.concatenate([s["gamma"] for s in states], 1)
+    lam = np.concatenate([s["lam"] for s in states], 0)
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    want = ref.communities()
+    for s in states:
+        assert np.array_equal(s["conv"], ref.converged)
+        assert int(s["iter"]) == ref.iter and bool(s["annealing"]) == ref.annealing
+        np.testing.assert_allclose(s["rows"][:, 1:], ref.rows[1:, 1:], rtol=1e-9, atol=1e-13)
+        assert np.array_equal(s["member"], want[:, int(s["k0"]):int(s["k1"])])   # each rank tags its own columns
+
+
+def test_native_ksharded_driver_world1(graph_files):
+    """svils_comm_init + svils_ksh_init_state + svils_sweep_ksharded with a communicator of ONE rank holding
+    every column (RCCL never saw more than one rank of this code on the hardware available): equals the
+    plain engine's sweeps at 1e-12 (the two phi forms differ in rounding) and the oracle's flags."""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    path, n, k = graph_files["lfr"], 1000, 100
+    setup = Setup(path, n, k)
+    eng = _svils.Engine(n, k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, link_thresh=setup.link_thresh,
+                        lt_min_deg=setup.lt_min_deg, use_validation_stop=False, k_slice=(0, k))
+    eng.set_graph(setup.links)
+    eng.set_validation(setup.validation_sorted)
+    eng.set_state(setup.gamma, setup.lam)
+    eng.comm_init(_svils.comm_unique_id(), 0, 1)
+    eng.ksh_init_state()
+    eng.sweep_ksharded(8)
+    plain = setup.engine(use_validation_stop=False)
+    plain.sweep(8)
+    g1, l1, c1 = eng.state()
+    g2, l2, c2 = plain.state()
+    assert np.max(np.abs(g1 - g2) / g2) < 1e-12 and np.max(np.abs(l1 - l2) / np.abs(l2)) < 1e-12
+    assert np.array_equal(c1, c2)
+    np.testing.assert_allclose(eng.rows()[:, 1:], plain.rows()[:, 1:], rtol=1e-11, atol=1e-14)
+    assert np.array_equal(eng.communities(), plain.communities())
