@@ -239,6 +239,30 @@ class _Sharded:
         self.eng.sweep_sharded(n)
 
 
+class _KSharded:
+    """One chain over all ranks, K-sharded: rank r holds the columns [k r / G, k (r+1) / G) of every row and the
+    library all-reduces the four coupling buffers itself (svils_sweep_ksharded)."""
+
+    def __init__(self, setup, rank, world, device, dist):
+        import numpy as np
+        from svinet_amd import _svils
+        from svinet_amd.ksharded import column_slices
+        k0, k1 = column_slices(setup.k, world)[rank]
+        self.eng = e = _svils.Engine(setup.n, setup.k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta,
+                                     link_thresh=setup.link_thresh, lt_min_deg=setup.lt_min_deg,
+                                     use_validation_stop=False, device=device, k_slice=(k0, k1))
+        e.set_graph(setup.links)
+        e.set_validation(setup.validation_sorted)
+        e.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+        ids = [_svils.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        e.comm_init(ids[0], rank, world)
+        e.ksh_init_state()
+
+    def sweep(self, n):
+        self.eng.sweep_ksharded(n)
+
+
 def _timed(runner, eng, steps, dist, torch):
     """barrier + device sync on both sides of exactly `steps` sweeps; MAX over ranks"""
     eng.synchronize(); torch.cuda.synchronize()
@@ -487,10 +511,14 @@ def main():
     # config 4 (ca-AstroPh K=200) and the HBM-bound size (n=2e5, k=512) -- one chain over the N ranks each.
     if multi and not args.no_extra:
         extra = {}
-        for name, wl, wsteps in (("config4_astroph_k200", "astroph-k200", 50), ("hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10)):
+        for name, wl, wsteps, cls in (("config4_astroph_k200", "astroph-k200", 50, _Sharded),
+                                      ("hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _Sharded),
+                                      # the same two workloads with the columns sharded instead of the nodes
+                                      ("ksharded_config4_astroph_k200", "astroph-k200", 50, _KSharded),
+                                      ("ksharded_hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _KSharded)):
             try:
                 s2, p2, _, n2, k2, _ = _load_workload(wl)
-                r2 = _Sharded(s2, rank, world, local_rank, dist)
+                r2 = cls(s2, rank, world, local_rank, dist)
                 r2.sweep(3)
                 r2.eng.enable_timing((1 << _svils.KERNEL_PHI) | (1 << _svils.KERNEL_EXCHANGE), 1)
                 el2 = _timed(r2, r2.eng, wsteps, dist, torch)
