@@ -6,6 +6,7 @@ Layout:
   _svils.py    ctypes binding of the C ABI
   host_api.py  ctypes binding of the C++ host side
   sharded.py   node-block multi-GPU driver (torch.distributed / RCCL)
+  ksharded.py  K-sharded multi-GPU driver (every rank a column slice of all rows)
   build.py     in-tree hipcc / g++ build
 """
 import ctypes as _C
