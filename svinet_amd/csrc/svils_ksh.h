@@ -70,11 +70,22 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
     uint32_t p_active = 0;
     if (sparse_iter) p_active = d.active_cnt[p];
 
+    // a neighbour needs its row when its link takes the softmax branch and (MODE 1) is counted here; the row of
+    // the next one that does is in flight while the current one is reduced
+    auto needs_row = [&](uint32_t jj) {
+      const uint32_t qq = __builtin_amdgcn_readlane(mycol, jj), cc = __builtin_amdgcn_readlane(myconv, jj);
+      return ((pc != 0) == (cc != 0)) && (MODE == 2 || qq > p);
+    };
+    double r[V], rnext[V];
+    if (len > 0 && needs_row(0)) load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, 0) * ld, lw, ld, r);
     for (uint32_t j = 0; j < len; ++j) {
       const uint32_t q = __builtin_amdgcn_readlane(mycol, j);
       const uint32_t qc = __builtin_amdgcn_readlane(myconv, j);
       const uint32_t el = __builtin_amdgcn_readlane(myel, j);
+      if (j + 1 < len && needs_row(j + 1))
+        load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, j + 1) * ld, lw, ld, rnext);
       const bool count_me = q > p;
+      bool handled = false;
       if ((pc != 0) != (qc != 0)) {
         if constexpr (MODE == 2) {
           // exactly one endpoint converged: +1 at the converged community, on the rank that holds it (:622-631)
@@ -84,13 +95,13 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
             if (kidx[v] == c) acc[v] += 1.0;
           if (count_me && lane == 0) n_short++;
         }
-        continue;
+        handled = true;
+      } else if (MODE == 1 && !count_me) {
+        handled = true;   // one denominator per undirected link
       }
-      if (MODE == 1 && !count_me) continue;   // one denominator per undirected link
+      if (!handled) {   // (body kept at loop depth)
       bool sparse = false;
       if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
-      double r[V];
-      load_row<W, V>(epi + (size_t)q * ld, lw, ld, r);
       double e[V];
       double s = 0.0;
 #pragma unroll
@@ -122,6 +133,9 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
         }
         if (count_me && lane == 0) { if (sparse) n_sparse++; else n_dense++; }
       }
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) r[v] = rnext[v];
     }
     if constexpr (MODE == 2) {
 #pragma unroll
@@ -415,17 +429,15 @@ __global__ __launch_bounds__(256) void k_vdot_ksh(Geometry geo, DeviceState d) {
 
 // ---------------------------------------------------------------- likelihood row, stop rule, loop control
 // validation_likelihood + the tail of the loop body (src/linksampling.cc:966-1050,763-787) from the summed
-// vdot and rowx: one block, fixed-order sums, the same on every rank.
-__global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, Params prm) {
-  DevCtrl c = *d.ctrl;
-  if (c.stopped) return;
+// vdot and rowx.  k_vsum_ksh: the log terms of the held-out pairs, one fixed-order partial per block;
+// k_stop_ksh: one block adds the partials in block order -- the same numbers on every rank.
+__global__ __launch_bounds__(256) void k_vsum_ksh(Geometry geo, DeviceState d, Params prm) {
+  const DevCtrl *c = d.ctrl;
+  if (c->stopped) return;
   __shared__ double red[3][256];
-  __shared__ unsigned long long cred[3][256];
-  const uint32_t iter = c.iter;
-  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
   double sz = 0.0, so = 0.0, kz = 0.0;
-  if (do_val)
-    for (uint32_t i = threadIdx.x; i < d.nv; i += blockDim.x) {
+  if (d.nv > 0 && (c->iter % prm.reportfreq == 0))
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < d.nv; i += gridDim.x * blockDim.x) {
       const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1], y = d.vpairs[3 * (size_t)i + 2];
       const double pq = d.vdot[i] / (d.rowx[3 * (size_t)p] * d.rowx[3 * (size_t)q]);
       double sv = y ? pq : 1.0 - pq;
@@ -433,22 +445,37 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
       const double u = log(sv);
       if (y) so += u; else { sz += u; kz += 1.0; }
     }
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; red[2][threadIdx.x] = kz;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int a = 0; a < 3; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) d.tail_part[(size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, Params prm, uint32_t nvb) {
+  DevCtrl c = *d.ctrl;
+  if (c.stopped) return;
+  __shared__ unsigned long long cred[3][256];
+  const uint32_t iter = c.iter;
+  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
   for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {
     t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
   }
-  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; red[2][threadIdx.x] = kz;
   cred[0][threadIdx.x] = t0; cred[1][threadIdx.x] = t1; cred[2][threadIdx.x] = t2;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o)
-      for (int a = 0; a < 3; ++a) {
-        red[a][threadIdx.x] += red[a][threadIdx.x + o];
-        cred[a][threadIdx.x] += cred[a][threadIdx.x + o];
-      }
+      for (int a = 0; a < 3; ++a) cred[a][threadIdx.x] += cred[a][threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
+  double szeros = 0.0, sones = 0.0, kzd = 0.0;
+  for (uint32_t b = 0; b < nvb; ++b) {   // block order
+    szeros += d.tail_part[(size_t)b * 4]; sones += d.tail_part[(size_t)b * 4 + 1]; kzd += d.tail_part[(size_t)b * 4 + 2];
+  }
   c.parity ^= 1u;
   c.links_dense = cred[0][0]; c.links_sparse = cred[1][0]; c.links_shortcut = cred[2][0];
   if (d.sweep_stats) {
@@ -459,8 +486,7 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
   c.write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
   bool exit_now = false;
   if (do_val) {
-    const double szeros = red[0][0], sones = red[1][0];
-    const uint32_t kzeros = (uint32_t)red[2][0], kones = d.nv - kzeros;
+    const uint32_t kzeros = (uint32_t)kzd, kones = d.nv - kzeros;
     const double mean0 = szeros / kzeros, mean1 = sones / kones;
     const double a = prm.zeros_prob * mean0 + prm.ones_prob * mean1;
     double *row = d.rows + (size_t)(c.rows % d.rows_cap) * 10;
@@ -534,9 +560,12 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
 #undef CALL
       }
     } break;
-    case 4:     // likelihood row, stop rule, loop control
-      hipLaunchKernelGGL(k_stop_ksh, dim3(1), dim3(256), 0, s, g, d, p);
-      break;
+    case 4: {   // likelihood row, stop rule, loop control
+      uint32_t nvb = (d.nv + 1023) / 1024;   // four pairs per thread; tail_part holds 256 block partials
+      nvb = nvb < 1 ? 1 : nvb > 256 ? 256 : nvb;
+      hipLaunchKernelGGL(k_vsum_ksh, dim3(nvb), dim3(256), 0, s, g, d, p);
+      hipLaunchKernelGGL(k_stop_ksh, dim3(1), dim3(256), 0, s, g, d, p, nvb);
+    } break;
     case 5: {   // initial state: partial row sums of the gamma just set
 #define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
       KSH_DISPATCH(g, CALL);
