@@ -166,6 +166,180 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
   }
 }
 
+// ---------------------------------------------------------------- phi pass, K-sharded, slices of <= 64 columns
+// A 64-column slice is one double per lane in k_phi_ksh<1,.>: every neighbour pays the fixed per-row cost (read-lanes,
+// a six-step reduction, reciprocal) for 512 bytes.  Here a row is spread over 16 lanes x 4 doubles and the four
+// 16-lane groups of a wavefront take four DIFFERENT neighbours of the node per step: the reduction is four DPP steps
+// inside a row of lanes, shared by the four neighbours, and the bookkeeping is issued once per four.  The handle's
+// bitmask arrays (amask in, member out) are one word per node here (bit k = column k of the slice).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, Params prm) {
+  constexpr int W = 16, V = 4;
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double lds[V * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = lane >> 4, lw = lane & 15;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool write_comm = ctrl->write_comm != 0;
+  const bool sparse_iter = (long long)ctrl->iter > (long long)prm.sparse_after;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const double *__restrict__ epi = d.epi;
+  int kidx[V];
+  bool kval[V];
+  double eb[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)kidx[v] < K;
+    eb[v] = kval[v] ? exp_neg(d.elogbeta[2 * kidx[v]]) : 0.0;
+  }
+  double csum[1][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) csum[0][v] = 0.0;
+  uint32_t n_dense = 0, n_sparse = 0, n_short = 0;   // wave-uniform
+
+  for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_phi; it += gridDim.x * 4) {
+    const Item item_ = d.items_phi[d.item0_phi + it];
+    const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.node);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.off);
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.len);
+    const int32_t slot = __builtin_amdgcn_readfirstlane(item_.slot);
+    const uint64_t base = d.rowptr[p] + off;
+    uint32_t mycol = 0, myconv = 0, myel = 0;
+    if ((uint32_t)lane < len) {
+      mycol = d.col[base + lane];
+      myconv = conv[mycol];
+      myel = d.elink[base + lane];
+    }
+    const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)conv[p]);
+    double ap[V];
+    load_row<W, V>(epi + (size_t)p * ld, lw, ld, ap);
+#pragma unroll
+    for (int v = 0; v < V; ++v) ap[v] *= eb[v];
+    double acc[V];
+    uint32_t cnt[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { acc[v] = 0.0; cnt[v] = 0; }
+    uint32_t p_active = 0;
+    unsigned long long pmask = 0ull;
+    if (sparse_iter) { p_active = d.active_cnt[p]; pmask = d.amask[p]; }
+
+    // this group's neighbour of the four starting at j, and whether it needs its row
+    auto mine = [&](uint32_t j, uint32_t &q, uint32_t &qc, uint32_t &el, bool &need) {
+      const uint32_t jj = j + (uint32_t)g;
+      const int src = (int)(jj < len ? jj : 0u);
+      q = (uint32_t)__shfl((int)mycol, src, 64);
+      qc = (uint32_t)__shfl((int)myconv, src, 64);
+      el = (uint32_t)__shfl((int)myel, src, 64);
+      const bool valid = jj < len;
+      need = valid && ((pc != 0) == (qc != 0)) && (MODE == 2 || q > p);
+      return valid;
+    };
+    double r[V], rnext[V];
+    uint32_t q, qc, el;
+    bool need;
+    bool valid = mine(0, q, qc, el, need);
+    if (need) load_row<W, V>(epi + (size_t)q * ld, lw, ld, r);
+    for (uint32_t j = 0; j < len; j += 4) {
+      uint32_t q1 = 0, qc1 = 0, el1 = 0;
+      bool need1 = false, valid1 = false;
+      if (j + 4 < len) {
+        valid1 = mine(j + 4, q1, qc1, el1, need1);
+        if (need1) load_row<W, V>(epi + (size_t)q1 * ld, lw, ld, rnext);
+      }
+      const bool count_me = valid && lw == 0 && q > p;
+      if constexpr (MODE == 2) {
+        const bool shortc = valid && ((pc != 0) != (qc != 0));
+        if (__any(shortc)) {
+          // exactly one endpoint converged: +1 at the converged community, on the rank that holds it (:622-631)
+          const int c = (int)(pc ? pc : qc) - 1 - (int)geo.K0;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (shortc && kidx[v] == c) acc[v] += 1.0;
+          n_short += (uint32_t)__popcll(__ballot(shortc && count_me));
+        }
+      }
+      if (__any(need)) {
+        bool sparse = false;
+        unsigned long long um = ~0ull;
+        if (sparse_iter && need) {
+          sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
+          if (sparse) um = pmask | d.amask[q];
+        }
+        double e[V];
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          double t = need ? ap[v] * r[v] : 0.0;
+          if (sparse) t = ((um >> kidx[v]) & 1ull) ? t : 0.0;
+          e[v] = t;
+          s += t;
+        }
+        if constexpr (MODE == 1) {
+          s = group_sum<W>(s);
+          if (need && lw == 0) d.den[el] = s;
+        } else {
+          s = need ? d.den[el] : 1.0;   // the link's denominator over ALL columns
+          if (need && s < 1e-280 && !(sparse && s == 0.0)) ctrl->fault = 2u;   // see k_phi_ksh
+          const bool live = need && s > 0.0;
+          const double inv = live ? fast_rcp(s) : 0.0;
+          const double ts = prm.link_thresh * s;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            acc[v] = fma(e[v], inv, acc[v]);
+            if (write_comm) cnt[v] += (live && e[v] > ts) ? 1u : 0u;
+          }
+          n_sparse += (uint32_t)__popcll(__ballot(need && sparse && count_me));
+          n_dense += (uint32_t)__popcll(__ballot(need && !sparse && count_me));
+        }
+      }
+      q = q1; qc = qc1; el = el1; need = need1; valid = valid1;
+#pragma unroll
+      for (int v = 0; v < V; ++v) r[v] = rnext[v];
+    }
+    if constexpr (MODE == 2) {
+      // the four groups' shares of the node
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        acc[v] += __shfl_xor(acc[v], 16, 64);
+        acc[v] += __shfl_xor(acc[v], 32, 64);
+        cnt[v] += (uint32_t)__shfl_xor((int)cnt[v], 16, 64);
+        cnt[v] += (uint32_t)__shfl_xor((int)cnt[v], 32, 64);
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) csum[0][v] += acc[v];
+      }
+      if (slot < 0) {
+        if (g == 0) store_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
+        if (write_comm) {
+          unsigned long long w = 0ull;   // this lane's columns that are tagged, as bits of the node's word
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (g == 0 && kval[v] && cnt[v] > prm.lt_min_deg) w |= 1ull << kidx[v];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, 64);
+          if (lane == 0) d.member[p] = w;
+        }
+      } else {
+        if (g == 0) store_row<W, V>(d.parts + (size_t)slot * ld, lw, ld, acc);
+        if (write_comm && g == 0) {
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kval[v]) d.part_cnt[(size_t)slot * ld + kidx[v]] = cnt[v];
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 2) {
+    block_reduce_store<W, V, 1>(csum, d.part_a + (size_t)blockIdx.x * K, K, lds);
+    __shared__ unsigned long long lcnt[3 * 4];
+    block_store_link_counts(lane == 0 ? n_dense : 0ull, lane == 0 ? n_sparse : 0ull, lane == 0 ? n_short : 0ull,
+                            d.part_links, lcnt, 4);
+  }
+}
+
 // ---------------------------------------------- node finalise, first half: up to the new gamma
 // compute_mean_indicators + swap (src/linksampling.cc:526-545,751-755) on the own columns; what set_dir_exp and
 // prune need from the WHOLE row goes to rowx[p] as this rank's partial: sum_k gamma, |{k: gamma - alpha >= 1}|,
@@ -514,6 +688,9 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
 }
 
 // ------------------------------------------------------------------ launchers
+#ifndef KSH_NARROW
+#define KSH_NARROW 1
+#endif
 #define KSH_DISPATCH(g, CALL)                   \
   do {                                          \
     if ((g).V == 1) { CALL(1); }                \
@@ -528,14 +705,18 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
   const uint32_t nbn = (g.n + 3) / 4 > 2048 ? 2048 : (g.n + 3) / 4;   // node loops: one node per wavefront
   switch (phase) {
     case 0: {   // DEN
+      if (g.V == 1 && KSH_NARROW) { hipLaunchKernelGGL((k_phi_ksh16<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break; }
 #define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
       KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
     case 1: {   // PHI + sum + first half of the finalise pass
+      if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL((k_phi_ksh16<2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);
+      else {
 #define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
-      KSH_DISPATCH(g, CALL);
+        KSH_DISPATCH(g, CALL);
 #undef CALL
+      }
       launch_reduce_a(g, d, s);
 #define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0)
       KSH_DISPATCH(g, CALL);

@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("graph,world,k,sweeps", [("lfr", 2, 28, 70), ("lfr", 4, 100, 6), ("lfr", 3, 130, 5),
-                                                   ("astroph", 4, 200, 3)])
+                                                   ("astroph", 4, 200, 3),      # slices of <= 64 columns: k_phi_ksh16
+                                                   ("astroph", 2, 200, 3), ("lfr", 2, 300, 30),   # 100 / 150 columns: k_phi_ksh<2>, <4>
+                                                   ("lfr", 2, 600, 4)])         # 300 columns: k_phi_ksh<8>
 def test_ksharded_virtual_ranks_equal_oracle(graph_files, graph, world, k, sweeps):
     from svinet_amd.host_api import Setup
     from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
@@ -33,7 +35,7 @@ def test_ksharded_virtual_ranks_equal_oracle(graph_files, graph, world, k, sweep
         c = s.engine.control()
         assert c.iter == ref.iter and bool(c.annealing) == ref.annealing and c.sweeps_done == sweeps
         assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
-        np.testing.assert_allclose(s.engine.rows()[:, 1:], np.asarray(ref.rows)[1:sweeps + 1, 1:], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(s.engine.rows()[:, 1:], np.asarray(ref.rows)[1:sweeps + 1, 1:], rtol=1e-8, atol=1e-11)
         assert np.array_equal(s.engine.aux(3), ref.active_comms)
 
 
