@@ -538,6 +538,64 @@ __global__ __launch_bounds__(256) void k_s3_ksh(Geometry geo, DeviceState d) {
   __syncthreads();
   if (threadIdx.x == 0) d.part_q2[blockIdx.x] = ((xq[0] + xq[1]) + xq[2]) + xq[3];
 }
+// the same for slices of <= 64 columns: a row over 16 lanes x 4 doubles, four neighbours of the node per step (see k_phi_ksh16)
+__global__ __launch_bounds__(256) void k_s3_ksh16(Geometry geo, DeviceState d) {
+  constexpr int W = 16, V = 4;
+  DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  __shared__ double lds[V * 64];
+  __shared__ double xq[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = lane >> 4, lw = lane & 15;
+  const uint32_t K = geo.K, ld = geo.ld, K0 = geo.K0;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const double *__restrict__ mphi = d.mphi;
+  int kidx[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) kidx[v] = kmap<W, V>(lw, v);
+  double s3[1][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s3[0][v] = 0.0;
+  double out = 0.0;   // per group (its lanes agree): this rank's contribution to column K0 - 1
+  for (uint32_t it = blockIdx.x * 4 + wave; it < d.nitems_s3; it += gridDim.x * 4) {
+    const Item item_ = d.items_s3[d.item0_s3 + it];
+    const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.node);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.off);
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_.len);
+    const uint64_t base = d.rowptr[p] + off;
+    const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)conv[p]);
+    double mp[V];
+    load_row<W, V>(mphi + (size_t)p * ld, lw, ld, mp);
+    for (uint32_t j = (uint32_t)g; j < len; j += 4) {   // each group its own neighbours
+      const uint32_t q = d.col[base + j];
+      const uint32_t qc = conv[q];
+      if ((pc != 0) != (qc != 0)) {
+        const uint32_t cc = pc ? pc : qc;           // column read (global), target cc - 1
+        const uint32_t other = pc ? q : p;
+        if (cc < geo.Kt && cc >= K0 && cc < K0 + K) {
+          const double val = mphi[(size_t)other * ld + (cc - K0)];
+          if (cc == K0) out += val;
+          else {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+              if (kidx[v] == (int)(cc - K0) - 1) s3[0][v] += val;
+          }
+        }
+      } else {
+        double mq[V];
+        load_row<W, V>(mphi + (size_t)q * ld, lw, ld, mq);
+#pragma unroll
+        for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
+      }
+    }
+  }
+  block_reduce_store<W, V, 1>(s3, d.part_c + (size_t)blockIdx.x * K, K, lds);
+  // the four groups of the wave, in group order, then the waves
+  const double o1 = __shfl(out, 16, 64), o2 = __shfl(out, 32, 64), o3 = __shfl(out, 48, 64);
+  if (lane == 0) xq[wave] = ((out + o1) + o2) + o3;
+  __syncthreads();
+  if (threadIdx.x == 0) d.part_q2[blockIdx.x] = ((xq[0] + xq[1]) + xq[2]) + xq[3];
+}
 // this rank's outgoing Q2 share, summed over the s3 blocks in block order, into q2v (zero elsewhere)
 __global__ __launch_bounds__(256) void k_q2_ksh(Geometry geo, DeviceState d) {
   if (d.ctrl->stopped) return;
@@ -726,9 +784,12 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
 #define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 0)
       KSH_DISPATCH(g, CALL);
 #undef CALL
+      if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL(k_s3_ksh16, dim3(d.nb_c), dim3(256), 0, s, g, d);
+      else {
 #define CALL(V_) hipLaunchKernelGGL((k_s3_ksh<V_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
-      KSH_DISPATCH(g, CALL);
+        KSH_DISPATCH(g, CALL);
 #undef CALL
+      }
       launch_reduce_c(g, d, s);
       hipLaunchKernelGGL(k_q2_ksh, dim3(1), dim3(256), 0, s, g, d);
     } break;
