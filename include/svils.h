@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 2
+#define SVILS_ABI_VERSION 3   /* 3: svils_config gained k_begin / k_total (K-sharded handles) */
 
 typedef enum {
   SVILS_OK = 0,
