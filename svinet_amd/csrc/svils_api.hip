@@ -1072,6 +1072,7 @@ void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes) {
 
 int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
   if (!h || !cfg) return fail(SVILS_ERR_ARG, "svils_set_stochastic: null argument");
+  if (h->d.ksh) return fail(SVILS_ERR_UNSUPPORTED, "svils_set_stochastic: K-sharded handles run full sweeps only");
   if (!(cfg->tau0 >= 1.0) || !(cfg->kappa >= 0.0) || cfg->kappa > 1.0 || !(cfg->node_tau0 >= 1.0) ||
       !(cfg->node_kappa >= 0.0) || cfg->node_kappa > 1.0)
     return fail(SVILS_ERR_ARG, "svils_set_stochastic: need tau0 >= 1 and 0 <= kappa <= 1");
