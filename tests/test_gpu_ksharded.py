@@ -94,3 +94,31 @@ def test_native_ksharded_driver_world1(graph_files):
     assert np.array_equal(c1, c2)
     np.testing.assert_allclose(eng.rows()[:, 1:], plain.rows()[:, 1:], rtol=1e-11, atol=1e-14)
     assert np.array_equal(eng.communities(), plain.communities())
+
+
+@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 60), (3, 100, 40), (2, 300, 30)])
+def test_ksharded_active_set_path(graph_files, world, k, sweeps):
+    """the active-set branch (src/linksampling.cc:634-681) from the first sweep on (sparse_after_iter = 0, as in the
+    authors' shipped runs): the union of two active sets spans the slices, an empty union is empty on every rank"""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
+    path, n = graph_files["lfr"], 1000
+    setup = Setup(path, n, k)
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False, sparse_after_iter=0) for r in range(world)]
+    init_virtual(shards)
+    sweep_virtual(shards, sweeps)
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False, sparse_after_iter=0)
+    counts = []
+    for _ in range(sweeps):
+        ref.sweep()
+        counts.append(ref.link_counts())
+    assert sum(c[1] for c in counts) > 0, "the test must exercise the active-set branch"
+    states = [s.engine.state() for s in shards]
+    g = np.concatenate([st[0] for st in states], 1)
+    lam = np.concatenate([st[1] for st in states], 0)
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    for st, s in zip(states, shards):
+        assert np.array_equal(st[2], ref.converged)
+        got = [tuple(int(x) for x in r[:3]) for r in s.engine.sweep_stats(0, sweeps)]
+        assert got == counts
