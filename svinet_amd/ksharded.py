@@ -96,10 +96,11 @@ class KShardedSweep:
         torch = self.s.torch
         if self.dist.get_backend(self.group) == "gloo":
             self.s.engine.synchronize()
-            h = t.cpu()
+            h = t.cpu() if t.is_cuda else t
             self.dist.all_reduce(h, group=self.group)
-            t.copy_(h)
-            torch.cuda.synchronize()
+            if t.is_cuda:
+                t.copy_(h)
+                torch.cuda.synchronize()
         else:
             with torch.cuda.stream(self.s.stream):
                 self.dist.all_reduce(t, group=self.group)
