@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("graph,world,k,sweeps", [("lfr", 2, 28, 70), ("lfr", 4, 100, 6), ("lfr", 3, 130, 5),
-                                                   ("astroph", 4, 200, 3),      # slices of <= 64 columns: k_phi_ksh16
+                                                   ("astroph", 4, 200, 3), ("lfr", 7, 28, 20),   # slices of <= 64 columns (down to 4): k_phi_ksh16
                                                    ("astroph", 2, 200, 3), ("lfr", 2, 300, 30),   # 100 / 150 columns: k_phi_ksh<2>, <4>
                                                    ("lfr", 2, 600, 4)])         # 300 columns: k_phi_ksh<8>
 def test_ksharded_virtual_ranks_equal_oracle(graph_files, graph, world, k, sweeps):
