@@ -122,3 +122,27 @@ def test_ksharded_active_set_path(graph_files, world, k, sweeps):
         assert np.array_equal(st[2], ref.converged)
         got = [tuple(int(x) for x in r[:3]) for r in s.engine.sweep_stats(0, sweeps)]
         assert got == counts
+
+
+def test_ksharded_underflowing_denominator_is_loud():
+    """rows of (almost) disjoint support: every e^x_k of a link underflows on every rank.  The K-sharded layout has no
+    log-domain detour across ranks; it must stop with an error, not drop the link silently."""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
+    k, world = 200, 2
+    n = 2 * k + 20
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    chords = np.stack([np.arange(n), (np.arange(n) + 7) % n], 1)
+    pairs = np.concatenate([ring, chords]).astype(np.int32)
+    setup = Setup(n=n, k=k, pairs=pairs, heldout_ratio=0.0)
+    g = np.full((n, k), 5e-4)
+    g[np.arange(n), np.arange(n) % k] = 50.0
+    lam = np.tile([3.0, 2.0], (k, 1))
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False) for r in range(world)]
+    for s in shards:
+        s.engine.set_state(np.ascontiguousarray(g[:, s.k0:s.k1]), np.ascontiguousarray(lam[s.k0:s.k1]))
+    init_virtual(shards)
+    with pytest.raises(_svils.SvilsError, match="underflowed"):
+        sweep_virtual(shards, 1)       # the first host entry that looks at the control block reports it
+        shards[0].engine.control()
