@@ -289,12 +289,17 @@ int svils_gather_communities(svils_handle *h);
  * first; the node block of a K-sharded handle is [0, n)). */
 typedef enum {
   SVILS_KPHASE_DEN = 0, SVILS_KPHASE_PHI = 1, SVILS_KPHASE_FIN = 2, SVILS_KPHASE_LAMBDA = 3, SVILS_KPHASE_STOP = 4,
-  SVILS_KPHASE_INIT_ROWS = 5, SVILS_KPHASE_INIT_EXPAND = 6
+  SVILS_KPHASE_INIT_ROWS = 5, SVILS_KPHASE_INIT_EXPAND = 6,
+  SVILS_KPHASE_DENMAX = 7   /* log-domain mode only: before DEN, followed by a MAX (not SUM) of SVILS_KSH_DMAX */
 } svils_kphase;
-typedef enum { SVILS_KSH_DEN = 0, SVILS_KSH_ROWX = 1, SVILS_KSH_Q2 = 2, SVILS_KSH_VDOT = 3 } svils_ksh_buffer;
+typedef enum { SVILS_KSH_DEN = 0, SVILS_KSH_ROWX = 1, SVILS_KSH_Q2 = 2, SVILS_KSH_VDOT = 3, SVILS_KSH_DMAX = 4 } svils_ksh_buffer;
 int svils_ksweep_phase(svils_handle *h, svils_kphase phase);
 /* device pointer and length (doubles) of an exchange buffer */
 int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, size_t *ndoubles);
+/* Log-domain denominators: the product form of the DEN / PHI phases underflows when max_k x_k < -745 for a link (memberships
+ * concentrated on different communities at k_total >~ 740); this mode exchanges the per-link max first (phase DENMAX, MAX of
+ * SVILS_KSH_DMAX) and sums e^(x - max).  On by default for k_total > 700.  on = 1 / 0 sets it, on < 0 returns the setting. */
+int svils_ksh_log_domain(svils_handle *h, int on);
 int svils_ksh_init_state(svils_handle *h);           /* collective: the two INIT phases around their all-reduce */
 int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps);   /* collective, asynchronous */
 

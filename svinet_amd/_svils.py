@@ -27,7 +27,7 @@ EXPORTS = (
     "svils_set_timing_period", "svils_set_stochastic", "svils_step", "svils_stochastic_default", "svils_step_phase", "svils_step_window",
     "svils_get_sweep_stats", "svils_get_timed_links",
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
-    "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded",
+    "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
 )
 
 
@@ -142,8 +142,8 @@ def comm_unique_id():
     _chk(load().svils_comm_unique_id(buf))
     return buf.raw
 PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND = range(5)
-KPHASE_DEN, KPHASE_PHI, KPHASE_FIN, KPHASE_LAMBDA, KPHASE_STOP, KPHASE_INIT_ROWS, KPHASE_INIT_EXPAND = range(7)
-KSH_DEN, KSH_ROWX, KSH_Q2, KSH_VDOT = range(4)
+KPHASE_DEN, KPHASE_PHI, KPHASE_FIN, KPHASE_LAMBDA, KPHASE_STOP, KPHASE_INIT_ROWS, KPHASE_INIT_EXPAND, KPHASE_DENMAX = range(8)
+KSH_DEN, KSH_ROWX, KSH_Q2, KSH_VDOT, KSH_DMAX = range(5)
 
 
 class Engine:
@@ -200,6 +200,13 @@ class Engine:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(load().svils_ksh_buffer_ptr(self._h, int(which), C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def ksh_log_domain(self, on=None):
+        """set (True / False) or query (None) the log-domain denominators of a K-sharded handle"""
+        rc = load().svils_ksh_log_domain(self._h, -1 if on is None else int(bool(on)))
+        if on is None:
+            return bool(rc)
+        _chk(rc)
 
     def ksh_init_state(self):
         _chk(load().svils_ksh_init_state(self._h))

@@ -358,6 +358,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   // 3.45 -> 3.02 ms); beyond that it runs at the HBM gather ceiling either way and the extra n-by-k write of the
   // finalise pass would cost more than the exps (n=1e6 K=512: phi -0.6 ms, finalise +0.75 ms)
   d.ksh = cfg->k_total ? 1 : 0;
+  d.ksh_log = cfg->k_total > 700 ? 1 : 0;   // psi(1/K) < -745: concentrated memberships underflow the product form
   if (d.ksh || (!use_lpl(g.K) && nk * sizeof(double) <= 1536ull << 20)) guard(dalloc(h, &d.epi, nk));
   if (d.ksh) {
     guard(dalloc(h, &d.rowx, 3 * (size_t)g.n));
@@ -547,7 +548,8 @@ int svils_ksweep_phase(svils_handle *h, svils_kphase phase) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: not a K-sharded handle (svils_config.k_total)");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: set graph and state first");
-  if ((int)phase < 0 || (int)phase > 6) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: unknown phase %d", (int)phase);
+  if ((int)phase < 0 || (int)phase > 7) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: unknown phase %d", (int)phase);
+  if (phase == SVILS_KPHASE_DENMAX && !h->d.ksh_log) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: DENMAX belongs to the log-domain mode (svils_ksh_log_domain)");
   HIPCHK(hipSetDevice(h->cfg.device));
   launch_ksh_phase(h->geo, h->d, h->prm, (int)phase, h->stream);
   HIPCHK(hipGetLastError());
@@ -564,8 +566,17 @@ int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, s
     case SVILS_KSH_ROWX: *dptr = d.rowx; *ndoubles = 3 * (size_t)h->geo.n; return 0;
     case SVILS_KSH_Q2: *dptr = d.q2v; *ndoubles = h->geo.Kt; return 0;
     case SVILS_KSH_VDOT: *dptr = d.vdot; *ndoubles = d.nv; return 0;
+    case SVILS_KSH_DMAX: *dptr = d.dmax; *ndoubles = (size_t)d.nlinks; return 0;
   }
   return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: unknown buffer %d", (int)which);
+}
+
+int svils_ksh_log_domain(svils_handle *h, int on) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: null handle");
+  if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: not a K-sharded handle");
+  if (on < 0) return h->d.ksh_log;   // query
+  h->d.ksh_log = on ? 1 : 0;
+  return 0;
 }
 
 namespace {
@@ -576,7 +587,7 @@ int ksh_sum(svils_handle *h, svils_ksh_buffer which) {
   int rc = svils_ksh_buffer_ptr(h, which, &p, &n);
   if (rc || n == 0) return rc;
   Timed t(h, SVILS_KERNEL_EXCHANGE);
-  NCCLCHK(g_rccl.AllReduce(p, p, n, ncclDouble, ncclSum, h->comm, h->stream));
+  NCCLCHK(g_rccl.AllReduce(p, p, n, ncclDouble, which == SVILS_KSH_DMAX ? ncclMax : ncclSum, h->comm, h->stream));
   return 0;
 }
 }  // namespace
@@ -597,6 +608,10 @@ int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
                 (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
   for (uint32_t i = 0; i < nsweeps; ++i) {
     int rc;
+    if (h->d.ksh_log) {
+      if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DENMAX))) return rc;
+      if ((rc = ksh_sum(h, SVILS_KSH_DMAX))) return rc;   // MAX
+    }
     if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DEN))) return rc;
     if ((rc = ksh_sum(h, SVILS_KSH_DEN))) return rc;
     if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_PHI))) return rc;
@@ -801,6 +816,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     if (nlinks >= (1ull << 32)) return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handles index links with 32 bits");
     guard(dalloc(h, &d.elink, elink.size(), false));
     guard(dalloc(h, &d.den, std::max<uint64_t>(nlinks, 1)));
+    guard(dalloc(h, &d.dmax, std::max<uint64_t>(nlinks, 1)));
     guard(dalloc(h, &d.part_q2, d.nb_c));
   }
   if (rc) return rc;

@@ -122,6 +122,8 @@ struct DeviceState {
   int ksh;              // 1: the handle holds a column slice
   uint32_t *elink;      // [2L]  training-link index of every CSR entry
   double *den;          // [L]   softmax denominators of the links (partial -> SUM -> total)
+  int ksh_log;          // 1: log-domain denominators (max, then shifted sum): two L-sized exchanges, no underflow
+  double *dmax;         // [L]   log-domain mode: max_k x_k of the links (partial -> MAX -> total)
   double *rowx;         // [n][3] row sum of the new gamma, active-community count, sum of (community + 1) over them
   double *q2v;          // [Kt]  quirk Q2 contributions that belong to another rank's column
   double *vdot;         // [nv]  partial sum_k gamma_p gamma_q beta_k of the held-out pairs

@@ -18,7 +18,11 @@
 namespace svils {
 
 // ---------------------------------------------------------------- phi pass, K-sharded
-template <int V, int MODE>
+// LOG: the log-domain form for models whose denominators can underflow (max_k x_k < -745: concentrated memberships at
+// K >~ 740): MODE 0 writes the link's max over the own columns (-> MAX over the ranks), MODE 1 sums e^(x_k - max),
+// MODE 2 accumulates e^(x_k - max) / den -- two L-sized exchanges and K exps per link and pass instead of one exchange
+// and multiplies, which is why it is a mode (svils_ksh_log_domain; on by default above K = 700).
+template <int V, int MODE, bool LOG>
 __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Params prm) {
   constexpr int W = 64;
   DevCtrl *ctrl = d.ctrl;
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
   const bool write_comm = ctrl->write_comm != 0;
   const bool sparse_iter = (long long)ctrl->iter > (long long)prm.sparse_after;
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
-  const double *__restrict__ epi = d.epi;
+  const double *__restrict__ epi = LOG ? d.elogpi : d.epi;   // LOG: rows of Elogpi
   int kidx[V];
   bool kval[V];
   double eb[V];
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
   for (int v = 0; v < V; ++v) {
     kidx[v] = kmap<W, V>(lw, v);
     kval[v] = (uint32_t)kidx[v] < K;
-    eb[v] = kval[v] ? exp_neg(d.elogbeta[2 * kidx[v]]) : 0.0;
+    eb[v] = kval[v] ? (LOG ? d.elogbeta[2 * kidx[v]] : exp_neg(d.elogbeta[2 * kidx[v]])) : (LOG ? NEG_INF : 0.0);
   }
   double csum[1][V];
 #pragma unroll
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
     double ap[V];
     load_row<W, V>(epi + (size_t)p * ld, lw, ld, ap);
 #pragma unroll
-    for (int v = 0; v < V; ++v) ap[v] *= eb[v];
+    for (int v = 0; v < V; ++v) ap[v] = LOG ? ap[v] + eb[v] : ap[v] * eb[v];
     double acc[V];
     uint32_t cnt[V];
 #pragma unroll
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
     // the next one that does is in flight while the current one is reduced
     auto needs_row = [&](uint32_t jj) {
       const uint32_t qq = __builtin_amdgcn_readlane(mycol, jj), cc = __builtin_amdgcn_readlane(myconv, jj);
-      return ((pc != 0) == (cc != 0)) && (MODE == 2 || qq > p);
+      return ((pc != 0) == (cc != 0)) && (MODE == 2 || qq > p);   // MODE 0 and 1: one value per undirected link
     };
     double r[V], rnext[V];
     if (len > 0 && needs_row(0)) load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, 0) * ld, lw, ld, r);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
           if (count_me && lane == 0) n_short++;
         }
         handled = true;
-      } else if (MODE == 1 && !count_me) {
+      } else if (MODE != 2 && !count_me) {
         handled = true;   // one denominator per undirected link
       }
       if (!handled) {   // (body kept at loop depth)
@@ -104,24 +108,48 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
       if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
       double e[V];
       double s = 0.0;
+      if constexpr (LOG) {
+        double m = NEG_INF;
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        double t = ap[v] * r[v];
-        if (sparse) {
-          const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
-          t = ((um >> lw) & 1ull) ? t : 0.0;
+        for (int v = 0; v < V; ++v) {
+          double t = ap[v] + r[v];   // padding columns: -inf
+          if (sparse) {
+            const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
+            t = ((um >> lw) & 1ull) ? t : NEG_INF;
+          }
+          e[v] = t;
+          m = fmax(m, t);
         }
-        e[v] = t;
-        s += t;
+        if constexpr (MODE == 0) {
+          m = group_max<W>(m);
+          if (lane == 0) d.dmax[el] = m;
+        } else {
+          const double M = d.dmax[el];   // over ALL columns; -inf: empty active-set union
+#pragma unroll
+          for (int v = 0; v < V; ++v) { e[v] = (M == NEG_INF) ? 0.0 : exp_neg(e[v] - M); s += e[v]; }
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          double t = ap[v] * r[v];
+          if (sparse) {
+            const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
+            t = ((um >> lw) & 1ull) ? t : 0.0;
+          }
+          e[v] = t;
+          s += t;
+        }
       }
-      if constexpr (MODE == 1) {
+      if constexpr (MODE == 0) {
+        // (LOG only) nothing else to do for this link
+      } else if constexpr (MODE == 1) {
         s = group_sum<W>(s);
         if (lane == 0) d.den[el] = s;
       } else {
         s = d.den[el];   // the link's denominator over ALL columns
-        // a denominator that underflowed (possible only for rows of disjoint support at very large K): this layout has
-        // no log-domain detour across ranks yet -- say so instead of dropping the link
-        if (s < 1e-280 && !(sparse && s == 0.0)) ctrl->fault = 2u;
+        // a denominator that underflowed (possible only for rows of disjoint support at very large K): the product form
+        // has no way back -- say so instead of dropping the link (the log-domain mode cannot get here: its sum is >= 1)
+        if (!LOG && s < 1e-280 && !(sparse && s == 0.0)) ctrl->fault = 2u;
         if (s > 0.0) {   // 0: empty active-set union, contributes nothing (:642-664)
           const double inv = fast_rcp(s);
           const double ts = prm.link_thresh * s;
@@ -763,15 +791,25 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
   const uint32_t nbn = (g.n + 3) / 4 > 2048 ? 2048 : (g.n + 3) / 4;   // node loops: one node per wavefront
   switch (phase) {
     case 0: {   // DEN
-      if (g.V == 1 && KSH_NARROW) { hipLaunchKernelGGL((k_phi_ksh16<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break; }
-#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+      if (g.V == 1 && KSH_NARROW && !d.ksh_log) { hipLaunchKernelGGL((k_phi_ksh16<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break; }
+      if (d.ksh_log) {
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 1, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+        KSH_DISPATCH(g, CALL);
+#undef CALL
+        break;
+      }
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 1, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
       KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
     case 1: {   // PHI + sum + first half of the finalise pass
-      if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL((k_phi_ksh16<2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);
+      if (d.ksh_log) {
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 2, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+        KSH_DISPATCH(g, CALL);
+#undef CALL
+      } else if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL((k_phi_ksh16<2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);
       else {
-#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 2, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
         KSH_DISPATCH(g, CALL);
 #undef CALL
       }
@@ -815,6 +853,11 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
     } break;
     case 6: {   // initial state: Elogpi from the summed row sums
 #define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
+      KSH_DISPATCH(g, CALL);
+#undef CALL
+    } break;
+    case 7: {   // log-domain mode: per-link max over the own columns (then MAX over the ranks, then DEN)
+#define CALL(V_) hipLaunchKernelGGL((k_phi_ksh<V_, 0, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p)
       KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;

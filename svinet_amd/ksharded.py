@@ -6,6 +6,7 @@ only, each a buffer of partials SUMmed over the ranks between two phases (DESIGN
 svinet_amd/csrc/svils_ksh.h, tests/test_ksharded_protocol.py):
 
     DEN -> SUM den[L] -> PHI -> SUM rowx[3n] -> FIN -> SUM q2v[K] -> LAMBDA -> SUM vdot[V] -> STOP
+    (log-domain mode, the default above K = 700: DENMAX -> MAX dmax[L] first, then the same)
 
 The native driver is svils_comm_init + svils_ksh_init_state + svils_sweep_ksharded (RCCL all-reduces on the
 engine's stream).  This module is the caller-driven form: `KShard` wraps one engine and exposes its exchange
@@ -25,7 +26,8 @@ def column_slices(k, world):
 
 
 class KShard:
-    def __init__(self, setup, rank, world, device_index=0, **engine_kw):
+    def __init__(self, setup, rank, world, device_index=0, log_domain=None, **engine_kw):
+        """log_domain: None = the library's default (on above K = 700), True / False forces it"""
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
@@ -42,13 +44,21 @@ class KShard:
         dev = torch.device("cuda", device_index)
         self.stream = torch.cuda.ExternalStream(e.stream(), device=dev)
         self.buf = {}
-        for which in (_svils.KSH_DEN, _svils.KSH_ROWX, _svils.KSH_Q2, _svils.KSH_VDOT):
+        if log_domain is not None:
+            e.ksh_log_domain(log_domain)
+        self.log_domain = e.ksh_log_domain()
+        for which in (_svils.KSH_DEN, _svils.KSH_ROWX, _svils.KSH_Q2, _svils.KSH_VDOT, _svils.KSH_DMAX):
             p, n = e.ksh_buffer(which)
             self.buf[which] = _as_tensor(torch, p, 8 * n, "<f8", dev) if n else None
 
 
 _ORDER = ((_svils.KPHASE_DEN, _svils.KSH_DEN), (_svils.KPHASE_PHI, _svils.KSH_ROWX), (_svils.KPHASE_FIN, _svils.KSH_Q2),
           (_svils.KPHASE_LAMBDA, _svils.KSH_VDOT), (_svils.KPHASE_STOP, None))
+
+
+def _order(shard):
+    """(phase, buffer to reduce after it) of one sweep; the log-domain mode exchanges the per-link max first"""
+    return (((_svils.KPHASE_DENMAX, _svils.KSH_DMAX),) if shard.log_domain else ()) + _ORDER
 
 
 def _sum_virtual(shards, which):
@@ -59,7 +69,10 @@ def _sum_virtual(shards, which):
         s.engine.synchronize()
     tot = ts[0].clone()
     for t in ts[1:]:
-        tot += t
+        if which == _svils.KSH_DMAX:
+            tot = shards[0].torch.maximum(tot, t)
+        else:
+            tot += t
     for t in ts:
         t.copy_(tot)
     shards[0].torch.cuda.synchronize()
@@ -76,7 +89,7 @@ def init_virtual(shards):
 def sweep_virtual(shards, nsweeps=1):
     """all ranks in ONE process (tests): the exchanges are plain tensor sums in rank order"""
     for _ in range(nsweeps):
-        for phase, which in _ORDER:
+        for phase, which in _order(shards[0]):
             for s in shards:
                 s.engine.ksweep_phase(phase)
             if which is not None:
@@ -94,16 +107,17 @@ class KShardedSweep:
         if t is None:
             return
         torch = self.s.torch
+        op = self.dist.ReduceOp.MAX if which == _svils.KSH_DMAX else self.dist.ReduceOp.SUM
         if self.dist.get_backend(self.group) == "gloo":
             self.s.engine.synchronize()
             h = t.cpu() if t.is_cuda else t
-            self.dist.all_reduce(h, group=self.group)
+            self.dist.all_reduce(h, op=op, group=self.group)
             if t.is_cuda:
                 t.copy_(h)
                 torch.cuda.synchronize()
         else:
             with torch.cuda.stream(self.s.stream):
-                self.dist.all_reduce(t, group=self.group)
+                self.dist.all_reduce(t, op=op, group=self.group)
 
     def init(self):
         self.s.engine.ksweep_phase(_svils.KPHASE_INIT_ROWS)
@@ -112,7 +126,7 @@ class KShardedSweep:
 
     def sweep(self, nsweeps=1):
         for _ in range(nsweeps):
-            for phase, which in _ORDER:
+            for phase, which in _order(self.s):
                 self.s.engine.ksweep_phase(phase)
                 if which is not None:
                     self._sum(which)

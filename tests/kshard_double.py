@@ -48,6 +48,7 @@ class NumpyKShard:
                     _svils.KSH_Q2: torch.zeros(k, dtype=torch.float64), _svils.KSH_VDOT: torch.zeros(V, dtype=torch.float64)}
         self.engine = _Engine(self)
         self.stream = None
+        self.log_domain = False
 
     def owns(self, c):
         return (c >= self.k0) & (c < self.k1)

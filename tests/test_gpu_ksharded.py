@@ -70,7 +70,8 @@ def test_ksharded_processes_one_gpu(graph_files, tmp_path, world, k, sweeps):
         assert np.array_equal(s["member"], want[:, int(s["k0"]):int(s["k1"])])   # each rank tags its own columns
 
 
-def test_native_ksharded_driver_world1(graph_files):
+@pytest.mark.parametrize("log_domain", [False, True])
+def test_native_ksharded_driver_world1(graph_files, log_domain):
     """svils_comm_init + svils_ksh_init_state + svils_sweep_ksharded with a communicator of ONE rank holding
     every column (RCCL never saw more than one rank of this code on the hardware available): equals the
     plain engine's sweeps at 1e-12 (the two phi forms differ in rounding) and the oracle's flags."""
@@ -83,6 +84,7 @@ def test_native_ksharded_driver_world1(graph_files):
     eng.set_graph(setup.links)
     eng.set_validation(setup.validation_sorted)
     eng.set_state(setup.gamma, setup.lam)
+    eng.ksh_log_domain(log_domain)
     eng.comm_init(_svils.comm_unique_id(), 0, 1)
     eng.ksh_init_state()
     eng.sweep_ksharded(8)
@@ -139,10 +141,65 @@ def test_ksharded_underflowing_denominator_is_loud():
     g = np.full((n, k), 5e-4)
     g[np.arange(n), np.arange(n) % k] = 50.0
     lam = np.tile([3.0, 2.0], (k, 1))
-    shards = [KShard(setup, r, world, 0, use_validation_stop=False) for r in range(world)]
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False, log_domain=False) for r in range(world)]
     for s in shards:
         s.engine.set_state(np.ascontiguousarray(g[:, s.k0:s.k1]), np.ascontiguousarray(lam[s.k0:s.k1]))
     init_virtual(shards)
     with pytest.raises(_svils.SvilsError, match="underflowed"):
         sweep_virtual(shards, 1)       # the first host entry that looks at the control block reports it
         shards[0].engine.control()
+
+
+@pytest.mark.parametrize("k,world", [(200, 2), (64, 2), (800, 4)])
+def test_ksharded_log_domain_handles_underflowing_rows(k, world):
+    """the same rows of disjoint support in the log-domain mode (per-link max exchanged first): two sweeps equal the oracle's
+    sequential log-sum-exp.  K = 800 takes the mode by default (k_total > 700)."""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
+    n = 2 * k + 20
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    chords = np.stack([np.arange(n), (np.arange(n) + 7) % n], 1)
+    pairs = np.concatenate([ring, chords]).astype(np.int32)
+    setup = Setup(n=n, k=k, pairs=pairs, heldout_ratio=0.0)
+    ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, heldout_ratio=0.0, use_validation_stop=False)
+    ref.set_skip_validation(True)
+    g = np.full((n, k), 5e-4)
+    g[np.arange(n), np.arange(n) % k] = 50.0
+    lam = np.tile([3.0, 2.0], (k, 1))
+    ref.set_gamma(g); ref.set_lambda(lam); ref.refresh()
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False, log_domain=None if k > 700 else True) for r in range(world)]
+    assert all(s.log_domain for s in shards)
+    for s in shards:
+        s.engine.set_state(np.ascontiguousarray(g[:, s.k0:s.k1]), np.ascontiguousarray(lam[s.k0:s.k1]))
+    init_virtual(shards)
+    for _ in range(2):
+        ref.sweep()
+        sweep_virtual(shards, 1)
+        states = [s.engine.state() for s in shards]
+        gg = np.concatenate([st[0] for st in states], 1)
+        ll = np.concatenate([st[1] for st in states], 0)
+        assert np.isfinite(gg).all() and np.isfinite(ll).all()
+        np.testing.assert_allclose(gg, ref.gamma, rtol=1e-7)
+        np.testing.assert_allclose(ll, ref.lam, rtol=1e-7)
+        for st in states:
+            assert np.array_equal(st[2], ref.converged)
+
+
+def test_ksharded_log_domain_equals_product_form(graph_files):
+    """on an ordinary model the two forms agree (LFR K=100, 3 ranks, 40 sweeps) and both equal the oracle"""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
+    path, n, k, world, sweeps = graph_files["lfr"], 1000, 100, 3, 40
+    setup = Setup(path, n, k)
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    for mode in (True, False):
+        shards = [KShard(setup, r, world, 0, use_validation_stop=False, log_domain=mode) for r in range(world)]
+        init_virtual(shards)
+        sweep_virtual(shards, sweeps)
+        states = [s.engine.state() for s in shards]
+        g = np.concatenate([st[0] for st in states], 1)
+        assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+        assert all(np.array_equal(st[2], ref.converged) for st in states)
+        assert (lambda c: (c.links_dense, c.links_sparse, c.links_shortcut))(shards[0].engine.control()) == ref.link_counts()
