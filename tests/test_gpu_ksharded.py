@@ -98,15 +98,16 @@ def test_native_ksharded_driver_world1(graph_files, log_domain):
     assert np.array_equal(eng.communities(), plain.communities())
 
 
-@pytest.mark.parametrize("world,k,sweeps", [(2, 28, 60), (3, 100, 40), (2, 300, 30)])
-def test_ksharded_active_set_path(graph_files, world, k, sweeps):
+@pytest.mark.parametrize("world,k,sweeps,log_domain", [(2, 28, 60, False), (3, 100, 40, False), (2, 300, 30, False),
+                                                        (2, 28, 60, True), (2, 300, 30, True)])
+def test_ksharded_active_set_path(graph_files, world, k, sweeps, log_domain):
     """the active-set branch (src/linksampling.cc:634-681) from the first sweep on (sparse_after_iter = 0, as in the
     authors' shipped runs): the union of two active sets spans the slices, an empty union is empty on every rank"""
     from svinet_amd.host_api import Setup
     from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
     path, n = graph_files["lfr"], 1000
     setup = Setup(path, n, k)
-    shards = [KShard(setup, r, world, 0, use_validation_stop=False, sparse_after_iter=0) for r in range(world)]
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False, sparse_after_iter=0, log_domain=log_domain) for r in range(world)]
     init_virtual(shards)
     sweep_virtual(shards, sweeps)
     ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False, sparse_after_iter=0)
