@@ -327,6 +327,10 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
       delete h;
       return fail(SVILS_ERR_ARG, "K-sharded handle: need k_begin + k <= k_total <= %d and the node block [0, n)", SVILS_MAX_K);
     }
+    if (cfg->link_thresh < 0.5) {
+      delete h;
+      return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handle: link_thresh < 1/2 needs the argmax over all columns of a link (node-block sharding has it)");
+    }
     g.K0 = cfg->k_begin;
     g.Kt = cfg->k_total;
     g.k10 = cfg->k_total / 10;

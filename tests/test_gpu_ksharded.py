@@ -204,3 +204,21 @@ def test_ksharded_log_domain_equals_product_form(graph_files):
         assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
         assert all(np.array_equal(st[2], ref.converged) for st in states)
         assert (lambda c: (c.links_dense, c.links_sparse, c.links_shortcut))(shards[0].engine.control()) == ref.link_counts()
+
+
+def test_ksharded_rejects_what_it_does_not_do(graph_files):
+    """link_thresh < 1/2 (argmax tagging over all columns) and mini-batch steps are refused, not approximated"""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    setup = Setup(graph_files["lfr"], 1000, 100)
+    kw = dict(ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, lt_min_deg=0, use_validation_stop=False, k_slice=(0, 50))
+    with pytest.raises(_svils.SvilsError, match="link_thresh"):
+        _svils.Engine(1000, 100, link_thresh=0.3, **kw)
+    eng = _svils.Engine(1000, 100, link_thresh=0.5, **kw)
+    with pytest.raises(_svils.SvilsError, match="K-sharded"):
+        eng.set_stochastic(batch_nodes=100)
+    eng.set_graph(setup.links)
+    eng.set_validation(setup.validation_sorted)
+    eng.set_state(np.ascontiguousarray(setup.gamma[:, :50]), np.ascontiguousarray(setup.lam[:50]))
+    with pytest.raises(_svils.SvilsError, match="K-sharded"):
+        eng.sweep(1)
