@@ -301,6 +301,13 @@ int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, s
  * SVILS_KSH_DMAX) and sums e^(x - max).  On by default for k_total > 700.  on = 1 / 0 sets it, on < 0 returns the setting. */
 int svils_ksh_log_domain(svils_handle *h, int on);
 int svils_ksh_init_state(svils_handle *h);           /* collective: the two INIT phases around their all-reduce */
+/* On a K-sharded handle svils_validation_row is collective too (partial dot products of the own columns, SUM of
+ * SVILS_KSH_VDOT, the log terms in pair order); call it after svils_ksh_init_state or between two sweeps. */
+/* save_model / communities of a sharded run (src/linksampling.cc:804-837,882-917): every rank hands `bytes`
+ * bytes of host memory (its slice, padded to a common size) and receives world * bytes, rank by rank.
+ * Staged through device memory, ncclAllGather on the handle's stream; synchronises.  Collective.
+ * A handle without a communicator (world of one) copies send to recv. */
+int svils_comm_allgather_host(svils_handle *h, const void *send, void *recv, size_t bytes);
 int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps);   /* collective, asynchronous */
 
 const char *svils_last_error(void);

@@ -28,6 +28,7 @@ EXPORTS = (
     "svils_get_sweep_stats", "svils_get_timed_links",
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
     "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
+    "svils_comm_allgather_host",
 )
 
 
@@ -118,6 +119,7 @@ def load():
     L.svils_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.svils_sweep_sharded.argtypes = [vp, C.c_uint32]
     L.svils_gather_communities.argtypes = [vp]
+    L.svils_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -344,6 +346,13 @@ class Engine:
 
     def gather_communities(self):
         _chk(load().svils_gather_communities(self._h))
+
+    def allgather_host(self, send, world):
+        """every rank's `send` (equal byte counts), rank by rank: array of shape (world,) + send.shape.  Collective."""
+        send = np.ascontiguousarray(send)
+        recv = np.empty((world,) + send.shape, dtype=send.dtype)
+        _chk(load().svils_comm_allgather_host(self._h, send.ctypes.data, recv.ctypes.data, send.nbytes))
+        return recv
 
     def device_buffer(self, which):
         p, b, r = C.c_void_p(), C.c_size_t(), C.c_size_t()

@@ -629,6 +629,68 @@ int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
   return 0;
 }
 
+namespace {
+// validation_likelihood (src/linksampling.cc:966-1002) of a K-sharded state between two sweeps: the partial dot
+// products of the own columns, summed over the ranks, then the log terms on the host in pair order
+// (the order of the reference's map walk).  rowx[3p] holds the full row sum of gamma[p] after
+// svils_ksh_init_state and after every sweep.  Collective.
+int ksh_validation_row(svils_handle *h, double *row10) {
+  if (!h->have_graph) return fail(SVILS_ERR_ARG, "svils_validation_row: a K-sharded handle needs its graph and svils_ksh_init_state first");
+  if (!h->comm && h->geo.K != h->geo.Kt) return fail(SVILS_ERR_ARG, "svils_validation_row: call svils_comm_init first");
+  launch_ksh_phase(h->geo, h->d, h->prm, 8, h->stream);   // k_vdot_ksh alone
+  HIPCHK(hipGetLastError());
+  int rc = ksh_sum(h, SVILS_KSH_VDOT);
+  if (rc) return rc;
+  const DeviceState &d = h->d;
+  std::vector<double> vdot(d.nv), rowx(3 * (size_t)h->geo.n);
+  std::vector<uint32_t> vp(3 * (size_t)d.nv);
+  DevCtrl c;
+  HIPCHK(hipMemcpyAsync(vdot.data(), d.vdot, vdot.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(rowx.data(), d.rowx, rowx.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(vp.data(), d.vpairs, vp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double sz = 0.0, so = 0.0;
+  uint32_t kz = 0, ko = 0;
+  for (uint32_t i = 0; i < d.nv; ++i) {
+    const uint32_t p = vp[3 * (size_t)i], q = vp[3 * (size_t)i + 1], y = vp[3 * (size_t)i + 2];
+    const double pq = vdot[i] / (rowx[3 * (size_t)p] * rowx[3 * (size_t)q]);
+    double sv = y ? pq : 1.0 - pq;
+    if (sv < 1e-30) sv = 1e-30;
+    if (y) { so += log(sv); ko++; } else { sz += log(sv); kz++; }
+  }
+  const double mean0 = sz / kz, mean1 = so / ko;
+  row10[0] = (double)c.iter; row10[1] = (sz + so) / d.nv; row10[2] = (double)d.nv;
+  row10[3] = mean0; row10[4] = (double)kz; row10[5] = mean1; row10[6] = (double)ko;
+  row10[7] = h->prm.zeros_prob * mean0; row10[8] = h->prm.ones_prob * mean1; row10[9] = row10[7] + row10[8];
+  return 0;
+}
+}  // namespace
+
+int svils_comm_allgather_host(svils_handle *h, const void *send, void *recv, size_t bytes) {
+  if (!h || !send || !recv) return fail(SVILS_ERR_ARG, "svils_comm_allgather_host: null argument");
+  if (!h->comm) {
+    if (h->world != 1) return fail(SVILS_ERR_ARG, "svils_comm_allgather_host: call svils_comm_init first");
+    memcpy(recv, send, bytes);
+    return 0;
+  }
+  if (bytes == 0) return 0;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  unsigned char *tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, bytes * (size_t)h->world));
+  int rc = 0;
+  hipError_t e = hipMemcpyAsync(tmp + (size_t)h->rank * bytes, send, bytes, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    ncclResult_t r = g_rccl.AllGather(tmp + (size_t)h->rank * bytes, tmp, bytes, ncclUint8, h->comm, h->stream);
+    if (r != ncclSuccess) rc = fail(SVILS_ERR_DEVICE, "svils_comm_allgather_host: ncclAllGather: %s", g_rccl.GetErrorString(r));
+  }
+  if (!rc && e == hipSuccess) e = hipMemcpyAsync(recv, tmp, bytes * (size_t)h->world, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(tmp);
+  if (!rc && e != hipSuccess) rc = fail(SVILS_ERR_DEVICE, "svils_comm_allgather_host: %s", hipGetErrorString(e));
+  return rc;
+}
+
 int svils_gather_communities(svils_handle *h) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_gather_communities: null handle");
   if (!h->comm) return h->world == 1 ? 0 : fail(SVILS_ERR_ARG, "svils_gather_communities: call svils_comm_init first");
@@ -929,6 +991,7 @@ int svils_validation_row(svils_handle *h, double *row10) {
   if (!h->have_state) return fail(SVILS_ERR_ARG, "svils_validation_row: call svils_set_state first");
   if (h->d.nv == 0) return fail(SVILS_ERR_ARG, "svils_validation_row: no validation set");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->d.ksh) return ksh_validation_row(h, row10);
   launch_validation(h->geo, h->d, h->prm, h->stream);
   launch_row_only(h->geo, h->d, h->prm, h->row_scratch, h->stream);
   HIPCHK(hipGetLastError());

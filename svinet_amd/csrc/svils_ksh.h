@@ -861,6 +861,14 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
       KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
+    case 8: {   // the partial dot products alone (svils_validation_row between two sweeps)
+      if (d.nv) {
+        const uint32_t nb = (d.nv + 3) / 4 > 1024 ? 1024 : (d.nv + 3) / 4;
+#define CALL(V_) hipLaunchKernelGGL((k_vdot_ksh<V_>), dim3(nb), dim3(256), 0, s, g, d)
+        KSH_DISPATCH(g, CALL);
+#undef CALL
+      }
+    } break;
     default: break;
   }
 }

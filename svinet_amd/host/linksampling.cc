@@ -162,7 +162,13 @@ void LinkSampling::attach() {
   cfg.zeros_prob = zeros_prob_;
   cfg.device = env_.device;
   cfg.sparse_after_iter = env_.sparse_after;
-  if (env_.gpus > 1) {   // -gpus N: this process owns the node block of its rank
+  if (env_.kshard) {     // -gpus N -kshard: this process owns the columns [k0_, k1_) of every row
+    k0_ = (uint32_t)((uint64_t)k_ * (uint32_t)env_.rank / (uint32_t)env_.gpus);
+    k1_ = (uint32_t)((uint64_t)k_ * ((uint32_t)env_.rank + 1) / (uint32_t)env_.gpus);
+    cfg.k = k1_ - k0_;
+    cfg.k_begin = k0_;
+    cfg.k_total = k_;
+  } else if (env_.gpus > 1) {   // -gpus N: this process owns the node block of its rank
     const uint32_t B = (n_ + (uint32_t)env_.gpus - 1) / (uint32_t)env_.gpus;
     cfg.node_begin = std::min(n_, (uint32_t)env_.rank * B);
     cfg.node_end = std::min(n_, ((uint32_t)env_.rank + 1) * B);
@@ -201,6 +207,7 @@ void LinkSampling::attach() {
     sc.tau0 = env_.tau0; sc.kappa = env_.kappa; sc.node_tau0 = env_.nodetau0; sc.node_kappa = env_.nodekappa;
     if (svils_set_stochastic(h_, &sc)) die_svils("svils_set_stochastic");
   }
+  if (env_.kshard) send_graph();   // the K-sharded initial state needs the link list (row sums cross ranks)
   // with -accuracy validation_likelihood() returns at once (:969-970)
   if (!env_.accuracy && !val_sorted_.empty()) {
     std::vector<uint32_t> v(val_sorted_);
@@ -208,7 +215,14 @@ void LinkSampling::attach() {
       for (size_t i = 0; i < v.size(); i += 3) { v[i] = dev_of_[v[i]]; v[i + 1] = dev_of_[v[i + 1]]; }
     if (svils_set_validation(h_, v.data(), v.size() / 3)) die_svils("svils_set_validation");
   }
-  if (dev_of_.empty()) {
+  if (env_.kshard) {
+    const uint32_t w = k1_ - k0_;
+    std::vector<double> g((size_t)n_ * w);
+    for (uint32_t i = 0; i < n_; ++i)
+      std::copy(&gamma_[(size_t)i * k_ + k0_], &gamma_[(size_t)i * k_ + k0_] + w, &g[(size_t)i * w]);
+    if (svils_set_state(h_, g.data(), &lambda_[2 * (size_t)k0_], nullptr)) die_svils("svils_set_state");
+    if (svils_ksh_init_state(h_)) die_svils("svils_ksh_init_state");
+  } else if (dev_of_.empty()) {
     if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
   } else {
     std::vector<double> g((size_t)n_ * k_);
@@ -434,7 +448,8 @@ void LinkSampling::write_max(const double *r, int why, double max_h) const {   /
 
 void LinkSampling::save_model() {                          // src/linksampling.cc:804-837
   std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
-  if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
+  if (env_.kshard) fetch_state_ksharded(g, l);
+  else if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
   if (!dev_of_.empty()) {   // back to sequence-id order
     std::vector<double> t((size_t)n_ * k_);
     for (uint32_t i = 0; i < n_; ++i)
@@ -457,6 +472,44 @@ void LinkSampling::save_model() {                          // src/linksampling.c
   lambda_.swap(l);
 }
 
+// -kshard: every rank holds the columns [k0_, k1_); the slices are padded to the widest one, gathered
+// (svils_comm_allgather_host) and put back side by side.  Collective: every rank calls it.
+void LinkSampling::fetch_state_ksharded(std::vector<double> &g, std::vector<double> &l) {
+  const uint32_t G = (uint32_t)env_.gpus, w = k1_ - k0_, wmax = (k_ + G - 1) / G;
+  std::vector<double> mine((size_t)n_ * w + 2 * (size_t)w), send(((size_t)n_ + 2) * wmax, 0.0);
+  if (svils_get_state(h_, mine.data(), mine.data() + (size_t)n_ * w, nullptr)) die_svils("svils_get_state");
+  for (uint32_t i = 0; i < n_; ++i) std::copy(&mine[(size_t)i * w], &mine[(size_t)i * w] + w, &send[(size_t)i * wmax]);
+  for (uint32_t c = 0; c < w; ++c) {   // lambda as two rows of wmax behind the gamma rows
+    send[(size_t)n_ * wmax + c] = mine[(size_t)n_ * w + 2 * c];
+    send[((size_t)n_ + 1) * wmax + c] = mine[(size_t)n_ * w + 2 * c + 1];
+  }
+  std::vector<double> all(send.size() * G);
+  if (svils_comm_allgather_host(h_, send.data(), all.data(), send.size() * sizeof(double))) die_svils("svils_comm_allgather_host");
+  for (uint32_t r = 0; r < G; ++r) {
+    const uint32_t a = (uint32_t)((uint64_t)k_ * r / G), b = (uint32_t)((uint64_t)k_ * (r + 1) / G);
+    const double *src = &all[(size_t)r * send.size()];
+    for (uint32_t i = 0; i < n_; ++i) std::copy(src + (size_t)i * wmax, src + (size_t)i * wmax + (b - a), &g[(size_t)i * k_ + a]);
+    for (uint32_t c = a; c < b; ++c) {
+      l[2 * (size_t)c] = src[(size_t)n_ * wmax + (c - a)];
+      l[2 * (size_t)c + 1] = src[((size_t)n_ + 1) * wmax + (c - a)];
+    }
+  }
+}
+
+void LinkSampling::fetch_communities_ksharded() {
+  const uint32_t G = (uint32_t)env_.gpus, w = k1_ - k0_, wmax = (k_ + G - 1) / G;
+  std::vector<uint8_t> mine((size_t)n_ * w), send((size_t)n_ * wmax, 0), all((size_t)n_ * wmax * G);
+  if (svils_get_communities(h_, mine.data())) die_svils("svils_get_communities");
+  for (uint32_t i = 0; i < n_; ++i) std::copy(&mine[(size_t)i * w], &mine[(size_t)i * w] + w, &send[(size_t)i * wmax]);
+  if (svils_comm_allgather_host(h_, send.data(), all.data(), send.size())) die_svils("svils_comm_allgather_host");
+  member_.assign((size_t)n_ * k_, 0);
+  for (uint32_t r = 0; r < G; ++r) {
+    const uint32_t a = (uint32_t)((uint64_t)k_ * r / G), b = (uint32_t)((uint64_t)k_ * (r + 1) / G);
+    const uint8_t *src = &all[(size_t)r * send.size()];
+    for (uint32_t i = 0; i < n_; ++i) std::copy(src + (size_t)i * wmax, src + (size_t)i * wmax + (b - a), &member_[(size_t)i * k_ + a]);
+  }
+}
+
 void LinkSampling::write_groups() {                        // src/linksampling.cc:1452-1476
   FILE *f = open_or_die(Env::file_str("/groups.txt"), "groups");
   const std::vector<uint32_t> &s2i = network_.seq2id();
@@ -471,8 +524,10 @@ void LinkSampling::write_groups() {                        // src/linksampling.c
 }
 
 void LinkSampling::log_communities() {                     // :839-852, :882-917
-  member_.assign((size_t)n_ * k_, 0);
-  if (svils_get_communities(h_, member_.data())) die_svils("svils_get_communities");
+  if (!env_.kshard) {   // -kshard: fetch_communities_ksharded() has filled member_ on every rank
+    member_.assign((size_t)n_ * k_, 0);
+    if (svils_get_communities(h_, member_.data())) die_svils("svils_get_communities");
+  }
   if (!dev_of_.empty()) {
     std::vector<uint8_t> t((size_t)n_ * k_);
     for (uint32_t i = 0; i < n_; ++i)
@@ -506,7 +561,14 @@ void LinkSampling::log_communities() {                     // :839-852, :882-917
 
 void LinkSampling::do_on_stop() {                          // src/linksampling.cc:792-802
   // -gpus N: every rank takes part in the gather of the community bitmasks, rank 0 writes
-  if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
+  if (env_.kshard) {
+    fetch_communities_ksharded();
+    if (!env_.write_files) {   // the other ranks take part in the gather of the model, rank 0 writes it
+      std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
+      fetch_state_ksharded(g, l);
+      return;
+    }
+  } else if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
   if (!env_.write_files) return;
   log_communities();
   save_model();
@@ -539,6 +601,11 @@ int LinkSampling::infer() {
     fprintf(stderr, "error: LinkSampling::infer() without a device (attach_device=false)\n");
     exit(-1);
   }
+  send_graph();
+  return sweep_loop();
+}
+
+void LinkSampling::send_graph() {
   if (!graph_sent_) {
     const std::vector<uint32_t> &L = training_links();
     if (dev_of_.empty()) {
@@ -557,6 +624,9 @@ int LinkSampling::infer() {
     }
     graph_sent_ = true;
   }
+}
+
+int LinkSampling::sweep_loop() {
   const uint64_t nlinks = links_.size() / 2;
   svils_control c;
   if (svils_get_control(h_, &c)) die_svils("svils_get_control");
@@ -578,6 +648,8 @@ int LinkSampling::infer() {
     fflush(stdout);
     if (env_.minibatch) {
       if (svils_step(h_, batch)) die_svils("svils_step");
+    } else if (env_.kshard) {
+      if (svils_sweep_ksharded(h_, batch)) die_svils("svils_sweep_ksharded");
     } else if (env_.gpus > 1) {
       if (svils_sweep_sharded(h_, batch)) die_svils("svils_sweep_sharded");
     } else if (svils_sweep(h_, batch)) {
@@ -586,7 +658,8 @@ int LinkSampling::infer() {
     fetch_and_log_rows();
     if (svils_get_control(h_, &c)) die_svils("svils_get_control");
     if (!c.stopped) {                                             // :785 (the control block is replicated: same branch on every rank)
-      if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
+      if (env_.kshard) fetch_communities_ksharded();
+      else if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
       if (env_.write_files) log_communities();
     }
     if (c.stopped) {                                              // :1044-1048

@@ -67,6 +67,10 @@ class LinkSampling {
   void write_validation_row(const double *row, FILE *f) const;
   void write_max(const double *row, int why, double max_h) const;
   void log_communities();
+  void send_graph();                           // training links to the device (once)
+  int sweep_loop();                            // the body of infer()
+  void fetch_state_ksharded(std::vector<double> &g, std::vector<double> &l);   // -kshard: merged gamma / lambda (collective)
+  void fetch_communities_ksharded();           // -kshard: merged member_ (collective)
   void write_groups();
   uint32_t duration() const { return (uint32_t)(time(0) - start_time_); }
   void fetch_and_log_rows();
@@ -81,6 +85,7 @@ class LinkSampling {
   std::vector<double> gamma_, lambda_;
   std::vector<uint32_t> links_;
   bool links_done_ = false;
+  uint32_t k0_ = 0, k1_ = 0;                   // -kshard: this rank's columns
   std::vector<uint8_t> member_;                // last downloaded communities [n][k]
   // mini-batch mode: nodes are handed to the device under a random relabelling so that a window of
   // consecutive device ids is a uniform random subset; dev_of_[seq] / seq_of_[dev], empty otherwise

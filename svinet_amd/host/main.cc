@@ -59,6 +59,9 @@ static void usage() {
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
           "\t-gpus <N>\t-link-sampling over N GPUs of this node: one process per GPU (devices d .. d+N-1), node-block\n"
           "\t\t\tsharding, RCCL all-reduce / all-gather over xGMI between the phases of a sweep\n\n"
+          "\t-kshard\t\twith -gpus N: shard the K communities over the N GPUs (every GPU holds K/N columns of all rows;\n"
+          "\t\t\tper sweep four all-reduces of O(links) doubles instead of an all-gather of the rows) -- the\n"
+          "\t\t\tlayout for large K; needs -link-thresh >= 0.5 (the default)\n\n"
           "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
           "\t-sparse-after <i>\tthe active-set branch of the phi pass is used once the iteration count exceeds i\n"
           "\t\t\t(default 1000, the reference's constant)\n\n"
@@ -111,6 +114,7 @@ int main(int argc, char **argv) {
     else if (is("-strid")) { a.strid = true; }
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
     else if (is("-gpus")) { need(i); a.gpus = atoi(argv[++i]); }
+    else if (is("-kshard")) { a.kshard = true; }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
     else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
     else if (is("-sparse-after")) { need(i); a.sparse_after = atoi(argv[++i]); }
@@ -140,6 +144,10 @@ int main(int argc, char **argv) {
             unsupported ? "; unsupported option " : "", unsupported ? unsupported_flag.c_str() : "");
     return 2;
   }
+  if (a.kshard && (a.minibatch || !a.link_sampling)) {
+    fprintf(stderr, "error: -kshard belongs to full-sweep -link-sampling runs\n");
+    return -1;
+  }
   if (a.n == 0 || a.k == 0) {
     fprintf(stderr, "error: -n and -k are required\n");
     return -1;
@@ -151,6 +159,10 @@ int main(int argc, char **argv) {
   if (a.link_sampling && a.gpus > 1) {
     if (a.minibatch) {
       fprintf(stderr, "error: -gpus with -minibatch is not available from the command line\n");
+      return -1;
+    }
+    if (a.kshard && (uint32_t)a.gpus > a.k) {
+      fprintf(stderr, "error: -kshard needs at least one community per GPU\n");
       return -1;
     }
     char tmpl[] = "/tmp/svinet-comm-XXXXXX";

@@ -165,3 +165,34 @@ def test_cli_nmi(graph_files, tmp_path):
     assert all(l.startswith("mutual3:\t") for l in lines) and len(lines) == rows.shape[0] - 1   # row 0 is the constructor's
     vals = np.array([float(l.split("\t")[1]) for l in lines])
     assert vals[0] < 0.2 and vals[-1] > 0.8
+
+
+def test_cli_kshard_world_of_one(graph_files, tmp_path):
+    """`svinet -gpus 1 -kshard`: the K-sharded driver of the command line (slice hand-over, svils_ksh_init_state,
+    the collective constructor row, svils_sweep_ksharded, the gathers behind communities.txt / gamma.txt /
+    lambda.txt) with a world of one -- every file against the oracle's, as for the plain run."""
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop",
+              "-max-iterations", "20", "-gpus", "1", "-kshard"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False, max_iterations=20)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    _cmp_numeric(d / "groups.txt", rd / "groups.txt", 2, 1.1e-3)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    v = np.loadtxt(d / "validation.txt")
+    assert v.shape == (22, 11)                       # constructor row + one per sweep
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+
+
+def test_cli_kshard_refuses_what_it_cannot_do(graph_files, tmp_path):
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-kshard", "-minibatch", "64"],
+             str(tmp_path))
+    assert r.returncode != 0 and "-kshard" in r.stderr
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-gpus", "1", "-kshard",
+              "-link-thresh", "0.3", "-max-iterations", "2"], str(tmp_path))
+    assert r.returncode != 0 and "link_thresh" in r.stderr

@@ -87,9 +87,15 @@ def test_native_ksharded_driver_world1(graph_files, log_domain):
     eng.ksh_log_domain(log_domain)
     eng.comm_init(_svils.comm_unique_id(), 0, 1)
     eng.ksh_init_state()
-    eng.sweep_ksharded(8)
     plain = setup.engine(use_validation_stop=False)
+    # the constructor's validation_likelihood row (src/linksampling.cc:149-150) of a K-sharded state: collective
+    np.testing.assert_allclose(eng.validation_row(), plain.validation_row(), rtol=1e-12, atol=0)
+    eng.sweep_ksharded(8)
     plain.sweep(8)
+    np.testing.assert_allclose(eng.validation_row(), plain.validation_row(), rtol=1e-11, atol=0)   # between two sweeps
+    # svils_comm_allgather_host through the one-rank communicator (device staging + ncclAllGather)
+    blob = np.arange(12345, dtype=np.float64)
+    assert np.array_equal(eng.allgather_host(blob, 1)[0], blob)
     g1, l1, c1 = eng.state()
     g2, l2, c2 = plain.state()
     assert np.max(np.abs(g1 - g2) / g2) < 1e-12 and np.max(np.abs(l1 - l2) / np.abs(l2)) < 1e-12
