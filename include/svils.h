@@ -268,6 +268,9 @@ int svils_stream(svils_handle *h, void **stream);
  * issues the exchanges itself, on the handle's stream, between the phases of a sweep:
  *   phi pass -> all-reduce(sum) -> finalise -> all-gather(gamma rows, packed flags) -> expand ->
  *   s3 pass -> all-reduce(s1,s2,s3) -> tail (replicated).
+ * Once the annealing flag is off (it is replicated, only goes 1 -> 0 inside a run, and is read when a call
+ * starts and every 16 sweeps until then) sum[k] has one reader left, lambda[k][0] in the tail: its all-reduce
+ * is grouped with the one of s1,s2,s3 -- two exchange points per sweep instead of three.
  * librccl is loaded at run time (dlopen) the first time one of these entry points is used. */
 #define SVILS_COMM_ID_BYTES 128
 /* rank 0: a fresh ncclUniqueId to hand to every rank (any transport: pipe, file, MPI, torch store) */

@@ -506,6 +506,15 @@ int exchange_sum(svils_handle *h, double *v, size_t count) {
   NCCLCHK(g_rccl.AllReduce(v, v, count, ncclDouble, ncclSum, h->comm, h->stream));
   return 0;
 }
+int exchange_sum2(svils_handle *h, double *a, size_t na, double *b, size_t nb) {   // one grouped launch
+  if (!h->comm) return 0;
+  Timed t(h, SVILS_KERNEL_EXCHANGE);
+  NCCLCHK(g_rccl.GroupStart());
+  NCCLCHK(g_rccl.AllReduce(a, a, na, ncclDouble, ncclSum, h->comm, h->stream));
+  NCCLCHK(g_rccl.AllReduce(b, b, nb, ncclDouble, ncclSum, h->comm, h->stream));
+  NCCLCHK(g_rccl.GroupEnd());
+  return 0;
+}
 int exchange_rows(svils_handle *h) {
   if (!h->comm) return 0;
   Timed t(h, SVILS_KERNEL_EXCHANGE);
@@ -533,15 +542,33 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
                 (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
   HIPCHK(hipSetDevice(h->cfg.device));
   const Geometry &g = h->geo;
+  // `sum[k]` is needed between the phi pass and the finalise pass only while annealing (the ones/sum[k]
+  // scale, src/linksampling.cc:542); afterwards its only reader is lambda[k][0] in the tail, so its
+  // all-reduce rides with the one of s1,s2,s3: two collectives' latencies per sweep instead of three.
+  // The flag is replicated in every rank's control block and only ever goes from 1 to 0 inside a run, so
+  // every rank takes the same form; it is looked at (one stream synchronisation) when a call starts and
+  // every 16 sweeps until it is off.
+  bool annealing = true;
   for (uint32_t i = 0; i < nsweeps; ++i) {
     int rc;
+    if (annealing && (i & 15u) == 0u) {
+      DevCtrl c;
+      HIPCHK(hipMemcpyAsync(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (c.fault) return fault_error(c.fault);
+      annealing = c.annealing != 0;
+    }
     if ((rc = run_phase(h, SVILS_PHASE_A, false))) return rc;
-    if ((rc = exchange_sum(h, h->d.kvec_a, g.K))) return rc;
+    if (annealing && (rc = exchange_sum(h, h->d.kvec_a, g.K))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_B, false))) return rc;
     if ((rc = exchange_rows(h))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_EXPAND, false))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
-    if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
+    if (annealing) {
+      if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
+    } else if ((rc = exchange_sum2(h, h->d.kvec_a, g.K, h->d.kvec_c, 3 * (size_t)g.K))) {
+      return rc;
+    }
     if ((rc = run_phase(h, SVILS_PHASE_D, false))) return rc;
   }
   return 0;

@@ -92,6 +92,9 @@ class HipShard:
     def phase(self, ph):
         self.engine.sweep_phase(ph)
 
+    def annealing(self):
+        return self.engine.control().annealing != 0   # synchronises the engine's stream
+
     def gather_list(self):
         return self.rows + [self.xflags]
 
@@ -127,17 +130,33 @@ class ShardedSweep:
             return contextlib.nullcontext()
         return self.s.torch.cuda.stream(st)
 
+    def _annealing(self):
+        """the replicated annealing flag (a shard without one is treated as always annealing)"""
+        f = getattr(self.s, "annealing", None)
+        return True if f is None else bool(f() if callable(f) else f)
+
     def sweep(self, nsweeps=1):
+        """`sum[k]` is read between the phi pass and the finalise pass only while annealing (the ones/sum[k]
+        scale, src/linksampling.cc:542); afterwards its one reader is lambda[k][0] in the tail, so its
+        all-reduce moves next to the one of s1,s2,s3 (as svils_sweep_sharded does: one exchange point fewer per
+        sweep).  The flag only goes from 1 to 0 inside a run and is the same on every rank; it is looked at
+        when a call starts and every 16 sweeps until it is off."""
         s = self.s
+        annealing = True
         with self._ctx():
-            for _ in range(nsweeps):
+            for i in range(nsweeps):
+                if annealing and i % 16 == 0:
+                    annealing = self._annealing()
                 s.phase(_svils.PHASE_A)
-                self._allreduce(s.kvec_a)
+                if annealing:
+                    self._allreduce(s.kvec_a)
                 s.phase(_svils.PHASE_B)
                 for t in s.gather_list():
                     self._allgather_rows(t)
                 s.phase(_svils.PHASE_EXPAND)
                 s.phase(_svils.PHASE_C)
+                if not annealing:
+                    self._allreduce(s.kvec_a)
                 self._allreduce(s.kvec_c)
                 s.phase(_svils.PHASE_D)
                 s.end_sweep()
