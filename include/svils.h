@@ -279,6 +279,11 @@ int svils_comm_unique_id(void *id128);
 int svils_comm_init(svils_handle *h, const void *id128, int rank, int world);
 /* Enqueue `nsweeps` sharded sweeps (asynchronous, like svils_sweep).  Collective. */
 int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps);
+/* Mini-batch steps (svils_set_stochastic with shard_block = B) over the node-block shards, the exchanges issued
+ * here: per step all-reduce(sum) -> broadcasts of every rank's window rows (gamma, mphi, packed flags: world x
+ * batch_nodes rows, not n) -> expand -> all-reduce(s1,s2,s3) -- "the K-vector lambda and touched gamma rows at
+ * the global step".  svils_comm_init may come before or after svils_set_stochastic.  Collective, asynchronous. */
+int svils_step_sharded(svils_handle *h, uint32_t nsteps);
 /* all-gather of the community bitmasks before svils_get_communities on a sharded handle.  Collective. */
 int svils_gather_communities(svils_handle *h);
 

@@ -28,7 +28,7 @@ EXPORTS = (
     "svils_get_sweep_stats", "svils_get_timed_links",
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
     "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
-    "svils_comm_allgather_host",
+    "svils_comm_allgather_host", "svils_step_sharded",
 )
 
 
@@ -120,6 +120,7 @@ def load():
     L.svils_sweep_sharded.argtypes = [vp, C.c_uint32]
     L.svils_gather_communities.argtypes = [vp]
     L.svils_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t]
+    L.svils_step_sharded.argtypes = [vp, C.c_uint32]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -346,6 +347,9 @@ class Engine:
 
     def gather_communities(self):
         _chk(load().svils_gather_communities(self._h))
+
+    def step_sharded(self, nsteps=1):
+        _chk(load().svils_step_sharded(self._h, nsteps))
 
     def allgather_host(self, send, world):
         """every rank's `send` (equal byte counts), rank by rank: array of shape (world,) + send.shape.  Collective."""

@@ -429,6 +429,7 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -445,7 +446,7 @@ int rccl_load() {
     *(void **)(&g_rccl.F) = dlsym(lib, "nccl" #F);                                     \
     if (!g_rccl.F) return fail(SVILS_ERR_UNSUPPORTED, "librccl lacks nccl" #F);        \
   } while (0)
-  BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather);
+  BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather); BIND(Broadcast);
   BIND(GroupStart); BIND(GroupEnd); BIND(GetErrorString);
 #undef BIND
   g_rccl.lib = lib;
@@ -485,7 +486,6 @@ int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
     return fail(SVILS_ERR_ARG, "svils_comm_init: rank %d of %d needs node block [%u,%u) and n_alloc %u (handle has [%u,%u), %u)",
                 rank, world, std::min(g.n, (uint32_t)rank * B), std::min(g.n, ((uint32_t)rank + 1) * B), B * world,
                 g.node_begin, g.node_end, g.n_alloc);
-  if (h->stoch) return fail(SVILS_ERR_UNSUPPORTED, "svils_comm_init: mini-batch steps are exchanged by the caller (svils_step_phase)");
   int rc = rccl_load();
   if (rc) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -570,6 +570,58 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
       return rc;
     }
     if ((rc = run_phase(h, SVILS_PHASE_D, false))) return rc;
+  }
+  return 0;
+}
+
+namespace {
+int step_phase_impl(svils_handle *h, svils_phase phase, bool fused);
+
+// the rows every rank touched in this step: the window [b, e) of every rank's block, for gamma, mphi and the
+// packed flags -- one grouped launch of world broadcasts per array (rank r is the root of its own window)
+int exchange_windows(svils_handle *h, uint32_t b, uint32_t e) {
+  if (!h->comm || e <= b) return 0;
+  Timed t(h, SVILS_KERNEL_EXCHANGE);
+  const Geometry &g = h->geo;
+  const DeviceState &d = h->d;
+  const size_t B = g.n_alloc / (size_t)h->world, rows = e - b;
+  NCCLCHK(g_rccl.GroupStart());
+  for (int r = 0; r < h->world; ++r) {
+    const size_t row0 = (size_t)r * B + b;
+    double *gp = d.gamma + row0 * g.ld, *mp = d.mphi + row0 * g.ld;
+    uint32_t *xp = d.xflags + row0 * d.xf_ld;
+    NCCLCHK(g_rccl.Broadcast(gp, gp, rows * g.ld, ncclDouble, r, h->comm, h->stream));
+    NCCLCHK(g_rccl.Broadcast(mp, mp, rows * g.ld, ncclDouble, r, h->comm, h->stream));
+    NCCLCHK(g_rccl.Broadcast(xp, xp, rows * d.xf_ld, ncclUint32, r, h->comm, h->stream));
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  return 0;
+}
+}  // namespace
+
+// Mini-batch (Robbins-Monro) steps over node-block shards with the exchanges issued here: the global step of
+// the north_star -- all-reduce of the K-vectors, the touched gamma (and mphi, flag) rows of every rank's window.
+int svils_step_sharded(svils_handle *h, uint32_t nsteps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_step_sharded: null handle");
+  if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_sharded: call svils_set_stochastic first");
+  if (!h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step_sharded: svils_set_stochastic needs shard_block (the node-block size)");
+  if (!h->comm && h->geo.n_alloc != h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step_sharded: call svils_comm_init first");
+  if (h->comm && (size_t)h->geo.n_alloc / (size_t)h->world != h->scfg.shard_block)
+    return fail(SVILS_ERR_ARG, "svils_step_sharded: shard_block %u is not the communicator's node-block size", h->scfg.shard_block);
+  if (nsteps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
+    return fail(SVILS_ERR_ARG, "svils_step_sharded: at most %llu steps per call",
+                (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
+  const Geometry &g = h->geo;
+  for (uint32_t s = 0; s < nsteps; ++s) {
+    int rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_A, false))) return rc;
+    if ((rc = exchange_sum(h, h->d.kvec_a, g.K))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_B, false))) return rc;
+    if ((rc = exchange_windows(h, h->sw_begin, h->sw_end))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_EXPAND, false))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_C, false))) return rc;
+    if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
+    if ((rc = step_phase_impl(h, SVILS_PHASE_D, false))) return rc;
   }
   return 0;
 }

@@ -48,6 +48,7 @@ class Env {
     // -gpus N: one process per GPU (forked by main), node-block sharding with RCCL exchanges inside
     // the device library (svils_sweep_sharded); rank 0 writes the files
     int gpus = 1, rank = 0;
+    bool sharded = false;       // node-block sharding: set by -gpus N > 1, or by -sharded with one GPU (a communicator of one rank: the same code path)
     bool kshard = false;        // -kshard: shard the K columns over the ranks instead of the nodes
     std::string comm_file;      // where rank 0 leaves the ncclUniqueId for the others
   };
@@ -79,7 +80,7 @@ class Env {
   std::string ground_truth_fname;
   std::string datfname, label;
   int gpus, rank;
-  bool kshard;
+  bool kshard, sharded;
   std::string comm_file;
   bool batch_mode, link_sampling;
   bool strid;

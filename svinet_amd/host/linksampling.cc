@@ -168,18 +168,20 @@ void LinkSampling::attach() {
     cfg.k = k1_ - k0_;
     cfg.k_begin = k0_;
     cfg.k_total = k_;
-  } else if (env_.gpus > 1) {   // -gpus N: this process owns the node block of its rank
+  } else if (env_.sharded) {   // -gpus N: this process owns the node block of its rank
     const uint32_t B = (n_ + (uint32_t)env_.gpus - 1) / (uint32_t)env_.gpus;
     cfg.node_begin = std::min(n_, (uint32_t)env_.rank * B);
     cfg.node_end = std::min(n_, ((uint32_t)env_.rank + 1) * B);
     cfg.n_alloc = B * (uint32_t)env_.gpus;
   }
   if (svils_create(&cfg, &h_)) die_svils("svils_create");
-  if (env_.gpus > 1) {
+  if (env_.gpus > 1 || env_.sharded) {
     // rank 0 makes the ncclUniqueId and leaves it in comm_file (written aside, then renamed: readers
     // never see a partial file); the other ranks wait for it.  Then the collective communicator init.
     unsigned char id[SVILS_COMM_ID_BYTES];
-    if (env_.rank == 0) {
+    if (env_.gpus == 1) {   // -sharded with one GPU: a communicator of one rank, nobody to tell
+      if (svils_comm_unique_id(id)) die_svils("svils_comm_unique_id");
+    } else if (env_.rank == 0) {
       if (svils_comm_unique_id(id)) die_svils("svils_comm_unique_id");
       const std::string tmp = env_.comm_file + ".tmp";
       FILE *f = fopen(tmp.c_str(), "wb");
@@ -205,6 +207,7 @@ void LinkSampling::attach() {
     svils_stochastic sc;
     svils_stochastic_default(&sc, env_.minibatch);
     sc.tau0 = env_.tau0; sc.kappa = env_.kappa; sc.node_tau0 = env_.nodetau0; sc.node_kappa = env_.nodekappa;
+    if (env_.sharded) sc.shard_block = (n_ + (uint32_t)env_.gpus - 1) / (uint32_t)env_.gpus;   // every rank steps through its own block
     if (svils_set_stochastic(h_, &sc)) die_svils("svils_set_stochastic");
   }
   if (env_.kshard) send_graph();   // the K-sharded initial state needs the link list (row sums cross ranks)
@@ -568,7 +571,7 @@ void LinkSampling::do_on_stop() {                          // src/linksampling.c
       fetch_state_ksharded(g, l);
       return;
     }
-  } else if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
+  } else if (env_.sharded && svils_gather_communities(h_)) die_svils("svils_gather_communities");
   if (!env_.write_files) return;
   log_communities();
   save_model();
@@ -646,11 +649,13 @@ int LinkSampling::sweep_loop() {
     if (env_.max_iterations) batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - c.iter);
     printf("\riteration %d: processing %d links", c.iter, (int)nlinks);
     fflush(stdout);
-    if (env_.minibatch) {
+    if (env_.minibatch && env_.sharded) {
+      if (svils_step_sharded(h_, batch)) die_svils("svils_step_sharded");
+    } else if (env_.minibatch) {
       if (svils_step(h_, batch)) die_svils("svils_step");
     } else if (env_.kshard) {
       if (svils_sweep_ksharded(h_, batch)) die_svils("svils_sweep_ksharded");
-    } else if (env_.gpus > 1) {
+    } else if (env_.sharded) {
       if (svils_sweep_sharded(h_, batch)) die_svils("svils_sweep_sharded");
     } else if (svils_sweep(h_, batch)) {
       die_svils("svils_sweep");
@@ -659,7 +664,7 @@ int LinkSampling::sweep_loop() {
     if (svils_get_control(h_, &c)) die_svils("svils_get_control");
     if (!c.stopped) {                                             // :785 (the control block is replicated: same branch on every rank)
       if (env_.kshard) fetch_communities_ksharded();
-      else if (env_.gpus > 1 && svils_gather_communities(h_)) die_svils("svils_gather_communities");
+      else if (env_.sharded && svils_gather_communities(h_)) die_svils("svils_gather_communities");
       if (env_.write_files) log_communities();
     }
     if (c.stopped) {                                              // :1044-1048

@@ -59,6 +59,9 @@ static void usage() {
           "\t-device <d>\tHIP device ordinal (default 0)\n\n"
           "\t-gpus <N>\t-link-sampling over N GPUs of this node: one process per GPU (devices d .. d+N-1), node-block\n"
           "\t\t\tsharding, RCCL all-reduce / all-gather over xGMI between the phases of a sweep\n\n"
+          "\t\t\twith -minibatch <m>: every GPU steps through windows of m nodes of its own block; per step an all-reduce\n"
+          "\t\t\tof the K-vectors and broadcasts of the touched gamma rows (svils_step_sharded)\n\n"
+          "\t-sharded\ttake the -gpus N code path with one GPU as well (a communicator of one rank)\n\n"
           "\t-kshard\t\twith -gpus N: shard the K communities over the N GPUs (every GPU holds K/N columns of all rows;\n"
           "\t\t\tper sweep four all-reduces of O(links) doubles instead of an all-gather of the rows) -- the\n"
           "\t\t\tlayout for large K; needs -link-thresh >= 0.5 (the default)\n\n"
@@ -115,6 +118,7 @@ int main(int argc, char **argv) {
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
     else if (is("-gpus")) { need(i); a.gpus = atoi(argv[++i]); }
     else if (is("-kshard")) { a.kshard = true; }
+    else if (is("-sharded")) { a.sharded = true; }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
     else if (is("-outdir")) { need(i); a.outdir_root = argv[++i]; }
     else if (is("-sparse-after")) { need(i); a.sparse_after = atoi(argv[++i]); }
@@ -157,10 +161,6 @@ int main(int argc, char **argv) {
   // graph and runs the (seeded, deterministic) host-side initialisation itself; rank 0 owns the output
   // directory and the files, the others compute their node block only.
   if (a.link_sampling && a.gpus > 1) {
-    if (a.minibatch) {
-      fprintf(stderr, "error: -gpus with -minibatch is not available from the command line\n");
-      return -1;
-    }
     if (a.kshard && (uint32_t)a.gpus > a.k) {
       fprintf(stderr, "error: -kshard needs at least one community per GPU\n");
       return -1;

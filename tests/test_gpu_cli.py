@@ -196,3 +196,40 @@ def test_cli_kshard_refuses_what_it_cannot_do(graph_files, tmp_path):
     r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-gpus", "1", "-kshard",
               "-link-thresh", "0.3", "-max-iterations", "2"], str(tmp_path))
     assert r.returncode != 0 and "link_thresh" in r.stderr
+
+
+def test_cli_sharded_code_path_world_of_one(graph_files, tmp_path):
+    """`svinet -sharded`: the -gpus N driver of the command line (node-block handle, communicator, svils_sweep_sharded,
+    svils_gather_communities) with one GPU -- the files against the oracle's, as for the plain run."""
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop",
+              "-max-iterations", "40", "-sharded", "-sweep-batch", "7"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False, max_iterations=40)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    v = np.loadtxt(d / "validation.txt")
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+
+
+def test_cli_sharded_minibatch_world_of_one(graph_files, tmp_path):
+    """`svinet -sharded -minibatch m`: svils_step_sharded behind the command line; the same files as the plain
+    mini-batch run (gamma.txt / lambda.txt to the printed digits, the same communities)."""
+    args = ["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-rfreq", "5", "-no-stop",
+            "-max-iterations", "99", "-minibatch", "200", "-tau0", "1", "-kappa", "0.5", "-nodetau0", "1",
+            "-nodekappa", "0.5", "-sweep-batch", "5"]
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = _run(args, str(tmp_path / "a"))
+    rb = _run(args + ["-sharded"], str(tmp_path / "b"))
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    da, db = tmp_path / "a" / "n1000-k28-mmsb-linksampling", tmp_path / "b" / "n1000-k28-mmsb-linksampling"
+    _cmp_numeric(da / "gamma.txt", db / "gamma.txt", 2, 2.1e-5)
+    _cmp_numeric(da / "lambda.txt", db / "lambda.txt", 1, 2.1e-5)
+    assert (da / "communities.txt").read_text() == (db / "communities.txt").read_text()
+    va, vb = np.loadtxt(da / "validation.txt"), np.loadtxt(db / "validation.txt")
+    np.testing.assert_allclose(np.delete(va, 1, axis=1), np.delete(vb, 1, axis=1), rtol=0, atol=2e-9)

@@ -236,3 +236,31 @@ def test_sharded_minibatch_windows(graph_files, tmp_path):
     np.testing.assert_allclose(a["mphi"].sum(1), 0.5, rtol=1e-9)
     assert int(a["iter"]) == 90 and a["rows"].shape[0] == 90
     assert a["rows"][-1, 9] > a["rows"][0, 9]
+
+
+@pytest.mark.parametrize("k", [28, 64])
+def test_native_step_sharded_world1(graph_files, k):
+    """svils_step_sharded (mini-batch steps with the exchanges inside the library: K-vector all-reduces and the
+    broadcasts of every rank's window rows) with a communicator of ONE rank: equals svils_step on a plain handle
+    (phase-split vs fused launches: summation order only), and the collectives really ran."""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    n, steps, bn = 1000, 24, 300
+    setup = Setup(graph_files["lfr"], n, k)
+    eng = setup.engine(use_validation_stop=False, node_block=(0, n), n_alloc=n)
+    eng.comm_init(_svils.comm_unique_id(), 0, 1)        # before svils_set_stochastic: either order is accepted
+    eng.set_stochastic(batch_nodes=bn, tau0=4.0, kappa=0.6, shard_block=n)
+    eng.enable_timing(1 << _svils.KERNEL_EXCHANGE)
+    eng.step_sharded(steps)
+    eng.synchronize()
+    assert eng.timing()["exchange"][1] == 3 * steps
+    plain = setup.engine(use_validation_stop=False)
+    plain.set_stochastic(batch_nodes=bn, tau0=4.0, kappa=0.6)
+    plain.step(steps)
+    a, b = eng.state(), plain.state()
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-9)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-9)
+    assert np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(eng.rows(), plain.rows(), rtol=1e-9, atol=1e-12)
+    with pytest.raises(_svils.SvilsError):
+        plain.step_sharded(1)                            # no shard_block: not a node-block mini-batch handle
