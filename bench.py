@@ -123,6 +123,7 @@ def dense_only_window(setup, k, device, min_launches=10):
 
 
 HBM_BOUND_WORKLOAD = "synthetic:200000:512:24"
+CONFIG5_WORKLOAD = "mmsb:1000000:512:24"     # BASELINE config 5: planted MMSB graph, n = 1e6, k = 512
 
 
 def hbm_bound_record(device, sweeps=10):
@@ -318,7 +319,7 @@ def main():
     ap.add_argument("--main-timeout", type=int, default=420,
                     help="N>1: seconds the communicator set-up + warm-up + timed sweeps may take before rank 0 prints "
                          "an error line and every rank exits")
-    ap.add_argument("--extra-timeout", type=int, default=240,
+    ap.add_argument("--extra-timeout", type=int, default=480,
                     help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
     args = ap.parse_args()
 
@@ -527,7 +528,7 @@ def main():
     def watchdog():
         if not finished.wait(timeout=args.extra_timeout):
             if rank == 0:
-                out.setdefault("sharded_extra", {"error": "timed out after %d s" % args.extra_timeout})
+                out.setdefault("sharded_extra", {})["watchdog"] = "side records cut off after %d s" % args.extra_timeout
             emit()
             sys.stderr.write("bench.py: rank %d left on the watchdog\n" % rank)
             sys.stderr.flush()
@@ -540,20 +541,25 @@ def main():
     # config 4 (ca-AstroPh K=200) and the HBM-bound size (n=2e5, k=512) -- one chain over the N ranks each.
     if multi and not args.no_extra:
         extra = {}
+        if rank == 0:
+            out["sharded_extra"] = extra   # filled as the records complete: the watchdog prints what is there
         for name, wl, wsteps, cls in (("config4_astroph_k200", "astroph-k200", 50, _Sharded),
                                       ("hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _Sharded),
                                       # mini-batch steps on the headline graph: 8 windows per node block, 80 steps = 10 passes
                                       ("minibatch_steps_astroph_k20", "astroph-k20", 80, _ShardedSteps),
                                       # the same two workloads with the columns sharded instead of the nodes
                                       ("ksharded_config4_astroph_k200", "astroph-k200", 50, _KSharded),
-                                      ("ksharded_hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _KSharded)):
+                                      ("ksharded_hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _KSharded),
+                                      # BASELINE config 5 at full size (~25 s of host set-up each): the layout built for it, then node blocks
+                                      ("ksharded_config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _KSharded),
+                                      ("config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _Sharded)):
             try:
                 s2, p2, _, n2, k2, _ = _load_workload(wl)
                 r2 = cls(s2, rank, world, local_rank, dist)
                 r2.sweep(3)
                 el2 = _timed(r2, r2.eng, wsteps, dist, torch)
                 r2.eng.enable_timing((1 << _svils.KERNEL_PHI) | (1 << _svils.KERNEL_EXCHANGE), 1)
-                nev2 = 10
+                nev2 = min(10, wsteps)
                 r2.sweep(nev2)          # event pass after the timed sweeps (see above)
                 r2.eng.synchronize()
                 if rank == 0:
@@ -569,8 +575,6 @@ def main():
                     os.unlink(p2)
             except Exception as exc:  # the main measurement must survive a failure here
                 extra[name] = {"error": repr(exc)[:300]}
-        if rank == 0:
-            out["sharded_extra"] = extra
     if path:
         os.unlink(path)
     if dist is not None:
