@@ -75,7 +75,10 @@ __device__ __forceinline__ void store_epi(const DeviceState &d, uint32_t p, int 
 // fetched with one coalesced load each, and the next neighbour's Elogpi row is in
 // flight while the current one is reduced (two rows per wave in flight).
 template <int V, bool LOWT, bool EPI>
-__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
+// waves per SIMD asked of the compiler.  V = 16 (K = 513..1024): two -- the kernel then keeps 256 VGPRs and spills ~90 to
+// scratch, which still beats one 512-register wave per SIMD (ca-AstroPh K=640 phi 576 -> 397 us, K=1024 574 -> 503 us; n=2e5
+// K=640 5.5 -> 4.6 ms, n=1e5 K=1024 unchanged; three waves per SIMD: 4x slower) -- profiles/r02_ubench_and_rejected_variants.txt
+__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : 2)) void k_phi(Geometry geo, DeviceState d, Params prm) {
   constexpr int W = 64;
   constexpr bool PROD = EPI && !LOWT;   // product form on exp(Elogpi) rows, else exps of sums of Elogpi rows
   DevCtrl *ctrl = d.ctrl;
