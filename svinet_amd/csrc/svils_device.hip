@@ -383,7 +383,9 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
 // (:751-755), set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491),
 // one group per owned node.
 template <int W, int V, bool STOCH>
-__global__ __launch_bounds__(256) void k_finalize(Geometry geo, DeviceState d, Params prm) {
+// V = 16: two waves per SIMD asked for (256 VGPRs with spills instead of 277 + one wave): ca-AstroPh K=1024 354 -> 273 us,
+// n=1e5 K=1024 1.22 -> 1.04 ms
+__global__ __launch_bounds__(256, (V == 16 ? 2 : 1)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
