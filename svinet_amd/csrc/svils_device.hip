@@ -78,7 +78,7 @@ template <int V, bool LOWT, bool EPI>
 // waves per SIMD asked of the compiler.  V = 16 (K = 513..1024): two -- the kernel then keeps 256 VGPRs and spills ~90 to
 // scratch, which still beats one 512-register wave per SIMD (ca-AstroPh K=640 phi 576 -> 397 us, K=1024 574 -> 503 us; n=2e5
 // K=640 5.5 -> 4.6 ms, n=1e5 K=1024 unchanged; three waves per SIMD: 4x slower) -- profiles/r02_ubench_and_rejected_variants.txt
-__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : 2)) void k_phi(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : V <= 16 ? 2 : 1)) void k_phi(Geometry geo, DeviceState d, Params prm) {
   constexpr int W = 64;
   constexpr bool PROD = EPI && !LOWT;   // product form on exp(Elogpi) rows, else exps of sums of Elogpi rows
   DevCtrl *ctrl = d.ctrl;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
 template <int W, int V, bool STOCH>
 // V = 16: two waves per SIMD asked for (256 VGPRs with spills instead of 277 + one wave): ca-AstroPh K=1024 354 -> 273 us,
 // n=1e5 K=1024 1.22 -> 1.04 ms
-__global__ __launch_bounds__(256, (V == 16 ? 2 : 1)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
@@ -1140,6 +1140,7 @@ bool pick_layout(uint32_t K, int *W, int *V) {
   else if (K <= 128) { *W = 64; *V = 2; }
   else if (K <= 256) { *W = 64; *V = 4; }
   else if (K <= 512) { *W = 64; *V = 8; }
+  else if (K <= 768) { *W = 64; *V = 12; }    // six 16-byte chunks per lane: K = 513..768 does not pay for 1024 columns
   else if (K <= 1024) { *W = 64; *V = 16; }
   else { *W = 64; *V = 32; }
   return true;
@@ -1154,6 +1155,7 @@ bool pick_layout(uint32_t K, int *W, int *V) {
     else if ((geo).V == 2) { CALL(64, 2); }                                    \
     else if ((geo).V == 4) { CALL(64, 4); }                                    \
     else if ((geo).V == 8) { CALL(64, 8); }                                    \
+    else if ((geo).V == 12) { CALL(64, 12); }                                  \
     else if ((geo).V == 16) { CALL(64, 16); }                                  \
     else { CALL(64, 32); }                                                     \
   } while (0)
@@ -1165,6 +1167,7 @@ bool pick_layout(uint32_t K, int *W, int *V) {
     else if ((geo).V == 2) { CALL(64, 2); }                                    \
     else if ((geo).V == 4) { CALL(64, 4); }                                    \
     else if ((geo).V == 8) { CALL(64, 8); }                                    \
+    else if ((geo).V == 12) { CALL(64, 12); }                                  \
     else if ((geo).V == 16) { CALL(64, 16); }                                  \
     else { CALL(64, 32); }                                                     \
   } while (0)
@@ -1183,6 +1186,7 @@ void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStr
     case 2: PHI(2); break;
     case 4: PHI(4); break;
     case 8: PHI(8); break;
+    case 12: PHI(12); break;
     case 16: PHI(16); break;
     default: PHI(32); break;
   }
@@ -1201,6 +1205,7 @@ uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
       case 2: OCC((k_phi<2, false, false>)); break;
       case 4: OCC((k_phi<4, false, false>)); break;
       case 8: OCC((k_phi<8, false, false>)); break;
+      case 12: OCC((k_phi<12, false, false>)); break;
       case 16: OCC((k_phi<16, false, false>)); break;
       default: OCC((k_phi<32, false, false>)); break;
     }
@@ -1214,6 +1219,7 @@ uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
       case 2: OCC((k_s3<64, 2>)); break;
       case 4: OCC((k_s3<64, 4>)); break;
       case 8: OCC((k_s3<64, 8>)); break;
+      case 12: OCC((k_s3<64, 12>)); break;
       case 16: OCC((k_s3<64, 16>)); break;
       default: OCC((k_s3<64, 32>)); break;
     }
@@ -1245,6 +1251,7 @@ void launch_s3(const Geometry &g, const DeviceState &d, const Params &p, hipStre
     case 2: hipLaunchKernelGGL((k_s3<64, 2>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
     case 4: hipLaunchKernelGGL((k_s3<64, 4>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
     case 8: hipLaunchKernelGGL((k_s3<64, 8>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+    case 12: hipLaunchKernelGGL((k_s3<64, 12>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
     case 16: hipLaunchKernelGGL((k_s3<64, 16>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
     default: hipLaunchKernelGGL((k_s3<64, 32>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
   }

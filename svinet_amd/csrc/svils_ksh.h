@@ -783,6 +783,7 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
     else if ((g).V == 2) { CALL(2); }           \
     else if ((g).V == 4) { CALL(4); }           \
     else if ((g).V == 8) { CALL(8); }           \
+    else if ((g).V == 12) { CALL(12); }         \
     else if ((g).V == 16) { CALL(16); }         \
     else { CALL(32); }                          \
   } while (0)
