@@ -71,9 +71,9 @@ def test_random_graph(seed, n, k):
     check("sparse")
 
 
-@pytest.mark.parametrize("k,n", [(513, 30), (600, 40), (768, 36), (800, 30), (1100, 30), (2048, 64)])
+@pytest.mark.parametrize("k,n", [(257, 40), (300, 50), (384, 40), (400, 40), (513, 30), (600, 40), (768, 36), (800, 30), (1100, 30), (2048, 64)])
 def test_large_k_layouts(k, n):
-    """V = 12 (K = 513..768), V = 16 and V = 32 register layouts (K up to SVILS_MAX_K)"""
+    """V = 8, V = 12 (K = 513..768), V = 16 and V = 32 register layouts (K up to SVILS_MAX_K)"""
     from svinet_amd.host_api import Setup
     rng = np.random.default_rng(k)
     pairs = _random_graph(rng, n, 5 * n)
