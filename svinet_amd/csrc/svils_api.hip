@@ -66,6 +66,9 @@ struct svils_handle {
   // native multi-GPU driver (svils_comm_init)
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  unsigned char *stage = nullptr;   // device staging of svils_comm_allgather_host: world x stage_bytes, grown collectively
+  size_t stage_bytes = 0;
+  uint32_t *stage_flag = nullptr;   // device word: "my allocation failed", summed over the ranks
   std::vector<uint32_t> timed_sweeps;   // sweeps_done index of every sweep whose phi launch was bracketed
   uint64_t sweeps_issued = 0;           // sweeps enqueued so far (== DevCtrl.sweeps_done unless stopped)
   // hipGraph replay of whole sweeps (host launch cost: 8 launches x ~7 us per sweep eager)
@@ -151,7 +154,7 @@ struct Timed {
 int fault_error(uint32_t code) {
   if (code == 2u)
     return fail(SVILS_ERR_DEVICE, "K-sharded sweep: the softmax denominator of a link underflowed (rows of disjoint support); "
-                                  "this layout has no log-domain detour across ranks -- use node-block sharding for this model");
+                                  "switch the log-domain exchange on for this model: svils_ksh_log_domain(h, 1) (the default above K = 700)");
   return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
 }
 
@@ -438,8 +441,18 @@ Rccl g_rccl;
 
 int rccl_load() {
   if (g_rccl.lib) return 0;
-  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  // SVILS_RCCL_LIBRARY names the RCCL build to bind (a site's own librccl; tests/ point it at a transport that
+  // lets several processes share one GPU -- tests/fakerccl).  A named library that does not load is an error:
+  // there is no silent second choice.
+  void *lib = nullptr;
+  const char *named = getenv("SVILS_RCCL_LIBRARY");
+  if (named && *named) {
+    lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(SVILS_ERR_UNSUPPORTED, "SVILS_RCCL_LIBRARY=%s does not load (%s)", named, dlerror());
+  } else {
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  }
   if (!lib) return fail(SVILS_ERR_UNSUPPORTED, "librccl not found (%s): the multi-GPU driver needs RCCL", dlerror());
 #define BIND(F)                                                                        \
   do {                                                                                 \
@@ -755,19 +768,36 @@ int svils_comm_allgather_host(svils_handle *h, const void *send, void *recv, siz
   }
   if (bytes == 0) return 0;
   HIPCHK(hipSetDevice(h->cfg.device));
-  unsigned char *tmp = nullptr;
-  HIPCHK(hipMalloc(&tmp, bytes * (size_t)h->world));
-  int rc = 0;
-  hipError_t e = hipMemcpyAsync(tmp + (size_t)h->rank * bytes, send, bytes, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) {
-    ncclResult_t r = g_rccl.AllGather(tmp + (size_t)h->rank * bytes, tmp, bytes, ncclUint8, h->comm, h->stream);
-    if (r != ncclSuccess) rc = fail(SVILS_ERR_DEVICE, "svils_comm_allgather_host: ncclAllGather: %s", g_rccl.GetErrorString(r));
+  // the staging buffer persists and grows only when a larger payload comes (every rank passes the same `bytes`, so
+  // they grow at the same call).  The ranks agree that everybody's allocation worked BEFORE the gather: a rank
+  // that ran out of memory must not leave its peers blocked in the collective.
+  if (bytes > h->stage_bytes) {
+    if (h->stage) (void)hipFree(h->stage);
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    if (!h->stage_flag) HIPCHK(hipMalloc(&h->stage_flag, sizeof(uint32_t)));
+    const size_t want = bytes + bytes / 4;   // some head room: payloads of one run differ by little
+    const uint32_t failed = hipMalloc(&h->stage, want * (size_t)h->world) == hipSuccess ? 0u : 1u;
+    if (failed) { h->stage = nullptr; (void)hipGetLastError(); }
+    HIPCHK(hipMemcpyAsync(h->stage_flag, &failed, sizeof failed, hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(g_rccl.AllReduce(h->stage_flag, h->stage_flag, 1, ncclUint32, ncclSum, h->comm, h->stream));
+    uint32_t nfailed = 0;
+    HIPCHK(hipMemcpyAsync(&nfailed, h->stage_flag, sizeof nfailed, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nfailed) {
+      if (h->stage) (void)hipFree(h->stage);
+      h->stage = nullptr;
+      return fail(SVILS_ERR_DEVICE, "svils_comm_allgather_host: %u of %d ranks could not allocate %zu staging bytes", nfailed, h->world,
+                  want * (size_t)h->world);
+    }
+    h->stage_bytes = want;
   }
-  if (!rc && e == hipSuccess) e = hipMemcpyAsync(recv, tmp, bytes * (size_t)h->world, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(tmp);
-  if (!rc && e != hipSuccess) rc = fail(SVILS_ERR_DEVICE, "svils_comm_allgather_host: %s", hipGetErrorString(e));
-  return rc;
+  unsigned char *tmp = h->stage;
+  HIPCHK(hipMemcpyAsync(tmp + (size_t)h->rank * bytes, send, bytes, hipMemcpyHostToDevice, h->stream));
+  NCCLCHK(g_rccl.AllGather(tmp + (size_t)h->rank * bytes, tmp, bytes, ncclUint8, h->comm, h->stream));
+  HIPCHK(hipMemcpyAsync(recv, tmp, bytes * (size_t)h->world, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 int svils_gather_communities(svils_handle *h) {
@@ -790,6 +820,8 @@ int svils_destroy(svils_handle *h) {
   if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
   if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
   comm_destroy(h);
+  if (h->stage) (void)hipFree(h->stage);
+  if (h->stage_flag) (void)hipFree(h->stage_flag);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -868,7 +900,13 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), rpw_resident_blocks(g, 2, h->cfg.device));
   d.nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
   // lane-per-link layout for small K: wave-items of 64 consecutive entries of a class list
-  d.lpl = (use_lpl(g.K) && !d.ksh) ? 1 : 0;
+  // The class lists pack an entry index into 27 bits: graphs of 2^26 training links or more take the
+  // row-per-wavefront kernels at small K too (they index with 64 bits and have no such limit; slower per link at
+  // K <= 56, but the reference's main use case -- small K on a large graph -- must not be refused).
+  // SVILS_LPL_MAX_ENTRIES lowers the switch-over point (tests exercise the fallback on small graphs with it).
+  uint64_t lpl_max_entries = 1ull << 27;
+  if (const char *e = getenv("SVILS_LPL_MAX_ENTRIES")) lpl_max_entries = std::min<uint64_t>(lpl_max_entries, strtoull(e, nullptr, 10));
+  d.lpl = (use_lpl(g.K) && !d.ksh && 2 * nlinks < lpl_max_entries) ? 1 : 0;
   d.nlinks = nlinks;
   d.ent_begin = rowptr[g.node_begin];
   d.ent_end = rowptr[g.node_end];
@@ -885,8 +923,6 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   }
   std::vector<uint32_t> erow;
   if (d.lpl) {
-    if (2 * nlinks >= (1ull << 27))
-      return fail(SVILS_ERR_UNSUPPORTED, "k <= 56 supports up to 2^26 training links (got %llu)", (unsigned long long)nlinks);
     // classification tiles: 1024 entries, more on large graphs so that there are at most ~2048 tiles
     // (the scatter pass adds up the counts of all tiles below its own); erow / col padded to whole tiles
     d.cls_tile = 1024u * (uint32_t)std::max<uint64_t>(1, (2 * nlinks + 1024ull * 2048 - 1) / (1024ull * 2048));

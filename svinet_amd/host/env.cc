@@ -62,7 +62,7 @@ Env::Env(const Args &a)
       load_heldout(a.val_load), load_heldout_fname(a.val_file_location),
       load_test(a.test_load), load_test_fname(a.test_file_location),
       nmi(a.nmi), ground_truth_fname(a.ground_truth_fname),
-      datfname(a.datfname), label(a.label), gpus(a.gpus), rank(a.rank), kshard(a.kshard), sharded((a.sharded || a.gpus > 1) && !a.kshard), comm_file(a.comm_file),
+      datfname(a.datfname), label(a.label), gpus(a.gpus), rank(a.rank), kshard(a.kshard), sharded((a.sharded || a.gpus > 1) && !a.kshard), comm_rfd(a.comm_rfd), comm_wfds(a.comm_wfds),
       batch_mode(a.batch), link_sampling(a.link_sampling), strid(a.strid),
       terminate(0), total_pairs(0), ones_prob(0), zeros_prob(1),
       device(a.device), sweep_batch(a.sweep_batch ? a.sweep_batch : 1), write_files(a.write_files),

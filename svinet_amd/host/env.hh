@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 namespace svinet {
 
@@ -50,7 +51,11 @@ class Env {
     int gpus = 1, rank = 0;
     bool sharded = false;       // node-block sharding: set by -gpus N > 1, or by -sharded with one GPU (a communicator of one rank: the same code path)
     bool kshard = false;        // -kshard: shard the K columns over the ranks instead of the nodes
-    std::string comm_file;      // where rank 0 leaves the ncclUniqueId for the others
+    // the ncclUniqueId travels from rank 0 to the others through pipes made before the fork: rank 0 holds the write
+    // ends, rank r > 0 the read end of its own
+    int comm_rfd = -1;
+    std::vector<int> comm_wfds;
+    std::vector<int> device_list;   // -device-list d0,d1,..: the HIP ordinal of every rank (default: device, device+1, ..)
   };
 
   explicit Env(const Args &a);
@@ -81,7 +86,8 @@ class Env {
   std::string datfname, label;
   int gpus, rank;
   bool kshard, sharded;
-  std::string comm_file;
+  int comm_rfd;
+  std::vector<int> comm_wfds;
   bool batch_mode, link_sampling;
   bool strid;
   volatile int terminate;

@@ -176,23 +176,26 @@ void LinkSampling::attach() {
   }
   if (svils_create(&cfg, &h_)) die_svils("svils_create");
   if (env_.gpus > 1 || env_.sharded) {
-    // rank 0 makes the ncclUniqueId and leaves it in comm_file (written aside, then renamed: readers
-    // never see a partial file); the other ranks wait for it.  Then the collective communicator init.
+    // rank 0 makes the ncclUniqueId and writes it into the pipes main() made before the fork; the other
+    // ranks read it from theirs (a rank 0 that died closes the pipe: the read fails, nobody waits for ever).
+    // Then the collective communicator init.
     unsigned char id[SVILS_COMM_ID_BYTES];
     if (env_.gpus == 1) {   // -sharded with one GPU: a communicator of one rank, nobody to tell
       if (svils_comm_unique_id(id)) die_svils("svils_comm_unique_id");
     } else if (env_.rank == 0) {
       if (svils_comm_unique_id(id)) die_svils("svils_comm_unique_id");
-      const std::string tmp = env_.comm_file + ".tmp";
-      FILE *f = fopen(tmp.c_str(), "wb");
-      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); exit(-1); }
-      fclose(f);
-      if (rename(tmp.c_str(), env_.comm_file.c_str())) { perror("rename"); exit(-1); }
+      for (int fd : env_.comm_wfds) {
+        if (write(fd, id, sizeof id) != (ssize_t)sizeof id) { perror("rank 0: communicator id"); exit(-1); }
+        close(fd);
+      }
     } else {
-      FILE *f = nullptr;
-      for (int tries = 0; tries < 6000 && !(f = fopen(env_.comm_file.c_str(), "rb")); ++tries) usleep(10000);
-      if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "rank %d: no communicator id in %s\n", env_.rank, env_.comm_file.c_str()); exit(-1); }
-      fclose(f);
+      size_t got = 0;
+      while (got < sizeof id) {
+        const ssize_t r = read(env_.comm_rfd, id + got, sizeof id - got);
+        if (r <= 0) { fprintf(stderr, "rank %d: no communicator id from rank 0\n", env_.rank); exit(-1); }
+        got += (size_t)r;
+      }
+      close(env_.comm_rfd);
     }
     if (svils_comm_init(h_, id, env_.rank, env_.gpus)) die_svils("svils_comm_init");
   }
@@ -505,6 +508,7 @@ void LinkSampling::fetch_communities_ksharded() {
   if (svils_get_communities(h_, mine.data())) die_svils("svils_get_communities");
   for (uint32_t i = 0; i < n_; ++i) std::copy(&mine[(size_t)i * w], &mine[(size_t)i * w] + w, &send[(size_t)i * wmax]);
   if (svils_comm_allgather_host(h_, send.data(), all.data(), send.size())) die_svils("svils_comm_allgather_host");
+  if (!env_.write_files) return;   // the other ranks only take part in the collective; rank 0 writes
   member_.assign((size_t)n_ * k_, 0);
   for (uint32_t r = 0; r < G; ++r) {
     const uint32_t a = (uint32_t)((uint64_t)k_ * r / G), b = (uint32_t)((uint64_t)k_ * (r + 1) / G);
@@ -578,9 +582,12 @@ void LinkSampling::do_on_stop() {                          // src/linksampling.c
   write_groups();
 }
 
-void LinkSampling::fetch_and_log_rows() {
+// true when the batch reached a report (the reference's `_iter % reportfreq == 0` block, :777-785): new likelihood
+// rows.  The row count lives in the replicated control block, so every rank of a -gpus N run sees the same answer.
+bool LinkSampling::fetch_and_log_rows() {
   svils_control c;
   if (svils_get_control(h_, &c)) die_svils("svils_get_control");
+  const bool reported = c.rows > rows_logged_ || env_.accuracy || val_sorted_.empty();
   if (c.rows > rows_logged_) {
     std::vector<double> rows((size_t)(c.rows - rows_logged_) * 10);
     if (svils_get_rows(h_, rows_logged_, c.rows - rows_logged_, rows.data())) die_svils("svils_get_rows");
@@ -594,6 +601,7 @@ void LinkSampling::fetch_and_log_rows() {
     if (vf_) write_max(&rows[(size_t)(c.rows - rows_logged_ - 1) * 10], c.why, c.max_h);
     rows_logged_ = c.rows;
   }
+  return reported;
 }
 
 // LinkSampling::infer, src/linksampling.cc:556-790.  The loop body lives on
@@ -660,9 +668,9 @@ int LinkSampling::sweep_loop() {
     } else if (svils_sweep(h_, batch)) {
       die_svils("svils_sweep");
     }
-    fetch_and_log_rows();
+    const bool reported = fetch_and_log_rows();
     if (svils_get_control(h_, &c)) die_svils("svils_get_control");
-    if (!c.stopped) {                                             // :785 (the control block is replicated: same branch on every rank)
+    if (!c.stopped && reported) {                                 // :777-785 (the control block is replicated: same branch on every rank)
       if (env_.kshard) fetch_communities_ksharded();
       else if (env_.sharded && svils_gather_communities(h_)) die_svils("svils_gather_communities");
       if (env_.write_files) log_communities();
@@ -671,7 +679,16 @@ int LinkSampling::sweep_loop() {
       do_on_stop();
       return 1;
     }
-    if (env_.terminate && env_.gpus == 1) {                       // :763-766 (SIGTERM; -gpus N: per-process, would split the ranks)
+    // :763-766 (SIGTERM: save the model and go on).  -gpus N: the signal reaches the ranks at different sweeps, and
+    // do_on_stop() is collective there, so the ranks agree first: one byte per rank, gathered at every poll
+    bool term = env_.terminate != 0;
+    if (env_.gpus > 1) {
+      const unsigned char mine = term ? 1 : 0;
+      std::vector<unsigned char> all((size_t)env_.gpus, 0);
+      if (svils_comm_allgather_host(h_, &mine, all.data(), 1)) die_svils("svils_comm_allgather_host");
+      term = std::any_of(all.begin(), all.end(), [](unsigned char b) { return b != 0; });
+    }
+    if (term) {
       do_on_stop();
       env_.terminate = 0;
     }

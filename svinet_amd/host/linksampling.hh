@@ -73,7 +73,7 @@ class LinkSampling {
   void fetch_communities_ksharded();           // -kshard: merged member_ (collective)
   void write_groups();
   uint32_t duration() const { return (uint32_t)(time(0) - start_time_); }
-  void fetch_and_log_rows();
+  bool fetch_and_log_rows();
 
   Env &env_;
   Network &network_;

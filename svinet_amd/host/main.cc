@@ -7,6 +7,7 @@
 // flags that select the reference's other engines are recognised and rejected
 // with a message instead of being silently ignored.
 #include <csignal>
+#include <cerrno>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <cstdio>
@@ -35,6 +36,13 @@ static void term_handler(int sig) {   // src/main.cc:29-40
   }
 }
 
+// -gpus N, parent process: the ranks it forked (-1 once reaped); signals are passed on to them
+static std::vector<pid_t> g_kids;
+static void forward_handler(int sig) {
+  for (pid_t k : g_kids)
+    if (k > 0) kill(k, sig);
+}
+
 static void usage() {
   fprintf(stdout,
           "\nSVINET (MI355X link-sampling build): stochastic variational inference of undirected networks\n"
@@ -61,6 +69,7 @@ static void usage() {
           "\t\t\tsharding, RCCL all-reduce / all-gather over xGMI between the phases of a sweep\n\n"
           "\t\t\twith -minibatch <m>: every GPU steps through windows of m nodes of its own block; per step an all-reduce\n"
           "\t\t\tof the K-vectors and broadcasts of the touched gamma rows (svils_step_sharded)\n\n"
+          "\t-device-list <d0,d1,..>\tthe HIP device ordinal of every rank of a -gpus N run (default: d, d+1, ..)\n\n"
           "\t-sharded\ttake the -gpus N code path with one GPU as well (a communicator of one rank)\n\n"
           "\t-kshard\t\twith -gpus N: shard the K communities over the N GPUs (every GPU holds K/N columns of all rows;\n"
           "\t\t\tper sweep four all-reduces of O(links) doubles instead of an all-gather of the rows) -- the\n"
@@ -117,6 +126,16 @@ int main(int argc, char **argv) {
     else if (is("-strid")) { a.strid = true; }
     else if (is("-device")) { need(i); a.device = atoi(argv[++i]); }
     else if (is("-gpus")) { need(i); a.gpus = atoi(argv[++i]); }
+    else if (is("-device-list")) {
+      need(i);
+      a.device_list.clear();
+      for (const char *p = argv[++i]; *p;) {
+        char *e = nullptr;
+        a.device_list.push_back((int)strtol(p, &e, 10));
+        if (e == p) { fprintf(stderr, "error: -device-list wants d0,d1,...\n"); return -1; }
+        p = *e == ',' ? e + 1 : e;
+      }
+    }
     else if (is("-kshard")) { a.kshard = true; }
     else if (is("-sharded")) { a.sharded = true; }
     else if (is("-sweep-batch")) { need(i); a.sweep_batch = atoi(argv[++i]); }
@@ -157,48 +176,82 @@ int main(int argc, char **argv) {
     return -1;
   }
 
+  if (a.gpus < 1) {
+    fprintf(stderr, "error: -gpus needs a positive count\n");
+    return -1;
+  }
+  if (a.kshard && (uint32_t)a.gpus > a.k) {
+    fprintf(stderr, "error: -kshard needs at least one community per GPU\n");
+    return -1;
+  }
+  if (!a.device_list.empty() && (int)a.device_list.size() != a.gpus) {
+    fprintf(stderr, "error: -device-list names %d devices for -gpus %d\n", (int)a.device_list.size(), a.gpus);
+    return -1;
+  }
+  if (a.gpus == 1 && !a.device_list.empty()) a.device = a.device_list[0];
+
   // -gpus N: fork one process per GPU before anything touches the HIP runtime.  Every rank reads the
   // graph and runs the (seeded, deterministic) host-side initialisation itself; rank 0 owns the output
-  // directory and the files, the others compute their node block only.
+  // directory and the files, the others compute their node block (or column slice) only.  The communicator
+  // id goes from rank 0 to rank r through a pipe made here.
   if (a.link_sampling && a.gpus > 1) {
-    if (a.kshard && (uint32_t)a.gpus > a.k) {
-      fprintf(stderr, "error: -kshard needs at least one community per GPU\n");
-      return -1;
+    std::vector<int> rfds((size_t)a.gpus, -1), wfds((size_t)a.gpus, -1);
+    for (int r = 1; r < a.gpus; ++r) {
+      int fd[2];
+      if (pipe(fd)) { perror("pipe"); return -1; }
+      rfds[r] = fd[0];
+      wfds[r] = fd[1];
     }
-    char tmpl[] = "/tmp/svinet-comm-XXXXXX";
-    const int fd = mkstemp(tmpl);
-    if (fd < 0) { perror("mkstemp"); return -1; }
-    close(fd);
-    unlink(tmpl);                      // rank 0 re-creates it atomically once the id is in it
-    a.comm_file = tmpl;
-    std::vector<pid_t> kids;
     const int dev0 = a.device;
     for (int r = 0; r < a.gpus; ++r) {
       const pid_t pid = fork();
-      if (pid < 0) { perror("fork"); return -1; }
+      if (pid < 0) {
+        perror("fork");
+        for (pid_t k : g_kids) kill(k, SIGKILL);
+        return -1;
+      }
       if (pid == 0) {
+        g_kids.clear();
         a.rank = r;
-        a.device = dev0 + r;
+        a.device = a.device_list.empty() ? dev0 + r : a.device_list[r];
         if (r > 0) a.write_files = false;
-        kids.clear();
+        for (int q = 1; q < a.gpus; ++q) {   // keep only the ends this rank uses
+          if (r == 0) a.comm_wfds.push_back(wfds[q]); else close(wfds[q]);
+          if (q == r) a.comm_rfd = rfds[q]; else close(rfds[q]);
+        }
         goto run;
       }
-      kids.push_back(pid);
+      g_kids.push_back(pid);
     }
-    {
-      int rc = 0;
-      for (size_t r = 0; r < kids.size(); ++r) {
-        int st = 0;
-        waitpid(kids[r], &st, 0);
-        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-        if (code != 0 && rc == 0) {
-          rc = code;
-          for (pid_t k : kids) kill(k, SIGKILL);   // a rank died: the others would wait in a collective for ever
-        }
+    for (int q = 1; q < a.gpus; ++q) { close(rfds[q]); close(wfds[q]); }
+    // SIGTERM (the reference's "save the model" signal) and SIGINT go on to the ranks; they agree among themselves
+    // at their next poll (LinkSampling::sweep_loop)
+    signal(SIGTERM, forward_handler);
+    signal(SIGINT, forward_handler);
+    // reap in the order the ranks finish: the first one that fails takes the others with it, because they would
+    // wait in a collective for ever; only pids not reaped yet are signalled
+    int rc = 0;
+    size_t left = g_kids.size();
+    while (left) {
+      int st = 0;
+      const pid_t pid = waitpid(-1, &st, 0);
+      if (pid < 0) {
+        if (errno == EINTR) continue;
+        break;
       }
-      unlink(tmpl);
-      return rc;
+      bool ours = false;
+      for (pid_t &k : g_kids)
+        if (k == pid) { k = -1; ours = true; }
+      if (!ours) continue;
+      --left;
+      const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+      if (code != 0 && rc == 0) {
+        rc = code;
+        for (pid_t k : g_kids)
+          if (k > 0) kill(k, SIGKILL);
+      }
     }
+    return rc;
   }
 run:
   Env env(a);

@@ -1,0 +1,288 @@
+// TEST INFRASTRUCTURE -- never part of the product.
+//
+// A stand-in for librccl that lets SEVERAL PROCESSES SHARING ONE GPU form a communicator, so that the
+// library's native multi-rank drivers (svils_sweep_sharded, svils_step_sharded, svils_sweep_ksharded,
+// svils_comm_allgather_host, svils_gather_communities and `svinet -gpus N`) run with rank > 0 on the
+// one-GPU test box (real RCCL refuses two ranks on one device).  libsvils binds RCCL through dlopen; the
+// environment variable SVILS_RCCL_LIBRARY names the library, and only tests/ ever point it here.
+//
+// Transport: a POSIX shared-memory segment named after the 128-byte unique id, one staging slot per rank.
+// Every collective is executed synchronously at the call (or at ncclGroupEnd for grouped calls, in issue
+// order): stream synchronise, device -> slot, barrier, combine from the slots in rank order, -> device,
+// barrier.  That is stricter than RCCL's stream ordering, never weaker, and deterministic.  Sums are taken
+// in rank order on every rank, so the result is bit-identical everywhere (as RCCL's all-reduce is).
+// A rank that does not show up within FAKERCCL_TIMEOUT_S (default 120) fails the collective on the others.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+constexpr size_t kHeader = 4096;
+constexpr size_t kSlot = 8u << 20;   // bytes staged per rank and round
+
+struct Header {
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  std::atomic<uint32_t> failed;
+  std::atomic<uint64_t> calls;   // collectives executed (all ranks count the same ones): test evidence
+};
+
+struct Comm {
+  int rank = 0, world = 1;
+  Header *hdr = nullptr;
+  unsigned char *slots = nullptr;
+  size_t bytes = 0;
+  char name[64] = {0};
+  unsigned long long calls = 0, moved = 0;   // collectives this rank executed, payload bytes it contributed
+};
+
+struct Op {
+  int kind;   // 0 all-reduce, 1 all-gather, 2 broadcast
+  const void *send;
+  void *recv;
+  size_t count;
+  ncclDataType_t dt;
+  ncclRedOp_t red;
+  int root;
+  Comm *comm;
+  hipStream_t stream;
+};
+
+std::vector<Comm *> g_live;   // communicators not destroyed yet: their statistics are written at process exit
+
+void write_stats(const Comm *c) {   // test evidence: "<rank> <world> <collectives> <bytes>" per communicator
+  if (const char *path = getenv("FAKERCCL_STATS")) {
+    if (FILE *f = fopen(path, "a")) {
+      fprintf(f, "%d %d %llu %llu\n", c->rank, c->world, c->calls, c->moved);
+      fclose(f);
+    }
+  }
+}
+
+void at_exit() {
+  for (const Comm *c : g_live) write_stats(c);
+  g_live.clear();
+}
+
+thread_local int g_depth = 0;
+thread_local std::vector<Op> g_ops;
+
+double timeout_s() {
+  const char *e = getenv("FAKERCCL_TIMEOUT_S");
+  return e ? atof(e) : 120.0;
+}
+
+size_t dtype_size(ncclDataType_t dt) {
+  switch (dt) {
+    case ncclInt8: case ncclUint8: return 1;
+    case ncclFloat16: case ncclBfloat16: return 2;
+    case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+    case ncclInt64: case ncclUint64: case ncclFloat64: return 8;
+    default: return 0;
+  }
+}
+
+bool barrier(Comm *c) {
+  Header *h = c->hdr;
+  if (h->failed.load()) return false;
+  const uint32_t gen = h->generation.load();
+  if (h->arrived.fetch_add(1) + 1 == (uint32_t)c->world) {
+    h->arrived.store(0);
+    h->generation.fetch_add(1);
+    return true;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const double lim = timeout_s();
+  unsigned spins = 0;
+  while (h->generation.load() == gen) {
+    if (h->failed.load()) return false;
+    if ((++spins & 1023u) == 0) {
+      sched_yield();
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
+        h->failed.store(1);
+        fprintf(stderr, "fakerccl: rank %d waited %.0f s at a barrier (a peer is missing)\n", c->rank, lim);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+template <class T>
+void combine(T *acc, const T *x, size_t n, ncclRedOp_t red) {
+  if (red == ncclSum) for (size_t i = 0; i < n; ++i) acc[i] += x[i];
+  else if (red == ncclMax) for (size_t i = 0; i < n; ++i) acc[i] = x[i] > acc[i] ? x[i] : acc[i];
+  else for (size_t i = 0; i < n; ++i) acc[i] = x[i] < acc[i] ? x[i] : acc[i];   // ncclMin
+}
+
+#define HIPOK(e) do { if ((e) != hipSuccess) return ncclUnhandledCudaError; } while (0)
+
+ncclResult_t run(const Op &o) {
+  Comm *c = o.comm;
+  const size_t es = dtype_size(o.dt);
+  if (!es) return ncclInvalidArgument;
+  if (o.kind == 0 && !(o.red == ncclSum || o.red == ncclMax || o.red == ncclMin)) return ncclInvalidArgument;
+  if (o.kind == 0 && !(o.dt == ncclFloat64 || o.dt == ncclUint32 || o.dt == ncclUint64 || o.dt == ncclInt32 || o.dt == ncclInt64))
+    return ncclInvalidArgument;
+  HIPOK(hipStreamSynchronize(o.stream));
+  const size_t per = (kSlot / es) * es / 8 * 8;   // elements' bytes per round, multiple of 8
+  const size_t total = o.count * es;
+  std::vector<unsigned char> acc;
+  for (size_t off = 0; off < total || (total == 0 && off == 0); off += per) {
+    const size_t nb = total - off < per ? total - off : per;
+    unsigned char *mine = c->slots + (size_t)c->rank * kSlot;
+    if (o.kind != 2 || c->rank == o.root) {
+      if (nb) HIPOK(hipMemcpy(mine, (const unsigned char *)o.send + off, nb, hipMemcpyDeviceToHost));
+    }
+    if (!barrier(c)) return ncclSystemError;
+    if (o.kind == 0) {
+      acc.assign(c->slots, c->slots + nb);
+      for (int r = 1; r < c->world; ++r) {
+        const unsigned char *x = c->slots + (size_t)r * kSlot;
+        switch (o.dt) {
+          case ncclFloat64: combine((double *)acc.data(), (const double *)x, nb / 8, o.red); break;
+          case ncclUint64: combine((uint64_t *)acc.data(), (const uint64_t *)x, nb / 8, o.red); break;
+          case ncclInt64: combine((int64_t *)acc.data(), (const int64_t *)x, nb / 8, o.red); break;
+          case ncclUint32: combine((uint32_t *)acc.data(), (const uint32_t *)x, nb / 4, o.red); break;
+          default: combine((int32_t *)acc.data(), (const int32_t *)x, nb / 4, o.red); break;
+        }
+      }
+      if (nb) HIPOK(hipMemcpy((unsigned char *)o.recv + off, acc.data(), nb, hipMemcpyHostToDevice));
+    } else if (o.kind == 1) {
+      for (int r = 0; r < c->world; ++r)
+        if (nb) HIPOK(hipMemcpy((unsigned char *)o.recv + (size_t)r * total + off, c->slots + (size_t)r * kSlot, nb, hipMemcpyHostToDevice));
+    } else if (c->rank != o.root || o.recv != o.send) {
+      if (nb) HIPOK(hipMemcpy((unsigned char *)o.recv + off, c->slots + (size_t)o.root * kSlot, nb, hipMemcpyHostToDevice));
+    }
+    if (!barrier(c)) return ncclSystemError;
+    if (total == 0) break;
+  }
+  if (c->rank == 0) c->hdr->calls.fetch_add(1);
+  c->calls++;
+  c->moved += total;
+  return ncclSuccess;
+}
+
+ncclResult_t submit(const Op &o) {
+  if (!o.comm) return ncclInvalidArgument;
+  if (g_depth > 0) { g_ops.push_back(o); return ncclSuccess; }
+  return run(o);
+}
+
+uint64_t fnv(const void *p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
+  return h;
+}
+}  // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
+  if (!id) return ncclInvalidArgument;
+  memset(id, 0, sizeof *id);
+  uint64_t v[4] = {(uint64_t)getpid(), (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(), 0, 0};
+  FILE *f = fopen("/dev/urandom", "rb");
+  if (f) { if (fread(&v[2], 8, 2, f) != 2) v[2] = v[0] * 0x9e3779b97f4a7c15ull; fclose(f); }
+  snprintf(id->internal, sizeof id->internal, "fakerccl:%016llx%016llx%016llx", (unsigned long long)(v[0] ^ v[1]),
+           (unsigned long long)v[2], (unsigned long long)v[3]);
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int rank) {
+  if (!out || world < 1 || rank < 0 || rank >= world) return ncclInvalidArgument;
+  Comm *c = new Comm;
+  c->rank = rank;
+  c->world = world;
+  snprintf(c->name, sizeof c->name, "/fakerccl-%016llx", (unsigned long long)fnv(&id, sizeof id));
+  c->bytes = kHeader + (size_t)world * kSlot;
+  const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) { perror("fakerccl: shm_open"); delete c; return ncclSystemError; }
+  if (ftruncate(fd, (off_t)c->bytes) != 0) { perror("fakerccl: ftruncate"); close(fd); delete c; return ncclSystemError; }
+  void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { perror("fakerccl: mmap"); delete c; return ncclSystemError; }
+  c->hdr = (Header *)p;           // a new segment is zero-filled: counters start at 0 on whoever comes first
+  c->slots = (unsigned char *)p + kHeader;
+  const bool ok = barrier(c);     // everybody has mapped it
+  if (rank == 0) shm_unlink(c->name);
+  if (!ok) { munmap(p, c->bytes); delete c; return ncclSystemError; }
+  static bool registered = false;
+  if (!registered) { atexit(at_exit); registered = true; }
+  g_live.push_back(c);
+  *out = (ncclComm_t)c;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+  Comm *c = (Comm *)comm;
+  if (!c) return ncclSuccess;
+  write_stats(c);
+  for (size_t i = 0; i < g_live.size(); ++i)
+    if (g_live[i] == c) { g_live.erase(g_live.begin() + (long)i); break; }
+  munmap((void *)c->hdr, c->bytes);
+  delete c;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream) {
+  return submit(Op{0, send, recv, count, dt, op, 0, (Comm *)comm, stream});
+}
+
+ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclComm_t comm, hipStream_t stream) {
+  return submit(Op{1, send, recv, count, dt, ncclSum, 0, (Comm *)comm, stream});
+}
+
+ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataType_t dt, int root, ncclComm_t comm,
+                           hipStream_t stream) {
+  Comm *c = (Comm *)comm;
+  if (c && (root < 0 || root >= c->world)) return ncclInvalidArgument;
+  return submit(Op{2, send, recv, count, dt, ncclSum, root, c, stream});
+}
+
+ncclResult_t ncclGroupStart() {
+  ++g_depth;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd() {
+  if (g_depth <= 0) return ncclInvalidUsage;
+  if (--g_depth > 0) return ncclSuccess;
+  std::vector<Op> ops;
+  ops.swap(g_ops);
+  for (const Op &o : ops) {
+    const ncclResult_t r = run(o);
+    if (r != ncclSuccess) return r;
+  }
+  return ncclSuccess;
+}
+
+const char *ncclGetErrorString(ncclResult_t r) {
+  switch (r) {
+    case ncclSuccess: return "no error";
+    case ncclUnhandledCudaError: return "fakerccl: HIP call failed";
+    case ncclSystemError: return "fakerccl: a peer is missing (barrier timeout) or shared memory failed";
+    case ncclInvalidArgument: return "fakerccl: invalid argument";
+    case ncclInvalidUsage: return "fakerccl: invalid usage";
+    default: return "fakerccl: error";
+  }
+}
+
+// test evidence: how many collectives the communicator has executed
+unsigned long long fakercclCalls(ncclComm_t comm) {
+  Comm *c = (Comm *)comm;
+  return c ? (unsigned long long)c->hdr->calls.load() : 0ull;
+}
+}

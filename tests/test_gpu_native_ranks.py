@@ -1,0 +1,272 @@
+"""-m gpu: the library's OWN multi-rank drivers with rank > 0.
+
+svils_sweep_sharded, svils_step_sharded, svils_sweep_ksharded (+ log-domain), svils_comm_allgather_host,
+svils_gather_communities and the CLI `svinet -gpus N [-kshard | -minibatch m]` issue their collectives inside
+libsvils through a table of dlsym'd nccl* entry points.  On an 8-GPU node that table is RCCL; on the one-GPU test
+box RCCL refuses two ranks on one device, so these tests bind it (SVILS_RCCL_LIBRARY) to tests/fakerccl -- a
+tests-only transport that lets several processes on ONE GPU form a communicator -- and hold every rank's result
+against the oracle.  What runs here that no other test runs: every `rank * B * ld` offset, the in-place
+all-gathers, the world x 3 grouped broadcasts of exchange_windows with their roots, the collective staging of
+svils_comm_allgather_host, the pipe hand-shake of the communicator id and the reaping logic of `svinet -gpus N`.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FAKE = os.path.join(HERE, "fakerccl", "libfakerccl.so")
+SVINET = os.path.join(ROOT, "svinet_amd", "bin", "svinet")
+
+
+def _env(tmp_path=None):
+    if not os.path.exists(FAKE):
+        import __graft_entry__ as ge
+        ge.build_test_transport()
+    env = dict(os.environ)
+    env["SVILS_RCCL_LIBRARY"] = FAKE
+    env["FAKERCCL_TIMEOUT_S"] = "180"
+    if tmp_path is not None:
+        env["FAKERCCL_STATS"] = str(tmp_path / "fakerccl.stats")
+    return env
+
+
+def _run_ranks(tmp_path, path, n, k, count, world, mode):
+    out = str(tmp_path / "state")
+    worker = os.path.join(HERE, "native_rank_worker.py")
+    env = _env(tmp_path)
+    procs = [subprocess.Popen([sys.executable, worker, path, str(n), str(k), str(count), out, str(r), str(world), mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    errs = []
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        errs.append(err)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, errs[r][-3000:])
+    stats = [tuple(int(x) for x in line.split()) for line in open(env["FAKERCCL_STATS"])]
+    assert sorted(s[0] for s in stats) == list(range(world)) and all(s[1] == world for s in stats)
+    assert len({s[2] for s in stats}) == 1          # every rank executed the same number of collectives
+    return [np.load(out + ".%d.npz" % r) for r in range(world)], stats
+
+
+def _oracle(path, n, k, sweeps, **kw):
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False, **kw)
+    for _ in range(sweeps):
+        ref.sweep()
+    return ref
+
+
+def _check_node_block(states, ref, n, world, tags=True):
+    from svinet_amd.sharded import block_size
+    B = block_size(n, world)
+    for s in states:
+        assert np.max(np.abs(s["gamma"] - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+        assert np.max(np.abs(s["lam"] - ref.lam) / np.abs(ref.lam)) < 1e-9
+        assert np.array_equal(s["conv"], ref.converged)
+        assert int(s["iter"]) == ref.iter and bool(s["annealing"]) == ref.annealing
+        np.testing.assert_allclose(s["rows"][:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+        if tags:   # svils_gather_communities: every rank ends up with every block's tags
+            assert np.array_equal(s["member"], ref.communities())
+    for s in states[1:]:       # the replicated state is bit-identical across ranks
+        assert np.array_equal(s["gamma"], states[0]["gamma"]) and np.array_equal(s["lam"], states[0]["lam"])
+    return B
+
+
+@pytest.mark.parametrize("graph,world,k,sweeps", [("lfr", 2, 28, 40), ("lfr", 3, 64, 6), ("lfr", 3, 28, 35),
+                                                   ("astroph", 2, 200, 3)])
+def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps):
+    """svils_sweep_sharded in `world` processes: all-reduce of sum[k], the grouped in-place all-gather of the
+    gamma rows and packed flags at rank * B * ld, all-reduce of s1,s2,s3 (grouped with sum[k] once annealing is
+    off: LFR K=28 leaves annealing at sweep 29, seen at sweep 32)"""
+    path, n = graph_files[graph], {"lfr": 1000, "astroph": 17903}[graph]
+    states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, "sweep")
+    ref = _oracle(path, n, k, sweeps)
+    _check_node_block(states, ref, n, world)
+    late = sum(1 for i in range(sweeps) if i >= 32) if (graph, k) == ("lfr", 28) and not ref.annealing else 0
+    for s in states:
+        assert int(s["exchanges"]) == 3 * (sweeps - late) + 2 * late
+    # collectives on the wire: per sweep all-reduce + 2 (gathers) + all-reduce(s) [+1 when sum rides late], + the tag gather
+    assert stats[0][2] == 4 * (sweeps - late) + 4 * late + 1
+
+
+@pytest.mark.parametrize("world,k,steps,mode", [(2, 28, 30, "step:1:0"), (3, 64, 5, "step:1:0")])
+def test_native_step_sharded_full_window_is_a_sweep(graph_files, tmp_path, world, k, steps, mode):
+    """svils_step_sharded with one window per block and step size 1: full sweeps, so every rank equals the oracle.
+    The window rows travel as world x 3 in-place broadcasts, rank r the root of its own window."""
+    path, n = graph_files["lfr"], 1000
+    states, stats = _run_ranks(tmp_path, path, n, k, steps, world, mode)
+    ref = _oracle(path, n, k, steps)
+    _check_node_block(states, ref, n, world, tags=False)
+    assert stats[0][2] == steps * (2 + 3 * world) + 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_step_sharded_windows(graph_files, tmp_path, world):
+    """3 windows per block, damped steps: 90 steps.  The replicated state is bit-identical on all ranks, every node
+    has been updated (sum_k mphi = 1/2, quirk Q3), the held-out likelihood improves -- and with two ranks (where the
+    order of a two-term sum cannot differ between transports) the whole run equals the caller-driven protocol of
+    svinet_amd/sharded.py over gloo bit for bit: same kernels, same exchange points."""
+    path, n, k, steps = graph_files["lfr"], 1000, 28, 90
+    states, _ = _run_ranks(tmp_path, path, n, k, steps, world, "step:3:0.5")
+    a = states[0]
+    for b in states[1:]:
+        for key in ("gamma", "lam", "conv", "rows", "mphi"):
+            assert np.array_equal(a[key], b[key]), key
+    assert np.isfinite(a["gamma"]).all() and (a["gamma"] > 0).all() and (a["lam"] > 0).all()
+    np.testing.assert_allclose(a["mphi"].sum(1), 0.5, rtol=1e-9)
+    assert int(a["iter"]) == steps and a["rows"].shape[0] == steps
+    assert a["rows"][-1, 9] > a["rows"][0, 9]
+    if world != 2:
+        return
+    out = str(tmp_path / "pystate")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(HERE, "shard_worker.py"),
+                        path, str(n), str(k), str(steps), out, "step:3:0.5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    py = np.load(out + ".0.npz")
+    for key in ("gamma", "lam", "conv", "rows"):
+        assert np.array_equal(a[key], py[key]), key
+
+
+@pytest.mark.parametrize("world,k,sweeps,mode", [(2, 28, 40, "kshard"), (3, 100, 6, "kshard"), (3, 130, 5, "kshard-log"),
+                                                  (2, 28, 40, "kshard-log")])
+def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mode):
+    """svils_ksh_init_state + svils_sweep_ksharded in `world` processes (uneven slices at K=100/3, 130/3): the column
+    slices put together equal the oracle, flags / rows / counters replicated; svils_validation_row and
+    svils_comm_allgather_host (collective staging) with rank > 0"""
+    path, n = graph_files["lfr"], 1000
+    states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, mode)
+    ref = _oracle(path, n, k, sweeps)
+    g = np.concatenate([s["gamma"] for s in states], 1)
+    lam = np.concatenate([s["lam"] for s in states], 0)
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    want = ref.communities()
+    per_sweep = 5 if mode == "kshard-log" else 4
+    for r, s in enumerate(states):
+        assert np.array_equal(s["conv"], ref.converged)
+        assert int(s["iter"]) == ref.iter and bool(s["annealing"]) == ref.annealing
+        np.testing.assert_allclose(s["rows"][:, 1:], ref.rows[1:, 1:], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(s["row0"][1:], ref.rows[0, 1:], rtol=1e-9, atol=1e-13)   # constructor-time row
+        k0, k1 = int(s["k0"]), int(s["k1"])
+        assert np.array_equal(s["member"], want[:, k0:k1])
+        # what svils_comm_allgather_host handed to this rank: every rank's tags, rank by rank
+        for q, t in enumerate(states):
+            q0, q1 = int(t["k0"]), int(t["k1"])
+            assert np.array_equal(s["gathered"][q][:, :q1 - q0], want[:, q0:q1])
+        assert int(s["exchanges"]) == per_sweep * sweeps + 2   # + init rows + validation row
+    # + 2 collectives of the staging (the agreement all-reduce and the gather itself)
+    assert stats[0][2] == per_sweep * sweeps + 2 + 2
+
+
+# ----------------------------------------------------------------------------------------- the CLI, forked ranks
+def _cli(tmp_path, args, world, timeout=900, env=None):
+    env = env or _env(tmp_path)
+    cmd = [SVINET] + args + ["-gpus", str(world), "-device-list", ",".join(["0"] * world)]
+    return subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=timeout)
+
+
+def _cmp_numeric(path_a, path_b, skip, atol):
+    a, b = np.loadtxt(path_a), np.loadtxt(path_b)
+    assert a.shape == b.shape
+    assert np.array_equal(a[:, :skip], b[:, :skip])
+    np.testing.assert_allclose(a[:, skip:], b[:, skip:], rtol=1e-5, atol=atol)
+
+
+@pytest.mark.parametrize("world,extra", [(2, []), (3, ["-sweep-batch", "7"]), (2, ["-kshard"]), (3, ["-kshard", "-sweep-batch", "4"])])
+def test_cli_gpus_ranks_files_equal_oracle(graph_files, tmp_path, world, extra):
+    """`svinet -gpus N [-kshard]` with N forked ranks on GPU 0 (the id through the pipes, every rank its own
+    LinkSampling, the gathers behind the files): rank 0's files equal the oracle's writers, nobody else writes"""
+    path, n, k, M = graph_files["lfr"], 1000, 28, 40
+    r = _cli(tmp_path, ["-file", path, "-n", str(n), "-k", str(k), "-link-sampling", "-no-stop", "-max-iterations", str(M)] + extra, world)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = tmp_path / ("n%d-k%d-mmsb-linksampling" % (n, k))
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False, max_iterations=M)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    _cmp_numeric(d / "groups.txt", rd / "groups.txt", 2, 1.1e-3)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    v = np.loadtxt(d / "validation.txt")
+    assert v.shape == (M + 2, 11)                    # constructor row + one per sweep (quirk Q8: M + 1 sweeps)
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+    assert len([x for x in os.listdir(str(tmp_path)) if x.endswith("-linksampling")]) == 1
+    stats = [tuple(int(x) for x in line.split()) for line in open(str(tmp_path / "fakerccl.stats"))]
+    assert sorted(s[0] for s in stats) == list(range(world)) and len({s[2] for s in stats}) == 1 and stats[0][2] > M
+
+
+def test_cli_gpus_minibatch_ranks(graph_files, tmp_path):
+    """`svinet -gpus 2 -minibatch m`: svils_step_sharded behind the forked command line (relabelling on every rank,
+    shard_block, the window broadcasts).  Two ranks stepping through windows of m nodes of their own blocks visit the
+    rows in a different grouping than one process does, so there is no file to equal; what must hold: the run
+    completes, rank 0 writes a finite model and the held-out likelihood improves."""
+    path, n, k = graph_files["lfr"], 1000, 28
+    r = _cli(tmp_path, ["-file", path, "-n", str(n), "-k", str(k), "-link-sampling", "-rfreq", "4", "-no-stop", "-max-iterations", "79",
+                        "-minibatch", "125", "-tau0", "4", "-kappa", "0.5", "-nodetau0", "4", "-nodekappa", "0.5", "-sweep-batch", "4"], 2)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = tmp_path / ("n%d-k%d-mmsb-linksampling" % (n, k))
+    g = np.loadtxt(d / "gamma.txt")[:, 2:]
+    assert g.shape == (n, k) and np.isfinite(g).all() and (g > 0).all()
+    v = np.loadtxt(d / "validation.txt")
+    assert v.shape[0] >= 20 and v[-1, 10] > v[1, 10]
+
+
+def test_cli_gpus_rank_failure_does_not_hang(graph_files, tmp_path):
+    """a rank that dies (here: a device ordinal that does not exist) takes the others with it instead of leaving
+    them in a collective for ever; the parent returns non-zero (reaping in completion order)"""
+    import time
+    env = _env(tmp_path)
+    env["FAKERCCL_TIMEOUT_S"] = "600"          # the peers must be ended by the parent, not by the transport's timeout
+    t0 = time.time()
+    r = _cli(tmp_path, ["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop", "-max-iterations", "5"],
+             2, timeout=300, env=env)
+    assert r.returncode == 0                    # sanity: the same command with good devices runs
+    cmd = [SVINET, "-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop", "-max-iterations", "5",
+           "-label", "bad", "-gpus", "2", "-device-list", "0,99"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+
+
+def test_cli_gpus_sigterm_is_collective(graph_files, tmp_path):
+    """SIGTERM = "save the model and go on" (src/main.cc:29-40, src/linksampling.cc:763-766).  With -gpus N the parent
+    passes the signal on, the ranks see it at different sweeps and agree at their next poll (do_on_stop is collective
+    there): the model is written while the run goes on, and the run still ends normally."""
+    import signal
+    import time
+    env = _env(tmp_path)
+    cmd = [SVINET, "-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop", "-max-iterations", "1500",
+           "-gpus", "2", "-device-list", "0,0"]
+    p = subprocess.Popen(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    t0 = time.time()
+    while time.time() - t0 < 120 and not ((d / "validation.txt").exists() and len((d / "validation.txt").read_text().split("\n")) > 20):
+        time.sleep(0.05)
+    assert p.poll() is None, "the run ended before the signal"
+    p.send_signal(signal.SIGTERM)
+    t1 = time.time()
+    while time.time() - t1 < 60 and not (d / "gamma.txt").exists():
+        time.sleep(0.02)
+    saved_early = (d / "gamma.txt").exists() and p.poll() is None
+    out, err = p.communicate(timeout=600)
+    assert p.returncode == 0, err[-3000:]
+    assert "Got signal. Saving model and groups." in out
+    assert saved_early
+    v = np.loadtxt(d / "validation.txt")
+    assert v.shape[0] == 1502

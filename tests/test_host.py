@@ -147,3 +147,13 @@ def test_nmi_matches_the_shipped_mutual_txt():
     # a cover against itself is 1; unreadable files are reported
     own = os.path.join(d, "communities.txt")
     assert L.svih_nmi(os.fsencode(own), b"/nonexistent") < 0
+
+
+def test_cli_gpus_argument_checks(tmp_path, graph_files):
+    """-gpus / -device-list / -kshard are validated before anything forks or touches a device"""
+    import subprocess
+    for extra in (["-gpus", "0"], ["-gpus", "-3", "-kshard"], ["-gpus", "2", "-device-list", "0"],
+                  ["-gpus", "40", "-kshard"], ["-gpus", "2", "-device-list", "a,b"]):
+        r = subprocess.run([SVINET, "-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling"] + extra,
+                           cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "error" in r.stderr, extra
