@@ -122,46 +122,103 @@ def dense_only_window(setup, k, device, min_launches=10):
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
 
 
+def _pull_model(rec, k, n_nodes):
+    """The bytes the pull-style phi pass itself has to move: every directed softmax entry
+    reads its neighbour's Elogpi row (8K), every node reads its own row once and writes its accumulated
+    gammanext row once (16K per node) -- 16*K*L_softmax + 16*K*N per launch.  SURVEY 8d's 32*K-per-link model
+    also charges the push-style scatter (a 16K read-modify-write per link) that this design never performs,
+    which is why `frac` by that model can exceed 1 on HBM-bound sizes; this one cannot."""
+    nl = rec["launches_timed"]
+    li = rec["links_in_timed_launches"]
+    b = 16.0 * k * (li["dense"] + li["sparse"]) / nl + 16.0 * k * n_nodes
+    t = rec["avg_launch_us"] * 1e-6
+    return {"bytes_per_launch": b, "achieved": b / t / 1e9, "frac": b / t / 1e9 / HBM_PEAK_GBS,
+            "model": "16*K*L_softmax + 16*K*N (neighbour rows + own row + one gammanext row per node)"}
+
+
+def _reseed(eng, gamma0, lam0):
+    """back to the seeded initial state of `LinkSampling ls(env, network)`: gamma / lambda of init_gamma2 /
+    init_lambda, the constructor's loop state (src/linksampling.cc:19-33), no converged flag"""
+    eng.set_state(gamma0, lam0)
+    eng.set_control(iter=0, annealing=1, write_comm=0, nh=0, prev_h=-2147483647.0, max_h=-2147483647.0)
+
+
+def repeated_windows(eng, setup, warmup, steps, reps, torch):
+    """The SAME sweep window (sweeps warmup..warmup+steps of the seeded run) `reps` times from the re-seeded
+    state, each repetition timed exactly like the first one (device sync on both sides of exactly `steps` sweeps,
+    hipGraph replay, no per-kernel events).  A 20-sweep window is 1.2 ms of GPU time: a single one on a fresh
+    lease sees clocks that have not settled, the median over repetitions does not."""
+    import numpy as np
+    gamma0, lam0 = setup.gamma, setup.lam
+    times, finals = [], []
+    for _ in range(reps):
+        _reseed(eng, gamma0, lam0)
+        eng.sweep(warmup)
+        times.append(_timed(eng, eng, steps, None, torch))
+        c = eng.control()
+        finals.append((int(c.iter), int(c.links_dense), int(c.links_sparse), int(c.links_shortcut)))
+    assert len(set(finals)) == 1, "repetitions of the same window ended in different states: %r" % (set(finals),)
+    t = np.sort(np.asarray(times))
+    return times, {"reps": reps, "median_ms_per_step": float(np.median(t)) / steps * 1e3,
+                   "min_ms_per_step": float(t[0]) / steps * 1e3, "max_ms_per_step": float(t[-1]) / steps * 1e3,
+                   "p10_ms_per_step": float(t[int(0.1 * (len(t) - 1))]) / steps * 1e3,
+                   "p90_ms_per_step": float(t[int(round(0.9 * (len(t) - 1)))]) / steps * 1e3,
+                   "end_state_identical": True}
+
+
 HBM_BOUND_WORKLOAD = "synthetic:200000:512:24"
 CONFIG5_WORKLOAD = "mmsb:1000000:512:24"     # BASELINE config 5: planted MMSB graph, n = 1e6, k = 512
 
 
-def hbm_bound_record(device, sweeps=10):
-    """The same phi pass on a state that cannot sit in the 256 MB Infinity Cache (n = 2e5, k = 512:
-    0.82 GB per n-by-k array), measured in this invocation: the fraction of the 8 TB/s HBM peak by
-    algorithmic bytes and by the PMC-counted traffic of this workload (committed profile, provenance given)."""
+def hbm_bound_record(device, sweeps=10, workload=HBM_BOUND_WORKLOAD):
+    """The same phi pass on a state that cannot sit in the 256 MB Infinity Cache, measured in this invocation:
+    the fraction of the 8 TB/s HBM peak by SURVEY 8d's algorithmic bytes, by the pull design's own byte model and
+    by the PMC-counted traffic of this workload (committed profile, provenance given).
+    Default: n = 2e5, k = 512 on a uniform random graph (0.82 GB per n-by-k array).
+    workload = CONFIG5_WORKLOAD: BASELINE config 5 at full size -- the planted MMSB graph, n = 1e6, k = 512,
+    4.1 GB per n-by-k array (3 resident), the size SURVEY 8d makes the >= 50 % HBM-roofline claim on."""
     from svinet_amd import _svils
-    from svinet_amd.host_api import Setup
-    _, sn, sk, sd = HBM_BOUND_WORKLOAD.split(":")
-    n, k = int(sn), int(sk)
     t0 = time.perf_counter()
-    setup = Setup(n=n, k=k, pairs=_synthetic_pairs(n, int(sd), 20240517))
+    setup, _, _, n, k, data = _load_workload(workload)
     eng = setup.engine(use_validation_stop=False, device=device)
     eng.sweep(2)
     eng.synchronize()
     setup_s = time.perf_counter() - t0
-    eng.enable_timing(1 << _svils.KERNEL_PHI, 1)
+    # whole sweeps first, no events: ms per sweep as svils_sweep runs them
     t1 = time.perf_counter()
     eng.sweep(sweeps)
     eng.synchronize()
     el = time.perf_counter() - t1
-    rec = _phi_record(eng, k, "sweeps 2..%d of the seeded run" % (2 + sweeps))
+    # then the per-kernel pass (events around every launch)
+    eng.enable_timing(0xff, 1)
+    eng.sweep(sweeps)
+    eng.synchronize()
+    tm = eng.timing()
+    rec = _phi_record(eng, k, "sweeps %d..%d of the seeded run" % (2 + sweeps, 2 + 2 * sweeps))
     L = int(setup.nlinks)
+    ld = (k + 15) // 16 * 16
     rec.update({"workload": "%s: n=%d k=%d links/sweep=%d, state %.2f GB per n-by-k array (3 resident)"
-                            % (HBM_BOUND_WORKLOAD, n, k, L, n * 512 * 8 / 1e9),
-                "ms_per_sweep_eager": el / sweeps * 1e3, "edge_updates_per_s_eager": L * sweeps / el,
-                "setup_s": setup_s, "kernel": "k_phi<8,false,true> (row-per-wavefront, product form on exp(Elogpi) rows)"})
+                            % (workload, n, k, L, n * ld * 8 / 1e9),
+                "data": data,
+                "ms_per_sweep": el / sweeps * 1e3, "edge_updates_per_s": L * sweeps / el,
+                "kernels_us": {kk: v[0] / max(v[1], 1) * 1e3 for kk, v in tm.items() if v[1]},
+                "setup_s": setup_s,
+                "kernel": ("k_phi<8,false,%s> (row-per-wavefront, %s)" % (("true", "product form on exp(Elogpi) rows")
+                           if n * ld * 8 <= 1536 << 20 else ("false", "exp form: no exp(Elogpi) array above 1.5 GB")))})
     rec["frac_algorithmic"] = rec.pop("frac")
-    tr = _traffic(HBM_BOUND_WORKLOAD)
+    rec["pull_model"] = _pull_model(rec, k, n)
+    tr = _traffic(workload)
     if tr:
         real = tr["phi_hbm_bytes_per_launch"] / (rec["avg_launch_us"] * 1e-6) / 1e9
         rec["traffic"] = tr["phi_hbm_bytes_per_launch"]
         rec["traffic_source"] = {kk: tr.get(kk) for kk in ("source", "commit", "counters")}
         rec["achieved_counter_traffic"] = real
         rec["frac_counter_traffic"] = real / HBM_PEAK_GBS
-        rec["note"] = ("pull-style phi reads two Elogpi rows per directed entry and writes each gammanext row once, so the "
-                       "PMC-counted HBM bytes are below the 32*K-per-link model (which also counts the push-style scatter); "
-                       "frac_counter_traffic is the honest HBM utilisation")
+        rec["note"] = ("pull-style phi reads one neighbour row per directed entry and writes each gammanext row once, so the "
+                       "PMC-counted HBM bytes are close to pull_model and below the 32*K-per-link model (which also counts the "
+                       "push-style scatter: frac_algorithmic may exceed 1); frac_counter_traffic is the honest HBM utilisation"
+                       + ("" if n * ld * 8 * 3 > 1e9 * 4 else " -- at this size part of it is fed by the 256 MB Infinity Cache "
+                          "(FETCH_SIZE counts those hits): config5 is the all-HBM figure"))
     else:
         rec["traffic"] = None
     eng.close()
@@ -169,28 +226,35 @@ def hbm_bound_record(device, sweeps=10):
     return rec
 
 
-def cpu_baseline(path, pairs, n, k, warmup, steps, budget_s=25.0):
-    """The oracle (a port of the reference's single-threaded loop, oracle/svinet_oracle.c)
-    timed on this box's host cores over the same sweep window, bounded to ~budget_s."""
+def cpu_baseline(path, pairs, n, k, warmup, steps, min_s=12.0, budget_s=25.0):
+    """The oracle (a port of the reference's single-threaded loop, oracle/svinet_oracle.c) timed on this box's host
+    cores over the same sweep window of the same seeded run -- repeated from the seeded state until >= min_s of CPU
+    work have been timed (a 20-sweep window is ~1.6 s), bounded to ~budget_s."""
     from oracle import oracle as O
     net = O.Network(path, n) if path else O.Network(n=n, pairs=pairs)
-    ref = O.LinkSampling(net, k, use_validation_stop=False)
-    t_w0 = time.perf_counter()
-    for _ in range(warmup):
-        ref.sweep()
-    t_warm = time.perf_counter() - t_w0
-    per = t_warm / max(warmup, 1) if warmup else None
-    done, t0 = 0, time.perf_counter()
-    while done < steps:
-        ref.sweep()
-        done += 1
-        el = time.perf_counter() - t0
-        if el > budget_s and done >= 2:
+    done, el, reps, per = 0, 0.0, 0, None
+    while el < min_s and el < budget_s:
+        ref = O.LinkSampling(net, k, use_validation_stop=False)
+        t_w0 = time.perf_counter()
+        for _ in range(warmup):
+            ref.sweep()
+        if per is None and warmup:
+            per = (time.perf_counter() - t_w0) / warmup
+        t0 = time.perf_counter()
+        d = 0
+        while d < steps:
+            ref.sweep()
+            d += 1
+            if el + time.perf_counter() - t0 > budget_s and d >= 2:
+                break
+        el += time.perf_counter() - t0
+        done += d
+        reps += 1
+        if d < steps:
             break
-    el = time.perf_counter() - t0
     return {"value": ref.nlinks * done / el, "unit": "edge-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle (single-thread C port, -O2), sweeps %d..%d of the same seeded run (%d of %d timed steps), %.1f s"
-                      % (warmup, warmup + done, done, steps, el),
+            "sample": "oracle (single-thread C port, -O2), sweeps %d..%d of the same seeded run, %d sweeps timed in %d "
+                      "repetition(s) of the window, %.1f s" % (warmup, warmup + steps, done, reps, el),
             "host_cpus": os.cpu_count(), "warmup_s_per_sweep": per}
 
 
@@ -305,17 +369,20 @@ def main():
                     help="|".join(WORKLOADS) + "|astroph-k<K>|synthetic:<n>:<k>:<mean_deg>|mmsb:<n>:<k>:<mean_deg>")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-period", type=int, default=9,
-                    help="N=1: bracket the phi launch with hipEvents on every P-th sweep of the timed region (those "
-                         "sweeps are launched eagerly, the others replay hipGraphs); lowered automatically so that "
-                         "at least 10 launches are timed")
+                    help="N=1: the event pass after the timed region brackets the phi launch with hipEvents on every P-th "
+                         "sweep of the same window (those sweeps launch eagerly, the others replay hipGraphs); lowered "
+                         "automatically so that at least 10 launches are timed")
     ap.add_argument("--no-hbm-bound", action="store_true", help="skip the HBM-bound sub-record (n=2e5, k=512; ~15 s)")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="N=1: no hipEvents in the timed region (pure hipGraph replay); the roofline then comes from an "
-                         "eager pass after it")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the config-5 sub-record (planted MMSB graph, n=1e6, k=512 on this one GPU; ~60 s, 13 GB of HBM)")
+    ap.add_argument("--reps", type=int, default=50,
+                    help="N=1: repetitions of the timed window from the re-seeded state; `value` is their median (0: the single first window)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the N>1 code path (process group, RCCL communicator, sharded driver, side records) with "
                          "whatever world size there is -- a one-GPU box can exercise it with a world of one")
     ap.add_argument("--no-extra", action="store_true", help="N>1: skip the side records (config 4, HBM-bound size)")
+    ap.add_argument("--extra-list", default="", help="N>1: comma-separated names of the side records to run (default: all)")
+    ap.add_argument("--test-one-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--main-timeout", type=int, default=420,
                     help="N>1: seconds the communicator set-up + warm-up + timed sweeps may take before rank 0 prints "
                          "an error line and every rank exits")
@@ -333,6 +400,12 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.test_one_gpu:
+        # TEST MODE (tests/test_gpu_native_ranks.py): every rank on GPU 0, a gloo process group for the id broadcast and
+        # the timing reductions, and the library's collectives on the tests-only transport SVILS_RCCL_LIBRARY names --
+        # the N > 1 code path of this file on a one-GPU box.  Never a measurement.
+        assert os.environ.get("SVILS_RCCL_LIBRARY"), "--test-one-gpu needs the tests' transport (SVILS_RCCL_LIBRARY)"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_sharded
     dist = None
@@ -341,8 +414,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600),
-                                device_id=torch.device("cuda", local_rank))
+        if args.test_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600),
+                                    device_id=torch.device("cuda", local_rank))
 
     # N > 1: RCCL has never carried more than one rank of this code on the hardware available to its builders.
     # If the communicator set-up or the timed sharded sweeps ever block, rank 0 still owes the driver a JSON
@@ -382,45 +458,52 @@ def main():
         eng = runner.eng
     runner.sweep(args.warmup)
     period = max(1, min(args.event_period, args.steps // 10))   # >= 10 timed launches whenever steps >= 10
-    if multi:
-        pass   # no hipEvents in the sharded timed region: its sweeps are short enough for ten event records each to show
-    elif not args.no_kernel_events:
-        eng.enable_timing(1 << _svils.KERNEL_PHI, period)
+    # The timed region carries no hipEvents: svils_sweep replays whole sweeps as hipGraphs (N = 1) / the sharded
+    # driver issues its phases and collectives back to back (N > 1).  Per-kernel timings come from event passes
+    # of their own afterwards.
     elapsed = _timed(runner, eng, args.steps, dist, torch)
     ctrl = eng.control()
     if main_done is not None:
         main_done.set()
     assert ctrl.sweeps_done >= args.warmup + args.steps, "sweeps were skipped"
+    first_window_ms = elapsed / args.steps * 1e3
 
     same_window = None
     exch = None
-    if rank == 0:
-        if multi:
-            pass   # filled in below (every rank takes part in the event pass)
-        elif args.no_kernel_events:        # separate eager pass for the phi timing
-            eng.enable_timing(1 << _svils.KERNEL_PHI)
-            runner.sweep(max(10, min(args.steps, 20)))
+    repeat = None
+    if rank == 0 and not multi:
+        # N = 1: the same window again, `--reps` times from the re-seeded state; `value` is their median
+        if args.reps > 0:
+            times, repeat = repeated_windows(eng, setup, args.warmup, args.steps, args.reps, torch)
+            repeat["first_window_ms_per_step"] = first_window_ms
+            import numpy as np
+            elapsed = float(np.median(np.asarray(times)))
+            ctrl = eng.control()
+        # event pass of its own over the same window: every `period`-th sweep launches eagerly between hipEvents
+        _reseed(eng, setup.gamma, setup.lam)
+        eng.sweep(args.warmup)
+        eng.enable_timing(1 << _svils.KERNEL_PHI, period)
+        eng.sweep(args.steps)
+        eng.synchronize()
+        same_window = _phi_record(eng, k, "event pass over the same window: every %d-th sweep of sweeps %d..%d"
+                                  % (period, args.warmup, args.warmup + args.steps))
+        if same_window["launches_timed"] < 10:   # --steps below 10: top up after the window, labelled
+            extra = 10 - same_window["launches_timed"]
+            eng.enable_timing(1 << _svils.KERNEL_PHI, 1)
+            eng.sweep(extra)
             eng.synchronize()
-            same_window = _phi_record(eng, k, "eager pass of sweeps %d.. after the timed region" % (args.warmup + args.steps))
-        else:
-            same_window = _phi_record(eng, k, "every %d-th sweep of the timed region (sweeps %d..%d)"
-                                      % (period, args.warmup, args.warmup + args.steps))
-            if same_window["launches_timed"] < 10:   # --steps below 10: top up after the region, labelled
-                extra = 10 - same_window["launches_timed"]
-                eng.enable_timing(1 << _svils.KERNEL_PHI, 1)
-                runner.sweep(extra)
-                eng.synchronize()
-                more = _phi_record(eng, k, "")
-                n0, n1 = same_window["launches_timed"], more["launches_timed"]
-                t = (same_window["avg_launch_us"] or 0) * n0 + more["avg_launch_us"] * n1
-                li = {kk: same_window["links_in_timed_launches"][kk] + more["links_in_timed_launches"][kk]
-                      for kk in ("dense", "sparse", "shortcut")}
-                alg = 32.0 * k * (li["dense"] + li["sparse"])
-                ach = alg / (t * 1e-6) / 1e9
-                same_window = {"window": same_window["window"] + " + the %d sweeps after it (to reach 10 launches)" % extra,
-                               "launches_timed": n0 + n1, "avg_launch_us": t / (n0 + n1), "links_in_timed_launches": li,
-                               "algorithmic_bytes_per_launch": alg / (n0 + n1), "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+            more = _phi_record(eng, k, "")
+            n0, n1 = same_window["launches_timed"], more["launches_timed"]
+            t = (same_window["avg_launch_us"] or 0) * n0 + more["avg_launch_us"] * n1
+            li = {kk: same_window["links_in_timed_launches"][kk] + more["links_in_timed_launches"][kk]
+                  for kk in ("dense", "sparse", "shortcut")}
+            alg = 32.0 * k * (li["dense"] + li["sparse"])
+            ach = alg / (t * 1e-6) / 1e9
+            same_window = {"window": same_window["window"] + " + the %d sweeps after it (to reach 10 launches)" % extra,
+                           "launches_timed": n0 + n1, "avg_launch_us": t / (n0 + n1), "links_in_timed_launches": li,
+                           "algorithmic_bytes_per_launch": alg / (n0 + n1), "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+        eng.enable_timing(0, 1)
 
     if multi:
         # phi and exchange times from an event pass of its own right after the timed region (all ranks: the
@@ -464,11 +547,19 @@ def main():
                                             "shortcut": int(ctrl.links_shortcut),
                                             "scope": "this rank's node block" if multi else "all links"}},
         }
+        if repeat is not None:
+            out["repeat"] = repeat
+            out["value_definition"] = ("median over %d repetitions of the timed window (each: exactly %d sweeps from the re-seeded "
+                                       "state after %d warm-up sweeps, device sync on both sides, hipGraph replay, no events); "
+                                       "first_window_ms_per_step is the single first window" % (repeat["reps"], args.steps, args.warmup))
+        if args.test_one_gpu:
+            out["test_mode"] = "all ranks on GPU 0 over the tests' transport: a code-path check, not a measurement"
         tr = _traffic(args.workload) if not multi else None
         roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 64 else "k_phi (phi pass, A6)"}
         roof.update(same_window)
-        roof["timing"] = ("hipEvents around the phi launch on the engine's own stream" +
-                          ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if not multi else ""))
+        roof["timing"] = ("hipEvents around the phi launch on the engine's own stream, in an event pass of its own after the "
+                          "timed region" + ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if not multi else ""))
+        roof["pull_model"] = _pull_model(same_window, k, n if not multi else (n + world - 1) // world)
         roof["traffic"] = tr["phi_hbm_bytes_per_launch"] if tr else None
         roof["traffic_source"] = ({kk: tr.get(kk) for kk in ("source", "commit", "counters")} if tr else None)
         roof["note"] = ("achieved = 32*K bytes x (dense + active-set links of the timed sweeps) / phi time.  The state of this "
@@ -491,25 +582,15 @@ def main():
                 out["hbm_bound"] = hbm_bound_record(local_rank)
             except Exception as exc:
                 out["hbm_bound"] = {"error": repr(exc)[:200]}
+        if not multi and not args.no_config5 and args.workload != CONFIG5_WORKLOAD:
+            # BASELINE config 5 at full size on this one GPU: the size the >= 50 % HBM-roofline claim is made on
+            try:
+                out["config5"] = hbm_bound_record(local_rank, sweeps=5, workload=CONFIG5_WORKLOAD)
+            except Exception as exc:
+                out["config5"] = {"error": repr(exc)[:200]}
         if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
-        # The hipEvents around the phi launch force eager launches for the sampled sweeps.  Without per-kernel
-        # timing svils_sweep replays whole sweeps as hipGraphs; report that throughput over the SAME sweep
-        # window next to `value` (a fresh engine from the same seeded inputs).
-        if not multi and not args.no_kernel_events:
-            try:
-                eng2 = setup.engine(use_validation_stop=False, device=local_rank)
-                eng2.sweep(args.warmup)
-                el2 = _timed(eng2, eng2, args.steps, None, torch)
-                out["graph_replay"] = {"value": L * args.steps / el2, "unit": "edge-updates/s",
-                                       "ms_per_step": el2 / args.steps * 1e3,
-                                       "note": "same workload and sweep window, no per-kernel events, "
-                                               "svils_sweep replays 8-sweep hipGraphs"}
-                eng2.close()
-            except Exception as exc:
-                out["graph_replay"] = {"error": repr(exc)[:200]}
-
     # The one JSON line is owed to the driver whatever happens below: a watchdog emits it (without the
     # side records) and leaves if a side measurement or the teardown ever blocks on a collective.
     import threading
@@ -553,6 +634,8 @@ def main():
                                       # BASELINE config 5 at full size (~25 s of host set-up each): the layout built for it, then node blocks
                                       ("ksharded_config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _KSharded),
                                       ("config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _Sharded)):
+            if args.extra_list and name not in args.extra_list.split(","):
+                continue
             try:
                 s2, p2, _, n2, k2, _ = _load_workload(wl)
                 r2 = cls(s2, rank, world, local_rank, dist)

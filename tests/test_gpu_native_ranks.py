@@ -270,3 +270,24 @@ def test_cli_gpus_sigterm_is_collective(graph_files, tmp_path):
     assert saved_early
     v = np.loadtxt(d / "validation.txt")
     assert v.shape[0] == 1502
+
+
+def test_bench_multi_gpu_code_path_two_ranks(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), in its test mode:
+    both ranks on GPU 0, the library's collectives on the tests' transport.  The N > 1 path of bench.py -- sharded
+    runner, event pass, side records in both layouts, the JSON line -- with rank > 0 before any 8-GPU node runs it."""
+    import json
+    env = _env(tmp_path)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29691", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--test-one-gpu", "--extra-list", "config4_astroph_k200,minibatch_steps_astroph_k20,ksharded_config4_astroph_k200"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["roofline"]["launches_timed"] >= 10 and out["exchange"]["ms_per_sweep"] > 0
+    ex = out["sharded_extra"]
+    for name in ("config4_astroph_k200", "minibatch_steps_astroph_k20", "ksharded_config4_astroph_k200"):
+        assert "error" not in ex[name], ex[name]
+        assert ex[name]["value"] > 0
