@@ -59,6 +59,8 @@ struct svils_handle {
   // lane-per-link layout: the link classes on the device describe the sweep about to run (k_s3_lpl
   // refreshes them for the next sweep); cleared whenever flags / _iter / the window change under them
   bool cls_valid = false;
+  bool derive_ok = true;          // SVILS_DERIVE_M=0 keeps the stored mean indicators everywhere (A/B knob)
+  bool mphi_stale = false;        // whole sweeps (derive_m) left the stored mean indicators behind gamma: k_mphi_from_gamma on demand
   bool v_flush_needed = false;   // a three-launch sweep left its likelihood row / stop rule to the next launch
   bool v_flush_capture = false;  // ... and so do the sweeps captured in the hipGraphs
   void *cls_zero = nullptr;      // ltot + shist + scan descriptors, one contiguous block
@@ -173,6 +175,15 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
               bool fused) {
   hipStream_t s = h->stream;
   DeviceState d = d0;
+  // whole full sweeps keep the mean indicators in derived form (svils_internal.h: derive_m); anything else -- sweeps
+  // split at their exchange points, mini-batch steps -- works on the stored rows, brought up to date first
+  // (lane-per-link layout, K <= 56: its s3 kernel runs at the register limit of 16-wave blocks and keeps the stored form)
+  d.derive_m = (fused && !prm.stoch && !d.ksh && !d.lpl && h->derive_ok) ? 1 : 0;
+  if (!d.derive_m && h->mphi_stale) {
+    launch_mphi_from_gamma(h->geo, h->d, h->prm, s);
+    h->mphi_stale = false;
+  }
+  if (d.derive_m && ph == SVILS_PHASE_B) h->mphi_stale = true;
   d.fold = (fused && d.lpl && g.K <= 32) ? 1 : 0;   // K = 33..64: K-vectors via k_colreduce (2K columns are too wide to fold)
   // Three launches per sweep when this library drives whole full sweeps at K <= 32: the work of k_tail is
   // split between the last s3 block (lambda, loop control) and a role of the NEXT phi launch (likelihood,
@@ -360,13 +371,19 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.gamma, nk));
   d.gacc = d.gamma;   // full sweeps accumulate gammanext in place
   guard(dalloc(h, &d.elogpi, nk));
-  // exp(Elogpi) for the product form of k_phi (K > 56) while an n-by-k array stays below 1.5 GB: there the phi
-  // pass is bound by fp64 issue and trades its exps for multiplies (ca-AstroPh K=200: 174 -> 120 us, n=2e5 K=512:
-  // 3.45 -> 3.02 ms); beyond that it runs at the HBM gather ceiling either way and the extra n-by-k write of the
-  // finalise pass would cost more than the exps (n=1e6 K=512: phi -0.6 ms, finalise +0.75 ms)
+  // exp(Elogpi) for the product form of k_phi (K > 56): the phi pass trades its exps for multiplies (ca-AstroPh K=200:
+  // 174 -> 120 us, n=2e5 K=512: 3.45 -> 3.02 ms).  The price is one more n-by-k write in the finalise pass.  Whole-graph
+  // handles can afford it at any size since round 3: their sweeps no longer store the mean indicators (derive_m), so
+  // the finalise pass writes three n-by-k arrays as before (n=1e6 K=512, profiles/r03e_derive_m.txt: phi -1.3 ms,
+  // finalise +0.06 ms, s3 +0.2 ms per sweep).  Node-block handles (multi-GPU: mphi stays stored) keep the 1.5 GB limit:
+  // beyond it their phi pass runs at the HBM gather ceiling either way and the extra write costs more than the exps.
   d.ksh = cfg->k_total ? 1 : 0;
   d.ksh_log = cfg->k_total > 700 ? 1 : 0;   // psi(1/K) < -745: concentrated memberships underflow the product form
-  if (d.ksh || (!use_lpl(g.K) && nk * sizeof(double) <= 1536ull << 20)) guard(dalloc(h, &d.epi, nk));
+  if (const char *e = getenv("SVILS_DERIVE_M")) h->derive_ok = atoi(e) != 0;
+  const bool whole_graph = g.node_begin == 0 && g.node_end == g.n;
+  uint64_t epi_max_mb = (whole_graph && h->derive_ok) ? ~0ull >> 21 : 1536;
+  if (const char *e = getenv("SVILS_EPI_MAX_MB")) epi_max_mb = strtoull(e, nullptr, 10);   // A/B knob (profiles/r03*)
+  if (d.ksh || (!use_lpl(g.K) && nk * sizeof(double) <= epi_max_mb << 20)) guard(dalloc(h, &d.epi, nk));
   if (d.ksh) {
     guard(dalloc(h, &d.rowx, 3 * (size_t)g.n));
     guard(dalloc(h, &d.q2v, g.Kt));
@@ -381,6 +398,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.lambda, 2 * (size_t)g.K));
   guard(dalloc(h, &d.elogbeta, 2 * (size_t)g.K));
   guard(dalloc(h, &d.kvec_a, g.K));
+  guard(dalloc(h, &d.iscale, g.K));
   guard(dalloc(h, &d.kvec_c, 3 * (size_t)g.K + 4));
   d.rows_cap = 1u << 16;
   guard(dalloc(h, &d.rows, (size_t)d.rows_cap * 10));
@@ -939,8 +957,11 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     const int nw = lpl_phi_waves(g.K);
     const uint32_t phi_items = d.lpl_nitems;
     d.nb_a = cap((phi_items + nw - 1) / nw, std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_phi_resident_blocks(g.K, h->cfg.device)));
-    const uint32_t fw = lpl_finalize_waves();
-    d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fw * G - 1) / (fw * G), 512);   // two 10-wave blocks per CU
+    // finalise pass: 12-wave blocks of 64 / lpl_finalize_group(K) nodes per wavefront, as many as the device holds at
+    // once (one per CU at its register budget); larger graphs loop inside the blocks
+    const uint32_t fnodes = lpl_finalize_waves() * (64u / (uint32_t)lpl_finalize_group(g.K));
+    d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fnodes - 1) / fnodes,
+                 std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_finalize_resident_blocks(g.K, h->cfg.device)));
     d.s3_threads = lpl_s3_threads(g.K);
     d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 classification blocks
   }
@@ -980,13 +1001,20 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     guard(dalloc(h, &d.tpoll, tiles_all));
     if (g.K <= 32) guard(dalloc(h, &d.gacc0, (size_t)g.n_alloc * g.ld));   // three-launch sweeps accumulate beside gamma
     // ltot [2][8] u32 | shist [2][K] u64, cleared together before a stand-alone classification
-    h->cls_zero_bytes = 64 + 2 * (size_t)g.K * sizeof(unsigned long long);
+    const size_t shist_bytes = ((2 * (size_t)g.K * sizeof(unsigned long long)) + 63) / 64 * 64;
+    h->cls_zero_bytes = 64 + shist_bytes + 2 * 8 * 64 * sizeof(long long);   // ... | sumfx [2][8][64] i64
     unsigned char *cz = nullptr;
     guard(dalloc(h, &cz, h->cls_zero_bytes));
     h->cls_zero = cz;
     if (cz) {
       d.ltot = reinterpret_cast<uint32_t *>(cz);
       d.shist = reinterpret_cast<unsigned long long *>(cz + 64);
+      d.sumfx = reinterpret_cast<long long *>(cz + 64 + shist_bytes);
+      // sum[k] <= 2 * nlinks: 2^fx_shift * (2 * nlinks + 2) < 2^61
+      int bits = 1;
+      while ((1ull << bits) < 2 * nlinks + 2) ++bits;
+      d.fx_scale = std::ldexp(1.0, 61 - bits);
+      d.fx_inv = std::ldexp(1.0, bits - 61);
     }
   }
   guard(dalloc(h, &d.part_a, (size_t)d.nb_a * g.K));
@@ -1051,6 +1079,7 @@ int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) 
 int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
                     const uint32_t *converged) {
   if (!h || !gamma || !lambda) return fail(SVILS_ERR_ARG, "svils_set_state: null argument");
+  h->mphi_stale = false;   // the stored rows have nothing to do with the new gamma (nor has the reference's _mphi after load_model)
   HIPCHK(hipSetDevice(h->cfg.device));
   const Geometry &g = h->geo;
   DeviceState &d = h->d;
@@ -1358,7 +1387,8 @@ int open_step(svils_handle *h) {
       const int nw = lpl_phi_waves(g.K);
       const uint64_t items = ((d.ent_end - d.ent_begin + 63) >> 6) + 1;
       d.nb_a = fit((items + nw - 1) / nw, h->d.nb_a);
-      d.nb_b = fit(((uint64_t)(e - b) + lpl_finalize_waves() * G - 1) / (lpl_finalize_waves() * G), h->d.nb_b);
+      const uint32_t fnodes = lpl_finalize_waves() * (64u / (uint32_t)lpl_finalize_group(g.K));
+      d.nb_b = fit(((uint64_t)(e - b) + fnodes - 1) / fnodes, h->d.nb_b);
       d.nb_c = fit((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, h->d.nb_c);
     } else {
       d.nb_a = fit(((uint64_t)d.nitems_phi + 3) / 4, h->d.nb_a);
@@ -1526,6 +1556,11 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
       HIPCHK(hipMemcpy(out, h->d.elogbeta, 2 * (size_t)g.K * sizeof(double), hipMemcpyDeviceToHost));
       return 0;
     case 2:
+      if (h->mphi_stale) {
+        launch_mphi_from_gamma(h->geo, h->d, h->prm, h->stream);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->mphi_stale = false;
+      }
       HIPCHK(hipMemcpy2D(out, g.K * sizeof(double), h->d.mphi, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
       return 0;
     case 3:
@@ -1626,7 +1661,12 @@ int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr, size_t
     case SVILS_BUF_KVEC_C: *dptr = d.kvec_c; *bytes = 3 * (size_t)g.K * sizeof(double); *row_bytes = *bytes; return 0;
     case SVILS_BUF_GAMMA: *dptr = d.gamma; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
     case SVILS_BUF_ELOGPI: *dptr = d.elogpi; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
-    case SVILS_BUF_MPHI: *dptr = d.mphi; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_MPHI:
+      if (h->mphi_stale) {
+        launch_mphi_from_gamma(h->geo, h->d, h->prm, h->stream);
+        h->mphi_stale = false;
+      }
+      *dptr = d.mphi; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
     case SVILS_BUF_CONV: {
       // the buffer prune() writes during phase B = conv[parity ^ 1]; parity flips once per
       // sweep in phase D, and the host can mirror it as (sweeps_done & 1)

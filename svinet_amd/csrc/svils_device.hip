@@ -418,6 +418,12 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
   double s12[2][V];
 #pragma unroll
   for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
+  // 1 / scale of this sweep, for whoever derives the mean indicators from the gamma rows written below
+  if (blockIdx.x == 0 && threadIdx.x < W) {
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      if (kval[v]) d.iscale[kidx[v]] = annealing ? (STOCH ? d.kvec_a[kidx[v]] * prm.scale_a : d.kvec_a[kidx[v]]) / (double)prm.ones : 1.0;
+  }
 
   const uint32_t nown = geo.node_end - geo.node_begin;
   for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < nown; i += gridDim.x * 4 * G) {
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
           }
         if (lw == 0) d.ncnt[p] = c + 1u;
       }
-      store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+      if (STOCH || !d.derive_m) store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     } else {
       // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
 #pragma unroll
@@ -630,11 +636,28 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
   }
 }
 
+// The stored form of the mean indicators, brought up to date from the gamma rows of the last whole sweep (derive_m):
+// every row with a training link; the others keep their stale row (src/linksampling.cc:532-533).
+__global__ __launch_bounds__(256) void k_mphi_from_gamma(Geometry geo, DeviceState d, Params prm) {
+  const uint32_t K = geo.K, ld = geo.ld;
+  const double inv_nm1 = 1.0 / ((double)geo.n - 1.0);
+  const uint64_t total = (uint64_t)geo.n * ld;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t p = (uint32_t)(i / ld), k = (uint32_t)(i % ld);
+    if (k < K && d.rowptr[p + 1] != d.rowptr[p]) d.mphi[i] = (d.gamma[i] * d.iscale[k] - prm.alpha) * inv_nm1;
+  }
+}
+void launch_mphi_from_gamma(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  const uint64_t total = (uint64_t)g.n * g.ld;
+  const uint32_t nb = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_mphi_from_gamma, dim3(nb ? nb : 1), dim3(256), 0, s, g, d, p);
+}
+
 // ================================================================ s3 pass (A8)
 // src/linksampling.cc:731-746 over the upper half (q > p) of each owned row,
 // including quirk Q2 (mphi[q][pc], one past the converged community).
-template <int W, int V>
-__global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
+template <int W, int V, bool DERIVE>
+__global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
@@ -646,10 +669,17 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
-  const double *__restrict__ mphi = d.mphi;
+  // derive_m: the mean indicators come from the gamma rows, m = (gamma * iscale - alpha) / (n - 1)
+  constexpr bool derive = DERIVE;
+  const double *__restrict__ mphi = derive ? d.gamma : d.mphi;
+  const double alpha = prm.alpha, inv_nm1 = 1.0 / ((double)geo.n - 1.0);
   int kidx[V];
+  double isc[V];
 #pragma unroll
-  for (int v = 0; v < V; ++v) kidx[v] = kmap<W, V>(lw, v);
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    isc[v] = (derive && (uint32_t)kidx[v] < K) ? d.iscale[kidx[v]] : 0.0;
+  }
   double s3[1][V];
 #pragma unroll
   for (int v = 0; v < V; ++v) s3[0][v] = 0.0;
@@ -666,22 +696,32 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d) {
     const uint32_t pc = (uint32_t)uni((int)conv[p]);
     double mp[V];
     load_row<W, V>(mphi + (size_t)p * ld, lw, ld, mp);
+    if (derive) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) mp[v] = (uint32_t)kidx[v] < K ? (mp[v] * isc[v] - alpha) * inv_nm1 : 0.0;
+    }
     for (uint32_t j = g; j < item.len; j += G) {
       const uint32_t q = d.col[base + j];
       const uint32_t qc = conv[q];
       if (pc && !qc) {
-        const double val = pc < K ? mphi[(size_t)q * ld + pc] : 0.0;
+        double val = pc < K ? mphi[(size_t)q * ld + pc] : 0.0;
+        if (derive && pc < K) val = (val * d.iscale[pc] - alpha) * inv_nm1;
 #pragma unroll
         for (int v = 0; v < V; ++v)
           if (kidx[v] == (int)pc - 1) s3[0][v] += val;
       } else if (!pc && qc) {
-        const double val = qc < K ? mphi[(size_t)p * ld + qc] : 0.0;
+        double val = qc < K ? mphi[(size_t)p * ld + qc] : 0.0;
+        if (derive && qc < K) val = (val * d.iscale[qc] - alpha) * inv_nm1;
 #pragma unroll
         for (int v = 0; v < V; ++v)
           if (kidx[v] == (int)qc - 1) s3[0][v] += val;
       } else {
         double mq[V];
         load_row<W, V>(mphi + (size_t)q * ld, lw, ld, mq);
+        if (derive) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) mq[v] = (mq[v] * isc[v] - alpha) * inv_nm1;   // padding columns: mp is 0 there
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
       }
@@ -1068,6 +1108,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   if (d.lpl) {
     if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
     for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) d.shist[(size_t)cpar0 * K + k] = 0ull;
+    for (uint32_t k = threadIdx.x; k < 512u; k += blockDim.x) d.sumfx[(size_t)cpar0 * 512 + k] = 0;
   }
 }
 
@@ -1215,13 +1256,13 @@ uint32_t rpw_resident_blocks(const Geometry &g, int which, int device) {
 #undef CALL
   } else {
     switch (g.V) {
-      case 1: OCC((k_s3<64, 1>)); break;
-      case 2: OCC((k_s3<64, 2>)); break;
-      case 4: OCC((k_s3<64, 4>)); break;
-      case 8: OCC((k_s3<64, 8>)); break;
-      case 12: OCC((k_s3<64, 12>)); break;
-      case 16: OCC((k_s3<64, 16>)); break;
-      default: OCC((k_s3<64, 32>)); break;
+      case 1: OCC((k_s3<64, 1, false>)); break;
+      case 2: OCC((k_s3<64, 2, false>)); break;
+      case 4: OCC((k_s3<64, 4, false>)); break;
+      case 8: OCC((k_s3<64, 8, false>)); break;
+      case 12: OCC((k_s3<64, 12, false>)); break;
+      case 16: OCC((k_s3<64, 16, false>)); break;
+      default: OCC((k_s3<64, 32, false>)); break;
     }
   }
 #undef OCC
@@ -1246,15 +1287,21 @@ void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, h
 }
 void launch_s3(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   if (d.lpl) { launch_s3_lpl(g, d, p, s); return; }
-  switch (g.V) {   // K > 32 => W == 64
-    case 1: hipLaunchKernelGGL((k_s3<64, 1>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
-    case 2: hipLaunchKernelGGL((k_s3<64, 2>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
-    case 4: hipLaunchKernelGGL((k_s3<64, 4>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
-    case 8: hipLaunchKernelGGL((k_s3<64, 8>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
-    case 12: hipLaunchKernelGGL((k_s3<64, 12>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
-    case 16: hipLaunchKernelGGL((k_s3<64, 16>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
-    default: hipLaunchKernelGGL((k_s3<64, 32>), dim3(d.nb_c), dim3(256), 0, s, g, d); break;
+#define CALL(V_)                                                                                         \
+  do {                                                                                                   \
+    if (d.derive_m) hipLaunchKernelGGL((k_s3<64, V_, true>), dim3(d.nb_c), dim3(256), 0, s, g, d, p);    \
+    else hipLaunchKernelGGL((k_s3<64, V_, false>), dim3(d.nb_c), dim3(256), 0, s, g, d, p);              \
+  } while (0)
+  switch (g.V) {   // row-per-wavefront layout: W == 64 whatever K
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    case 12: CALL(12); break;
+    case 16: CALL(16); break;
+    default: CALL(32); break;
   }
+#undef CALL
 }
 void launch_reduce_c(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const ReduceJob j0{d.part_b, d.kvec_c, d.nb_b, 2 * g.K};

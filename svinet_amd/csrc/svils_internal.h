@@ -87,6 +87,12 @@ struct DeviceState {
   uint32_t *cls_args;             // [4] conv half, sparse flag, ltot/shist half of the classification in flight
   uint32_t *ltot;                 // [2][8] per cls_par: entries of class 0,1,2; entries with q > p of class 0,1,2
   unsigned long long *shist;      // [2][K] per cls_par: class-2 entries per community column
+  // `sum[k]` of whole sweeps driven by this library (fold): per-XCD fixed-point accumulators, [2][8][64] per cls_par.
+  // Every phi block adds its column sums with ONE 64-bit integer atomic per column (integers: associative, so the
+  // total is bit-reproducible whatever the arrival order); the finalise blocks read 8 x K words instead of folding
+  // up to 512 partial rows each.  sum[k] <= 2L, scaled by 2^fx_shift so that it fits 62 bits.
+  long long *sumfx;
+  double fx_scale, fx_inv;
   uint32_t cls_tile;              // raw entries per classification tile (a multiple of 1024)
   uint32_t cls_tile0, cls_ntiles; // tiles covering the owned entries
   uint64_t ent_pad;               // erow / col are padded to this many entries (0xffffffff)
@@ -129,6 +135,16 @@ struct DeviceState {
   double *vdot;         // [nv]  partial sum_k gamma_p gamma_q beta_k of the held-out pairs
   double *part_q2;      // [nb_c] per-block partial of this rank's outgoing Q2 contribution
   double *mphi;         // [n_alloc][ld]
+  // Whole sweeps driven by this library do not STORE the mean indicators: m = acc / tl is a function of the row the
+  // finalise pass writes anyway, gamma = (alpha + acc (n-1)/tl) * scale  =>  m = (gamma * iscale - alpha) / (n-1)
+  // (as k_expand derives it for rows another rank owns), so the s3 pass reads gamma rows and one n-by-k write per
+  // sweep disappears (the launch boundary behind the finalise pass costs ~0.6 us per MB it leaves dirty at small
+  // sizes; 4.1 GB of HBM writes per sweep at n = 1e6, k = 512).  iscale[k] = sum[k] / ones while annealing, else 1:
+  // written by the finalise pass of the sweep, so it always matches the gamma in memory.  The array is brought up
+  // to date on demand (k_mphi_from_gamma) when something wants the stored form (mini-batch steps, phase-split
+  // sweeps, svils_get_aux).
+  int derive_m;
+  double *iscale;       // [K]
   uint32_t *conv;       // [2][n_alloc]
   uint32_t *active_cnt; // [n_alloc]
   uint64_t *amask;      // [n_alloc][kw] lane-layout bitmask of _active_k
@@ -194,6 +210,8 @@ void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &
 uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K);
 uint32_t lpl_s3_threads(uint32_t K);
 uint32_t lpl_finalize_waves();
+int lpl_finalize_group(uint32_t K);
+uint32_t lpl_finalize_resident_blocks(uint32_t K, int device);
 uint32_t lpl_scatter_blocks(const DeviceState &d);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
@@ -202,6 +220,7 @@ void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hip
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s);
+void launch_mphi_from_gamma(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
                      hipStream_t s);
 bool pick_layout(uint32_t K, int *W, int *V);

@@ -192,8 +192,17 @@ __global__ __launch_bounds__(256) void k_validate_lpl(Geometry geo, DeviceState 
 // of the launch follows the number of items.  All 64 phi rows go through LDS in one pass.
 // !PIPE (K = 33..64): the row pair no longer fits beside the phi row; one item at a time, the 64
 // rows staged in two passes of 32 (half the LDS per wavefront).
+// K = 25..32 (KC = 14, 16): waves per block and waves per SIMD.  Round 2 ran them as 6-wave blocks at 3 waves/SIMD (153-168
+// VGPRs) and K = 28 / 32 were slower than K = 33; at 4 waves per block and 2 per SIMD like KC >= 18 the phi launch is 13-15 %
+// faster (profiles/r03_small_k_latency_chain.txt: ca-AstroPh K=28 37.8 -> 32.7 us, K=32 41.9 -> 35.5, LFR K=28 14.7 -> 12.7)
+#ifndef LPL_MID_NW
+#define LPL_MID_NW 4
+#endif
+#ifndef LPL_MID_OCC
+#define LPL_MID_OCC 2
+#endif
 template <int KC, int NW, bool PIPE>
-__global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? 3 : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID_OCC : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(0, 0);
   DevCtrl *ctrl = d.ctrl;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
@@ -439,76 +448,125 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? 3 : 4))
     double t = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < NW; ++w) t += red[w][threadIdx.x];
-    if (blockIdx.x == 0) t += (double)d.shist[(size_t)cpar * K + threadIdx.x];
-    d.part_a[(size_t)blockIdx.x * K + threadIdx.x] = t;
+    if (d.fold) {
+      // whole sweeps driven by the library: one fixed-point integer atomic per column into this XCD's accumulator
+      // (k_finalize_lpl adds the eight of them and the shortcut histogram)
+      const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID, bits [3:0]
+      __hip_atomic_fetch_add(&d.sumfx[((size_t)cpar * 8 + xcc) * 64 + threadIdx.x], (long long)rint(t * d.fx_scale),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (blockIdx.x == 0) t += (double)d.shist[(size_t)cpar * K + threadIdx.x];
+      d.part_a[(size_t)blockIdx.x * K + threadIdx.x] = t;
+    }
   }
 }
 
-// ======================================= node finalise (A7 + swap + A5 + A9), K <= 32
+// ======================================= node finalise (A7 + swap + A5 + A9), K <= 56
 // compute_mean_indicators (src/linksampling.cc:526-545), the gamma swap/reset (:751-755),
-// set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491), one group of W lanes per
-// owned node, lane = community.  gammanext[p] = the pieces k_phi_lpl left for the node in both
-// class lists (item order) + 1.0 per shortcut entry at its column.
+// set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491).  gammanext[p] = the pieces k_phi_lpl left
+// for the node in both class lists (item order) + 1.0 per shortcut entry at its column.
+//
+// One group of FW lanes per owned node, every lane NC communities (lw, lw + FW, ...; FW * NC >= K), so a
+// wavefront finalises 64 / FW nodes at once -- EIGHT for K <= 32 (FW = 8, NC = ceil(K / 8): 3 at K = 20, 4 at
+// K = 28).  Round 2 gave a node 32 lanes with one community each (12 of 32 idle at K = 20): on ca-AstroPh 17 903
+// nodes met 12 288 resident groups, so 46 % of the groups ran a second node behind the first one's chain of
+// dependent misses (index words -> pieces -> stores).  With eight nodes per wavefront the whole launch is ONE
+// resident round of 12-wave blocks, one per CU (so every block also folds `sum` once, not twice per CU), 20 of
+// 24 lane slots work at K = 20, and the NC digamma chains of a lane interleave.
+// The launch is a chain of cold misses (everything it reads was written by the launch before, on another XCD),
+// so accesses that do not depend on each other are issued together: the first node's index words go out before
+// anything else, its pieces before the fold of `sum` is consumed.
 template <int W>
 __device__ __forceinline__ unsigned long long group_mask() { return W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull); }
 
-// Block size of k_finalize_lpl: 80 VGPRs = 6 waves per SIMD = 24 waves per CU = two blocks of 12
-// waves (a block's waves go to the SIMDs in cyclic order, so only multiples of four waves pack; one
-// 16-wave block per CU meant a third round of node iterations for 47 of 256 blocks on ca-AstroPh).
 constexpr int FIN_THREADS = 768, FIN_WAVES = FIN_THREADS / 64;
+#ifndef FIN_OCC
+#define FIN_OCC 3
+#endif
 
-template <int W, bool STOCH>
-__global__ __launch_bounds__(FIN_THREADS, 6) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
+struct FinIdx {
+  uint32_t r[3][2];   // npos[l][p], npos[l][p + 1]
+  uint64_t rp0, rp1;  // rowptr[p], rowptr[p + 1]
+};
+__device__ __forceinline__ FinIdx fin_load_idx(const DeviceState &d, uint32_t p, bool ok) {
+  FinIdx x;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) { x.r[l][0] = ok ? d.npos[l][p] : 0u; x.r[l][1] = ok ? d.npos[l][p + 1] : 0u; }
+  x.rp0 = ok ? d.rowptr[p] : 0ull;
+  x.rp1 = ok ? d.rowptr[p + 1] : 0ull;
+  return x;
+}
+
+template <int FW, int NC, bool STOCH>
+__global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(1, 0);
   DevCtrl *ctrl = d.ctrl;
-  if (ctrl->stopped) return;
-  STAMP(1, 1);
-  constexpr int G = 64 / W;
+  constexpr int G = 64 / FW;
   __shared__ double2 logtab[128];
   __shared__ double ksum[64];
-  __shared__ double tmp[32 * 32];
-  __shared__ double s12l[FIN_WAVES][64][2];
-  __shared__ uint32_t shh[FIN_WAVES][64];   // per-group histogram of shortcut columns (G * W == 64 counters per wave)
-  load_logtab(logtab, d.logtab);
+  __shared__ double s12l[FIN_WAVES][FW][2 * NC];
+  __shared__ uint32_t shh[FIN_WAVES][G * FW * NC];   // per-group histogram of shortcut columns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int g = lane / W, lw = lane % W;
+  const int g = lane / FW, lw = lane % FW;
   const uint32_t K = geo.K, ld = geo.ld;
-  const bool annealing = ctrl->annealing != 0;
-  const bool write_comm = ctrl->write_comm != 0;
-  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
-  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
-  const uint32_t cpar = ctrl->cls_par;
-  const bool have1 = d.ltot[cpar * 8u + 1u] != 0u, have2 = d.ltot[cpar * 8u + 2u] != 0u;
+  const uint32_t nown = geo.node_end - geo.node_begin;
+  const uint32_t stride = gridDim.x * nw * G;
+  uint32_t i = (blockIdx.x * nw + wave) * G + g;
+  // nothing below depends on the control block until `scale`: the first node's index words go first
+  FinIdx ix = fin_load_idx(d, geo.node_begin + (i < nown ? i : 0u), i < nown);
+  const uint32_t stopped = ctrl->stopped, c_ann = (uint32_t)ctrl->annealing, c_wc = ctrl->write_comm, c_par = ctrl->parity;
+  // `sum` of a whole sweep (fold): the eight per-XCD fixed-point accumulators + the shortcut histogram, both halves
+  // requested now (the half in use is known once the control block has landed)
+  long long fx[2][8];
+  unsigned long long sh2[2] = {0ull, 0ull};
+  if (d.fold && threadIdx.x < 64) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) fx[h][x] = d.sumfx[((size_t)h * 8 + x) * 64 + threadIdx.x];
+      if (threadIdx.x < K) sh2[h] = d.shist[(size_t)h * K + threadIdx.x];
+    }
+  }
+  const uint32_t c_cpar = ctrl->cls_par;
+  load_logtab(logtab, d.logtab);
+  if (stopped) return;
+  STAMP(1, 1);
+  const bool annealing = c_ann != 0;
+  const bool write_comm = c_wc != 0;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)c_par * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(c_par ^ 1u) * geo.n_alloc;
   // three-launch sweeps: the s3 launch classifies the next sweep's links AND advances the control block,
   // so what the classification works from is recorded here, where the control block is at rest
   if (d.fused3 && blockIdx.x == 0 && threadIdx.x == 0) cls_record_args(d, prm, true);
   // `sum`: folded from the phi pass's per-block partial rows (block 0 also publishes it), or the
   // reduced / all-reduced vector when the caller splits the sweep at its exchange points
-  if (d.fold) {
-    if (annealing || blockIdx.x == 0) {
-      fold_rows<32, FIN_THREADS>(d.part_a, d.nb_a, K, tmp, ksum);
-      if (blockIdx.x == 0 && threadIdx.x < K) d.kvec_a[threadIdx.x] = ksum[threadIdx.x];
-    }
-  } else if (threadIdx.x < 64) {
-    ksum[threadIdx.x] = threadIdx.x < K ? d.kvec_a[threadIdx.x] : 1.0;
-  }
-  __syncthreads();
-  STAMP(1, 2);
-  const bool kval = (uint32_t)lw < K;
-  // _network.ones() / _sum[k], src/linksampling.cc:542
-  // (mini-batch step: the window's sum, scaled to an estimate of the full one)
-  const double scale = (annealing && kval) ? (double)prm.ones / (STOCH ? ksum[lw] * prm.scale_a : ksum[lw]) : 1.0;
-  double s1 = 0.0, s2 = 0.0;
+  bool kv[NC];
+#ifdef FIN_FULL_ROWS   // experiment: write whole padded rows (no partially written 128-byte line)
+#define ST(j) (ok && (uint32_t)(lw + (j) * FW) < ld)
+#else
+#define ST(j) (kv[j] && ok)
+#endif
+#pragma unroll
+  for (int j = 0; j < NC; ++j) kv[j] = (uint32_t)(lw + j * FW) < K;
+  double s1[NC], s2[NC], scale[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) { s1[j] = 0.0; s2[j] = 0.0; scale[j] = 1.0; }
 
-  const uint32_t nown = geo.node_end - geo.node_begin;
-  for (uint32_t i = (blockIdx.x * nw + wave) * G + g; i < nown; i += gridDim.x * nw * G) {
-    const uint32_t p = geo.node_begin + i;
-    const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
-    double acc = 0.0;
+  // The first round is taken by every lane (a group without a node runs it predicated off: the block's barriers
+  // and the fold need all threads); further rounds only exist on graphs of more nodes than resident groups.
+  for (bool first = true;; i += stride) {
+    const bool ok = i < nown;
+    if (!first && !__any(ok)) break;
+    const uint32_t p = geo.node_begin + (ok ? i : 0u);
+    if (!first) ix = fin_load_idx(d, p, ok);
+    const double tl = 2.0 * (double)(ix.rp1 - ix.rp0);  // quirk Q3
+    const size_t rowoff = (size_t)p * ld + lw;
+    double acc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[j] = 0.0;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      if (l == 1 && !have1) continue;
-      const uint32_t r0 = d.npos[l][p], r1 = d.npos[l][p + 1];
+      const uint32_t r0 = ix.r[l][0], r1 = ix.r[l][1];
       if (r1 > r0) {
         const double *sf = d.slot_f + (size_t)l * d.lpl_nitems * ld, *sl = d.slot_l + (size_t)l * d.lpl_nitems * ld;
         const double *direct = l ? d.gacc1 : d.gacc;
@@ -517,123 +575,203 @@ __global__ __launch_bounds__(FIN_THREADS, 6) void k_finalize_lpl(Geometry geo, D
           const double *src = ((r0 & 63u) == 0u) ? sf + (size_t)w0 * ld
                               : (((r1 - 1u) & 63u) == 63u) ? sl + (size_t)w0 * ld
                                                            : direct + (size_t)p * ld;
-          acc += src[lw];
-        } else {
-          // a hub's run spans many items: four pieces in flight at a time, added in item order
-          for (uint32_t wb = w0; wb <= w1; wb += 4) {
-            double pv[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) {
+          for (int j = 0; j < NC; ++j) acc[j] += kv[j] ? src[lw + j * FW] : 0.0;
+        } else {
+          // a hub's run spans many items: HP pieces in flight at a time, added in item order
+          constexpr uint32_t HP = NC >= 4 ? 1 : 2;
+#pragma unroll 1
+          for (uint32_t wb = w0; wb <= w1; wb += HP) {
+            double pv[HP][NC];
+#pragma unroll
+            for (uint32_t t = 0; t < HP; ++t) {
               const uint32_t w = wb + t;
               const double *src = (w == w0 && (r0 & 63u) != 0u) ? sl : sf;
-              pv[t] = w <= w1 ? src[(size_t)w * ld + lw] : 0.0;
+#pragma unroll
+              for (int j = 0; j < NC; ++j) pv[t][j] = (w <= w1 && kv[j]) ? src[(size_t)w * ld + lw + j * FW] : 0.0;
             }
 #pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) acc += pv[t];
+            for (uint32_t t = 0; t < HP; ++t)
+#pragma unroll
+              for (int j = 0; j < NC; ++j) acc[j] += pv[t][j];
           }
         }
       }
     }
-    if (have2) {   // exactly-one-converged links: +1 at the converged community (:622-631)
-      const uint32_t c0 = d.npos[2][p], c1 = d.npos[2][p + 1];
-      if (__any(c1 > c0)) {
-        // W entries at a time per group, counted with integer LDS atomics (order-free)
-        uint32_t *hh = &shh[wave][g * W];
-        hh[lw] = 0;
-        for (uint32_t jb = c0 + (uint32_t)lw; jb < c1; jb += 4 * W) {   // four loads in flight per lane
+    {   // exactly-one-converged links: +1 at the converged community (:622-631)
+      const uint32_t e0 = ix.r[2][0], e1 = ix.r[2][1];
+      if (__any(e1 > e0)) {
+        // FW entries at a time per group, counted with integer LDS atomics (order-free)
+        uint32_t *hh = &shh[wave][g * FW * NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) hh[lw + j * FW] = 0;
+        for (uint32_t jb = e0 + (uint32_t)lw; jb < e1; jb += 4 * FW) {   // four loads in flight per lane
           uint32_t cv[4];
 #pragma unroll
-          for (uint32_t t = 0; t < 4; ++t) cv[t] = (jb + t * W < c1) ? (uint32_t)d.scol[jb + t * W] : 0xffffu;
+          for (uint32_t t = 0; t < 4; ++t) cv[t] = (jb + t * FW < e1) ? (uint32_t)d.scol[jb + t * FW] : 0xffffu;
 #pragma unroll
           for (uint32_t t = 0; t < 4; ++t)
-            if (cv[t] != 0xffffu) atomicAdd(&hh[cv[t] % W], 1u);
+            if (cv[t] != 0xffffu) atomicAdd(&hh[cv[t] % (FW * NC)], 1u);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        acc += (double)hh[lw];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc[j] += (double)hh[lw + j * FW];
       }
     }
-    if (write_comm) {
-      unsigned long long b;
+    unsigned long long memb = 0ull;
+    uint32_t fc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) fc[j] = 0;
+    if (write_comm && ok) {
       if (d.fcnt) {
-        uint32_t c = 0;
-        if (kval) { c = d.fcnt[(size_t)p * ld + lw]; d.fcnt[(size_t)p * ld + lw] = 0; }
-        b = (__ballot(kval && c > prm.lt_min_deg) >> (g * W)) & group_mask<W>();
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (kv[j]) fc[j] = d.fcnt[rowoff + j * FW];
       } else {
-        b = d.member_acc[p];
+        memb = d.member_acc[p];
       }
-      if (lw == 0) {
+    }
+    double sold[STOCH ? NC : 1], gold[STOCH ? NC : 1];
+    uint32_t ncnt = 0;
+    if constexpr (STOCH) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) { sold[j] = 0.0; gold[j] = 0.0; }
+      if (tl > 0.0 && ok) {
+        ncnt = d.ncnt[p];
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (kv[j]) { gold[j] = d.gamma[rowoff + j * FW]; sold[j] = d.mphi[rowoff + j * FW]; }
+      }
+    }
+    if (first) {
+      // everything the first node needs is in flight; now `sum`
+      if (threadIdx.x < 64) {
+        double t = 1.0;
+        if (d.fold) {
+          long long a = 0;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) a += fx[c_cpar & 1u][x];
+          t = (double)a * d.fx_inv + (double)sh2[c_cpar & 1u];
+          if (blockIdx.x == 0 && threadIdx.x < K) d.kvec_a[threadIdx.x] = t;
+        } else if (threadIdx.x < K) {
+          t = d.kvec_a[threadIdx.x];
+        }
+        ksum[threadIdx.x] = threadIdx.x < K ? t : 1.0;
+        // 1 / scale of this sweep, for whoever derives the mean indicators from the gamma rows written below
+        if (blockIdx.x == 0 && threadIdx.x < K) d.iscale[threadIdx.x] = annealing ? (STOCH ? t * prm.scale_a : t) / (double)prm.ones : 1.0;
+      }
+      __syncthreads();   // ksum, the log table
+      STAMP(1, 2);
+      // _network.ones() / _sum[k], src/linksampling.cc:542
+      // (mini-batch step: the window's sum, scaled to an estimate of the full one)
+      if (annealing) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (kv[j]) scale[j] = (double)prm.ones / (STOCH ? ksum[lw + j * FW] * prm.scale_a : ksum[lw + j * FW]);
+      }
+      first = false;
+    }
+    if (write_comm) {
+      unsigned long long b = memb;
+      if (d.fcnt) {
+        b = 0ull;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          if (kv[j] && ok) d.fcnt[rowoff + j * FW] = 0;
+          b |= ((__ballot(kv[j] && fc[j] > prm.lt_min_deg) >> (g * FW)) & group_mask<FW>()) << (j * FW);
+        }
+      }
+      if (lw == 0 && ok) {
         d.member[(size_t)p * geo.kw] = b;
         if (!d.fcnt) d.member_acc[p] = 0ull;
       }
     }
-    double gn, m = 0.0;
+    double gn[NC], m[NC];
     if (tl > 0.0) {
-      const double g0 = prm.alpha + acc;
-      m = (g0 - prm.alpha) / tl;
-      gn = g0 + ((double)geo.n - tl - 1.0) * m;
-      if (annealing) gn *= scale;
-      if (kval) { s1 += m; s2 += m * m; }
-      else { m = 0.0; gn = 0.0; }
+      const double nl = (double)geo.n - tl - 1.0;
+      double rho = 0.0;
       if constexpr (STOCH) {
         // Robbins-Monro step of this node: gamma <- (1 - rho) gamma + rho gamma_hat with
         // rho = (tau0 + c)^-kappa, c = updates the node has had; s1/s2 are kept as running sums
         // over the stored mphi rows, so this row contributes (new - old)
-        const uint32_t c = d.ncnt[p];
-        const double rho = exp_neg(-prm.kappa * log_tab(prm.tau0 + (double)c, logtab));
-        if (kval) {
-          const double gold = d.gamma[(size_t)p * ld + lw], mold = d.mphi[(size_t)p * ld + lw];
-          gn = (1.0 - rho) * gold + rho * gn;
-          s1 -= mold;
-          s2 -= mold * mold;
-        }
-        if (lw == 0) d.ncnt[p] = c + 1u;
+        rho = exp_neg(-prm.kappa * log_tab(prm.tau0 + (double)ncnt, logtab));
+        if (lw == 0 && ok) d.ncnt[p] = ncnt + 1u;
       }
-      if (kval) d.mphi[(size_t)p * ld + lw] = m;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const double g0 = prm.alpha + acc[j];
+        m[j] = (g0 - prm.alpha) / tl;
+        gn[j] = g0 + nl * m[j];
+        if (annealing) gn[j] *= scale[j];
+        if (!kv[j]) { m[j] = 0.0; gn[j] = 0.0; }
+        if (kv[j] && ok) { s1[j] += m[j]; s2[j] += m[j] * m[j]; }
+        if constexpr (STOCH) {
+          if (kv[j]) gn[j] = (1.0 - rho) * gold[j] + rho * gn[j];
+          if (kv[j] && ok) { s1[j] -= sold[j]; s2[j] -= sold[j] * sold[j]; }
+        }
+        if ((STOCH || !d.derive_m) && ST(j)) d.mphi[rowoff + j * FW] = m[j];
+      }
     } else {
       // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
-      gn = kval ? prm.alpha : 0.0;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) { gn[j] = kv[j] ? prm.alpha : 0.0; m[j] = 0.0; }
     }
-    if (kval) d.gamma[(size_t)p * ld + lw] = gn;   // padding columns stay 0
-    double rs = group_sum<W>(gn);
-    double el;
-    if (K < (uint32_t)W) {
-      // lane K of the group is idle: let it evaluate psi(row sum) in the same digamma call
-      const double arg = ((uint32_t)lw == K) ? rs : (kval ? gn : 1.0);
-      const double ps = digamma(arg, logtab);
-      const double psi_rs = __shfl(ps, g * W + (int)K, 64);
-      el = kval ? ps - psi_rs : 0.0;
-    } else {
-      const double psi_rs = digamma(rs, logtab);
-      el = kval ? digamma(gn, logtab) - psi_rs : 0.0;
+    double rsl = 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (ST(j)) d.gamma[rowoff + j * FW] = gn[j];   // padding columns stay 0
+      rsl += gn[j];
     }
-    if (kval) d.elogpi[(size_t)p * ld + lw] = el;
-    // prune / check_and_set_converged, src/linksampling.cc:455-475
-    const bool act = kval && (gn - prm.alpha >= 1.0);
-    const unsigned long long bits = (__ballot(act) >> (g * W)) & group_mask<W>();
+    const double rs = group_sum<FW>(rsl);
+    // A slot above K is idle when K < FW * NC: lane FW - 1 evaluates psi(row sum) in its last slot, in the same
+    // digamma call as the last community of the other lanes; a full row (K == FW * NC) takes one more call
+    double ps[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      double arg = kv[j] ? gn[j] : 1.0;
+      if (j == NC - 1 && lw == FW - 1 && K < (uint32_t)(FW * NC)) arg = rs;
+      ps[j] = digamma(arg, logtab);
+    }
+    double psi_rs;
+    if (K < (uint32_t)(FW * NC)) psi_rs = __shfl(ps[NC - 1], g * FW + FW - 1, 64);
+    else psi_rs = digamma(rs, logtab);
+    unsigned long long bits = 0ull;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (ST(j)) d.elogpi[rowoff + j * FW] = kv[j] ? ps[j] - psi_rs : 0.0;
+      // prune / check_and_set_converged, src/linksampling.cc:455-475
+      bits |= ((__ballot(kv[j] && (gn[j] - prm.alpha >= 1.0)) >> (g * FW)) & group_mask<FW>()) << (j * FW);
+    }
     const uint32_t active = (uint32_t)__popcll(bits);
-    if (lw == 0) {
+    if (lw == 0 && ok) {
       const uint32_t cnew = (active == 1) ? (uint32_t)(63 - __builtin_clzll(bits)) + 1u : conv_old[p];
       const unsigned long long am = (active <= geo.k10) ? bits : 0ull;
       conv_new[p] = cnew;
       d.active_cnt[p] = active;
       d.amask[(size_t)p * geo.kw] = am;
+#ifndef FIN_SKIP_XFLAGS   // timing experiment only
       uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;   // the same flags, packed for the node-block exchange
       xf[0] = cnew; xf[1] = active; xf[2] = (uint32_t)am; xf[3] = (uint32_t)(am >> 32);
+#endif
     }
   }
   STAMP(1, 3);
-  // per-block partials of s1, s2: waves in order, then the groups of a wave in order
-  s12l[wave][lane][0] = s1;
-  s12l[wave][lane][1] = s2;
+  // per-block partials of s1, s2: the groups of a wave (butterfly over the group index), then the waves in order
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+#pragma unroll
+    for (int o = FW; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    if (lane < FW) { s12l[wave][lane][j] = s1[j]; s12l[wave][lane][NC + j] = s2[j]; }
+  }
   __syncthreads();
   if (threadIdx.x < 128) {
     const uint32_t which = threadIdx.x >> 6, k = threadIdx.x & 63u;
     if (k < K) {
+      const int kl = (int)k % FW, ks = (int)k / FW;
       double t = 0.0;
-      for (int w = 0; w < nw; ++w)
-        for (int gg = 0; gg < G; ++gg) t += s12l[w][gg * W + (int)k][which];
+      for (int w = 0; w < nw; ++w) t += s12l[w][kl][which * NC + ks];
       d.part_b[(size_t)blockIdx.x * 2 * K + which * K + k] = t;
     }
   }
@@ -852,6 +990,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
       __syncthreads();
       if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
       if (threadIdx.x < K) d.shist[(size_t)cpar0 * K + threadIdx.x] = 0ull;
+      if (threadIdx.x < 512) d.sumfx[(size_t)cpar0 * 512 + threadIdx.x] = 0;
       STAMP(2, 5);
     }
   }
@@ -873,8 +1012,8 @@ bool use_lpl(uint32_t K) { return K <= 56; }
 #define LPL_PIPE 0
 #endif
 constexpr bool lpl_pipe(int kc) { return LPL_PIPE && kc <= 16; }
-constexpr int lpl_waves(int kc) { return lpl_pipe(kc) ? LPL_PIPE_WAVES : kc >= 18 ? 4 : kc >= 14 ? 6 : 8; }
-int lpl_phi_waves(uint32_t K) { return LPL_PIPE && K <= 32 ? LPL_PIPE_WAVES : K > 32 ? 4 : K > 24 ? 6 : 8; }
+constexpr int lpl_waves(int kc) { return lpl_pipe(kc) ? LPL_PIPE_WAVES : kc >= 18 ? 4 : kc >= 14 ? LPL_MID_NW : 8; }
+int lpl_phi_waves(uint32_t K) { return LPL_PIPE && K <= 32 ? LPL_PIPE_WAVES : K > 32 ? 4 : K > 24 ? LPL_MID_NW : 8; }
 
 #define LPL_DISPATCH(K_, CALL)                 \
   do {                                         \
@@ -951,16 +1090,39 @@ void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hi
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }
-void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-#define FIN(W_)                                                                                     \
-  do {                                                                                              \
-    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, true>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p); \
-    else hipLaunchKernelGGL((k_finalize_lpl<W_, false>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p);  \
+// lanes per node in k_finalize_lpl (every lane ceil(K / lanes) communities) -> nodes per wavefront
+int lpl_finalize_group(uint32_t K) { return K <= 32 ? 8 : 16; }
+#ifdef FIN_FULL_ROWS
+#define FIN_NC3_MAXK 16
+#else
+#define FIN_NC3_MAXK 24
+#endif
+#define FIN_DISPATCH(K_, FIN)        \
+  do {                               \
+    if ((K_) <= 8) FIN(8, 1);        \
+    else if ((K_) <= 16) FIN(8, 2);  \
+    else if ((K_) <= FIN_NC3_MAXK) FIN(8, 3);  \
+    else if ((K_) <= 32) FIN(8, 4);  \
+    else if ((K_) <= 48) FIN(16, 3); \
+    else FIN(16, 4);                 \
   } while (0)
-  if (g.W == 8) FIN(8);
-  else if (g.W == 16) FIN(16);
-  else if (g.W == 32) FIN(32);
-  else FIN(64);
+// blocks of k_finalize_lpl the device holds at once (the full-sweep instantiation)
+uint32_t lpl_finalize_resident_blocks(uint32_t K, int device) {
+  int per_cu = 0, cus = 0;
+#define FIN(W_, NC_) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_finalize_lpl<W_, NC_, false>, FIN_THREADS, 0)
+  FIN_DISPATCH(K, FIN);
+#undef FIN
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (per_cu <= 0 || cus <= 0) return 256u;
+  return (uint32_t)per_cu * (uint32_t)cus;
+}
+void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+#define FIN(W_, NC_)                                                                                \
+  do {                                                                                              \
+    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, true>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p); \
+    else hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p);  \
+  } while (0)
+  FIN_DISPATCH(g.K, FIN);
 #undef FIN
 }
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
