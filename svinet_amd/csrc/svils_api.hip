@@ -59,6 +59,7 @@ struct svils_handle {
   // lane-per-link layout: the link classes on the device describe the sweep about to run (k_s3_lpl
   // refreshes them for the next sweep); cleared whenever flags / _iter / the window change under them
   bool cls_valid = false;
+  bool cflag_dirty = true;        // the host wrote converged flags (or nothing has yet): rebuild cflag[] before classifying
   bool derive_ok = true;          // SVILS_DERIVE_M=0 keeps the stored mean indicators everywhere (A/B knob)
   bool mphi_stale = false;        // whole sweeps (derive_m) left the stored mean indicators behind gamma: k_mphi_from_gamma on demand
   bool v_flush_needed = false;   // a three-launch sweep left its likelihood row / stop rule to the next launch
@@ -163,6 +164,10 @@ int fault_error(uint32_t code) {
 // (re)classify the links of the sweep about to run from the flags as they stand
 int classify_now(svils_handle *h, const Geometry &g, const DeviceState &d, const Params &prm) {
   Timed t(h, SVILS_KERNEL_CLASSIFY);
+  if (h->cflag_dirty) {
+    launch_cflag_rebuild(h->geo, h->d, h->stream);
+    h->cflag_dirty = false;
+  }
   HIPCHK(hipMemsetAsync(h->cls_zero, 0, h->cls_zero_bytes, h->stream));
   launch_classify(g, d, prm, h->stream);
   return 0;
@@ -391,6 +396,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.mphi, nk));
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
   guard(dalloc(h, &d.active_cnt, g.n_alloc));
+  guard(dalloc(h, &d.cflag, g.n_alloc));
   guard(dalloc(h, &d.amask, (size_t)g.n_alloc * g.kw));
   guard(dalloc(h, &d.member, (size_t)g.n_alloc * g.kw));
   d.xf_ld = 2u + 2u * g.kw;
@@ -1098,6 +1104,7 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   h->cls_valid = false;   // the converged flags changed under the link classes
+  h->cflag_dirty = true;
   h->have_state = true;
   return 0;
 }

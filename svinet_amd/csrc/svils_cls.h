@@ -26,15 +26,16 @@ struct ClsWork {
 };
 
 // class of the CSR entry (p, q): 0 softmax, 1 active-set softmax, 2 exactly one endpoint converged
-__device__ __forceinline__ int classify_entry(const uint32_t *__restrict__ conv, const uint32_t *__restrict__ active,
-                                              uint32_t k10, bool sparse_iter, uint32_t p, uint32_t q, uint32_t *col2) {
-  const uint32_t pc = conv[p], qc = conv[q];
+__device__ __forceinline__ int classify_entry(const uint32_t *__restrict__ cflag, bool sparse_iter, uint32_t p, uint32_t q,
+                                              uint32_t *col2) {
+  const uint32_t fp = cflag[p], fq = cflag[q];   // converged flag | "active_cnt < K / 10" << 31 (svils_internal.h)
+  const uint32_t pc = fp & 0x7fffffffu, qc = fq & 0x7fffffffu;
   if ((pc != 0) != (qc != 0)) {          // :622-631
     *col2 = (pc ? pc : qc) - 1u;
     return 2;
   }
   *col2 = 0;
-  return (sparse_iter && active[p] < k10 && active[q] < k10) ? 1 : 0;   // :634
+  return (sparse_iter && ((fp & fq) >> 31)) ? 1 : 0;   // :634
 }
 
 // next = false: classes of the sweep about to run (flags conv[parity], _iter);
@@ -97,7 +98,7 @@ __device__ __forceinline__ void cls_count_tiles(const Geometry &geo, const Devic
           const uint64_t e = e0 + j;
           if (e >= eb && e < ee) {
             uint32_t c2;
-            const int c = classify_entry(conv, d.active_cnt, geo.k10, sparse_iter, pp[j], qq[j], &c2);
+            const int c = classify_entry(d.cflag, sparse_iter, pp[j], qq[j], &c2);
             n01 += (c == 0 ? (1ull << 32) : 0ull) + (c == 1 ? 1ull : 0ull);
             if (qq[j] > pp[j]) up[c]++;
             if (c == 2) atomicAdd(&sh.hist[c2 & 63u], 1u);
@@ -200,7 +201,7 @@ __device__ __forceinline__ void cls_scatter_tiles(const Geometry &geo, const Dev
         for (int j = 0; j < 4; ++j) {
           const uint64_t e = e0 + j;
           if (e >= eb && e < ee) {
-            cls[j] = classify_entry(conv, d.active_cnt, geo.k10, sparse_iter, pp[j], qq[j], &c2[j]);
+            cls[j] = classify_entry(d.cflag, sparse_iter, pp[j], qq[j], &c2[j]);
             n01 += (cls[j] == 0 ? 1u : 0u) + (cls[j] == 1 ? 0x10000u : 0u);
           }
         }
@@ -366,7 +367,7 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
         const uint64_t e = e0 + j;
         if (e >= eb && e < ee) {
           uint32_t c2;
-          const int cl = classify_entry(conv, d.active_cnt, geo.k10, sparse_iter, pp[t][j], qq[t][j], &c2);
+          const int cl = classify_entry(d.cflag, sparse_iter, pp[t][j], qq[t][j], &c2);
           cc[t][j] = (uint32_t)cl | (c2 << 2);
           n01[t] += (cl == 0 ? 1u : 0u) + (cl == 1 ? 0x10000u : 0u);
           if (qq[t][j] > pp[t][j]) up[cl]++;

@@ -579,6 +579,7 @@ __device__ __forceinline__ void unpack_flags(const Geometry &geo, const DeviceSt
   const uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;
   d.conv[(size_t)(ctrl->parity ^ 1u) * geo.n_alloc + p] = xf[0];
   d.active_cnt[p] = xf[1];
+  d.cflag[p] = xf[0] | (xf[1] < geo.k10 ? 0x80000000u : 0u);
 #pragma unroll
   for (int v = 0; v < V; ++v)
     d.amask[(size_t)p * geo.kw + v] = (unsigned long long)xf[2 + 2 * v] | ((unsigned long long)xf[3 + 2 * v] << 32);
@@ -634,6 +635,17 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
     store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
   }
+}
+
+// cflag[] from conv[parity] and active_cnt[] as they stand (after the host replaced the flags)
+__global__ __launch_bounds__(256) void k_cflag_rebuild(Geometry geo, DeviceState d) {
+  const uint32_t *__restrict__ conv = d.conv + (size_t)d.ctrl->parity * geo.n_alloc;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < geo.n; p += gridDim.x * blockDim.x)
+    d.cflag[p] = conv[p] | (d.active_cnt[p] < geo.k10 ? 0x80000000u : 0u);
+}
+void launch_cflag_rebuild(const Geometry &g, const DeviceState &d, hipStream_t s) {
+  const uint32_t nb = std::min<uint32_t>((g.n + 255u) / 256u, 1024u);
+  hipLaunchKernelGGL(k_cflag_rebuild, dim3(nb ? nb : 1), dim3(256), 0, s, g, d);
 }
 
 // The stored form of the mean indicators, brought up to date from the gamma rows of the last whole sweep (derive_m):

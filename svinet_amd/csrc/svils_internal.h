@@ -147,6 +147,10 @@ struct DeviceState {
   double *iscale;       // [K]
   uint32_t *conv;       // [2][n_alloc]
   uint32_t *active_cnt; // [n_alloc]
+  // What the link classification needs of an endpoint, in ONE word: the latest converged flag (what prune() wrote last)
+  // | 0x80000000 when active_cnt < K / 10.  Written next to conv / active_cnt by whoever writes those; a second random
+  // gather per endpoint (active_cnt) cost the classification passes 4 us per sweep on ca-AstroPh once _iter > 1000.
+  uint32_t *cflag;      // [n_alloc]
   uint64_t *amask;      // [n_alloc][kw] lane-layout bitmask of _active_k
   uint64_t *member;     // [n_alloc][kw] lane-layout bitmask of communities
   uint32_t *xflags;     // [n_alloc][xf_ld] conv (new), active_cnt, amask words of every row, packed: ONE buffer to
@@ -220,6 +224,7 @@ void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hip
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s);
+void launch_cflag_rebuild(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_mphi_from_gamma(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,
                      hipStream_t s);

@@ -279,7 +279,69 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID
     double *mine = mylds + (lane % RP) * SROW;   // this lane's staged phi row
     int tagk = -1;   // community this link tags (src/linksampling.cc:668-681,704-717), -1: none
     bool dense_row = false;
-    if (valid) {
+    // active-set path (:634-681): a list of its own, so the branch is wave-uniform.  Only the columns of the union of
+    // the two active sets exist for such a link -- at most NU = 2 * (K / 10) of them (4 of 20 at K = 20) -- and only
+    // those are fetched (8 bytes each from the two rows), exponentiated and written into the otherwise zero staged row.
+    constexpr int NU = 2 * (KR / 10) > 0 ? 2 * (KR / 10) : 1;
+    if (list) {
+      double su[NU];
+      int ku[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { su[u] = NEG_INF; ku[u] = -1; }
+      if (valid) {
+        unsigned long long um = d.amask[p] | d.amask[q];   // kw == 1 for K <= 64; <= 2 * k10 bits
+        const double *rp = elogpi + (size_t)p * ld, *rq = elogpi + (size_t)q * ld;
+        double xa[NU], xb[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          xa[u] = 0.0; xb[u] = 0.0;
+          if (um) {
+            const int k = __builtin_ctzll(um);
+            um &= um - 1ull;
+            ku[u] = k;
+            xa[u] = rp[k];
+            xb[u] = rq[k];
+          }
+        }
+        double m = NEG_INF;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (ku[u] >= 0) su[u] = (xa[u] + xb[u]) + eb[ku[u]];   // the reference's order (:686)
+          m = max_f64(m, su[u]);
+        }
+        if (m != NEG_INF) {
+          dense_row = true;
+          int best = 0;
+#pragma unroll
+          for (int u = NU - 1; u >= 0; --u) best = (su[u] == m) ? ku[u] : best;   // first strict maximum (ascending k)
+          double ssum = 0.0;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) su[u] -= m;
+          if constexpr (NU % 2 == 0) {
+#pragma unroll
+            for (int u0 = 0; u0 < NU; u0 += 2) {
+              double t[2] = {su[u0], su[u0 + 1]};
+              exp_neg_n<2>(t);   // exp_neg(-inf) == 0 for the unused slots
+              su[u0] = t[0]; su[u0 + 1] = t[1];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) su[u] = exp_neg(su[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < NU; ++u) ssum += su[u];
+          const double inv = fast_rcp(ssum);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) su[u] *= inv;
+          if (write_comm && inv > prm.link_thresh) tagk = best;
+        }
+      }
+      // kept in the phi registers until the row is staged (values, then their column ids as bit patterns): the two
+      // paths share one set of live registers
+      static_assert(KR >= 2 * NU, "phi row too short for the packed active-set form");
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { phi[u] = su[u]; phi[NU + u] = __hiloint2double(0, ku[u]); }
+    } else if (valid) {
       // x_k = (Elogpi[p][k] + Elogpi[q][k]) + Elogbeta[k][0], the reference's order (:686)
       if constexpr (PIPE) {
 #pragma unroll
@@ -298,20 +360,14 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID
         }
       }
     }
-    unsigned long long inmask = ~0ull;
-    if (list && valid) inmask = d.amask[p] | d.amask[q];   // kw == 1 for K <= 64
     if constexpr (PIPE) {
       // the row registers are free again: rows of the next item, index pair of the one after it
       fetch_rows(pn, qn, ra, rb);
     }
     uint32_t pnn = 0xffffffffu, qnn = 0;
     if constexpr (PIPE) fetch_idx(it + 2 * step, pnn, qnn);
-    if (valid) {
+    if (valid && !list) {
       dense_row = true;
-      if (list) {   // active-set path (:634-681): columns outside the union of the two active sets drop out
-#pragma unroll
-        for (int k = 0; k < KR; ++k) phi[k] = ((inmask >> k) & 1ull) ? phi[k] : NEG_INF;
-      }
       // branch-free from here so the KR independent exp chains interleave
       double m = NEG_INF;
 #pragma unroll
@@ -343,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID
         if (write_comm && inv > prm.link_thresh) tagk = best;
         STAMP(0, 6);
       } else {
-        dense_row = false;  // empty active-set union (:642-664): the row is zero
+        dense_row = false;  // cannot happen on the dense path (every x_k is finite); kept as the guard it was
       }
     }
     // Stage the phi rows in LDS and let lane k sum column k over them in entry order, flushing at
@@ -391,12 +447,19 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       if (NPASS == 1 || (lane >> 5) == pass) {
-        if (dense_row) {
+        if (dense_row && !list) {
 #pragma unroll
           for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(phi[2 * c], phi[2 * c + 1]);
         } else {
 #pragma unroll
           for (int c = 0; c < KC; ++c) *reinterpret_cast<double2 *>(mine + 2 * c) = make_double2(0.0, 0.0);
+          if (list && dense_row) {   // the union's columns into the zero row (same lane, LDS in order)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+              const int k = __double2loint(phi[NU + u]);
+              if (k >= 0) mine[k] = phi[u];
+            }
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -750,6 +813,7 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
       const unsigned long long am = (active <= geo.k10) ? bits : 0ull;
       conv_new[p] = cnew;
       d.active_cnt[p] = active;
+      d.cflag[p] = cnew | (active < geo.k10 ? 0x80000000u : 0u);
       d.amask[(size_t)p * geo.kw] = am;
 #ifndef FIN_SKIP_XFLAGS   // timing experiment only
       uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;   // the same flags, packed for the node-block exchange
