@@ -300,7 +300,11 @@ typedef enum {
   SVILS_KPHASE_INIT_ROWS = 5, SVILS_KPHASE_INIT_EXPAND = 6,
   SVILS_KPHASE_DENMAX = 7   /* log-domain mode only: before DEN, followed by a MAX (not SUM) of SVILS_KSH_DMAX */
 } svils_kphase;
-typedef enum { SVILS_KSH_DEN = 0, SVILS_KSH_ROWX = 1, SVILS_KSH_Q2 = 2, SVILS_KSH_VDOT = 3, SVILS_KSH_DMAX = 4 } svils_ksh_buffer;
+typedef enum { SVILS_KSH_DEN = 0, SVILS_KSH_ROWX = 1, SVILS_KSH_Q2 = 2, SVILS_KSH_VDOT = 3, SVILS_KSH_DMAX = 4,
+               /* link_thresh < 1/2 only (argmax tagging, src/linksampling.cc:704-717, src/matrix.hh:521-532): the lowest
+                * column attaining the link's maximum, as a double; exchanged with MIN right after SVILS_KSH_DEN.  Such
+                * handles always run the log-domain exchange (the maximum is what SVILS_KSH_DMAX carries). */
+               SVILS_KSH_EARG = 5 } svils_ksh_buffer;
 int svils_ksweep_phase(svils_handle *h, svils_kphase phase);
 /* device pointer and length (doubles) of an exchange buffer */
 int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, size_t *ndoubles);

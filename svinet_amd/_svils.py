@@ -146,7 +146,7 @@ def comm_unique_id():
     return buf.raw
 PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND = range(5)
 KPHASE_DEN, KPHASE_PHI, KPHASE_FIN, KPHASE_LAMBDA, KPHASE_STOP, KPHASE_INIT_ROWS, KPHASE_INIT_EXPAND, KPHASE_DENMAX = range(8)
-KSH_DEN, KSH_ROWX, KSH_Q2, KSH_VDOT, KSH_DMAX = range(5)
+KSH_DEN, KSH_ROWX, KSH_Q2, KSH_VDOT, KSH_DMAX, KSH_EARG = range(6)
 
 
 class Engine:

@@ -69,6 +69,12 @@ struct svils_handle {
   // native multi-GPU driver (svils_comm_init)
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  // node-block sweeps: the row exchange runs on a stream of its own, in chunks, and the rows of a chunk are expanded
+  // (k_expand) on the compute stream while the next chunk travels
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready = nullptr;               // phase B done: the rows may leave
+  std::vector<hipEvent_t> ev_chunk;            // chunk c has arrived
+  uint32_t xchunks = 0;                        // 0: chosen from the payload (SVILS_XCHUNKS overrides)
   unsigned char *stage = nullptr;   // device staging of svils_comm_allgather_host: world x stage_bytes, grown collectively
   size_t stage_bytes = 0;
   uint32_t *stage_flag = nullptr;   // device word: "my allocation failed", summed over the ranks
@@ -346,10 +352,6 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
       delete h;
       return fail(SVILS_ERR_ARG, "K-sharded handle: need k_begin + k <= k_total <= %d and the node block [0, n)", SVILS_MAX_K);
     }
-    if (cfg->link_thresh < 0.5) {
-      delete h;
-      return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handle: link_thresh < 1/2 needs the argmax over all columns of a link (node-block sharding has it)");
-    }
     g.K0 = cfg->k_begin;
     g.Kt = cfg->k_total;
     g.k10 = cfg->k_total / 10;
@@ -384,6 +386,11 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   // beyond it their phi pass runs at the HBM gather ceiling either way and the extra write costs more than the exps.
   d.ksh = cfg->k_total ? 1 : 0;
   d.ksh_log = cfg->k_total > 700 ? 1 : 0;   // psi(1/K) < -745: concentrated memberships underflow the product form
+  // link_thresh < 1/2: a phi above the threshold need not be the maximum, so the tag goes to the first strict maximum
+  // over ALL columns (src/matrix.hh:521-532).  The log-domain exchange already carries the link's maximum; the lowest
+  // column attaining it travels next to the denominators (SVILS_KSH_EARG, MIN) -- no further pass over the rows.
+  d.ksh_lowt = (d.ksh && cfg->link_thresh < 0.5) ? 1 : 0;
+  if (d.ksh_lowt) d.ksh_log = 1;
   if (const char *e = getenv("SVILS_DERIVE_M")) h->derive_ok = atoi(e) != 0;
   const bool whole_graph = g.node_begin == 0 && g.node_end == g.n;
   uint64_t epi_max_mb = (whole_graph && h->derive_ok) ? ~0ull >> 21 : 1536;
@@ -531,6 +538,7 @@ int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
   NCCLCHK(g_rccl.CommInitRank(&h->comm, world, id, rank));
   h->rank = rank;
   h->world = world;
+  if (const char *e = getenv("SVILS_XCHUNKS")) h->xchunks = (uint32_t)std::max(0, atoi(e));   // chunks of the pipelined row exchange
   return 0;
 }
 
@@ -562,6 +570,61 @@ int exchange_rows(svils_handle *h) {
   NCCLCHK(g_rccl.AllGather(d.gamma + (size_t)h->rank * B * g.ld, d.gamma, B * g.ld, ncclDouble, h->comm, h->stream));
   NCCLCHK(g_rccl.AllGather(d.xflags + (size_t)h->rank * B * d.xf_ld, d.xflags, B * d.xf_ld, ncclUint32, h->comm, h->stream));
   NCCLCHK(g_rccl.GroupEnd());
+  return 0;
+}
+
+// chunks of the pipelined row exchange: one (the grouped all-gather above) while the whole n-by-k payload is small,
+// up to eight of >= 64 MB each beyond that
+uint32_t exchange_chunks(const svils_handle *h) {
+  if (h->xchunks) return h->xchunks;
+  const uint64_t bytes = (uint64_t)h->geo.n_alloc * h->geo.ld * sizeof(double);
+  return (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, bytes / (128ull << 20)));
+}
+
+// Phase B -> [row exchange || PHASE_EXPAND] -> phase C of a node-block sweep.  The gamma rows and packed flags of every
+// rank's node block travel in C chunks on the communication stream (chunk c = rows [c B / C, (c+1) B / C) of EVERY
+// block: one grouped launch of world x 2 in-place broadcasts, rank r the root of its own rows); as soon as chunk c has
+// arrived the compute stream re-derives Elogpi / exp(Elogpi) / mphi / flags of those rows (k_expand: n k digammas in
+// total, ~1 ms at n = 1e6, k = 512) while chunk c + 1 is on the links.  Exposed: the first chunk's transfer and the
+// last chunk's expansion instead of the whole gather followed by the whole expansion.
+int exchange_rows_and_expand(svils_handle *h) {
+  const uint32_t C = h->comm ? exchange_chunks(h) : 1u;
+  if (C <= 1) {
+    int rc = exchange_rows(h);
+    if (rc) return rc;
+    return run_phase(h, SVILS_PHASE_EXPAND, false);
+  }
+  const Geometry &g = h->geo;
+  const DeviceState &d = h->d;
+  const uint32_t B = g.n_alloc / (uint32_t)h->world;
+  if (!h->comm_stream) HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  if (!h->ev_ready) HIPCHK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+  while (h->ev_chunk.size() < C) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->ev_chunk.push_back(e);
+  }
+  Timed t(h, SVILS_KERNEL_EXCHANGE);   // on the compute stream: from "rows may leave" to "last chunk expanded"
+  HIPCHK(hipEventRecord(h->ev_ready, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+  for (uint32_t c = 0; c < C; ++c) {
+    const uint32_t xb = (uint32_t)((uint64_t)B * c / C), xe = (uint32_t)((uint64_t)B * (c + 1) / C);
+    if (xe <= xb) continue;
+    const size_t rows = xe - xb;
+    NCCLCHK(g_rccl.GroupStart());
+    for (int r = 0; r < h->world; ++r) {
+      const size_t row0 = (size_t)r * B + xb;
+      double *gp = d.gamma + row0 * g.ld;
+      uint32_t *xp = d.xflags + row0 * d.xf_ld;
+      NCCLCHK(g_rccl.Broadcast(gp, gp, rows * g.ld, ncclDouble, r, h->comm, h->comm_stream));
+      NCCLCHK(g_rccl.Broadcast(xp, xp, rows * d.xf_ld, ncclUint32, r, h->comm, h->comm_stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipEventRecord(h->ev_chunk[c], h->comm_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chunk[c], 0));
+    launch_expand_chunk(g, d, h->prm, xb, xe, B, h->stream);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 }  // namespace
@@ -598,8 +661,7 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
     if ((rc = run_phase(h, SVILS_PHASE_A, false))) return rc;
     if (annealing && (rc = exchange_sum(h, h->d.kvec_a, g.K))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_B, false))) return rc;
-    if ((rc = exchange_rows(h))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_EXPAND, false))) return rc;
+    if ((rc = exchange_rows_and_expand(h))) return rc;
     if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
     if (annealing) {
       if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
@@ -687,6 +749,7 @@ int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, s
     case SVILS_KSH_Q2: *dptr = d.q2v; *ndoubles = h->geo.Kt; return 0;
     case SVILS_KSH_VDOT: *dptr = d.vdot; *ndoubles = d.nv; return 0;
     case SVILS_KSH_DMAX: *dptr = d.dmax; *ndoubles = (size_t)d.nlinks; return 0;
+    case SVILS_KSH_EARG: *dptr = d.earg; *ndoubles = d.ksh_lowt ? (size_t)d.nlinks : 0; return 0;
   }
   return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: unknown buffer %d", (int)which);
 }
@@ -695,6 +758,7 @@ int svils_ksh_log_domain(svils_handle *h, int on) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: not a K-sharded handle");
   if (on < 0) return h->d.ksh_log;   // query
+  if (!on && h->d.ksh_lowt) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: link_thresh < 1/2 needs the log-domain exchange (it carries the link's maximum)");
   h->d.ksh_log = on ? 1 : 0;
   return 0;
 }
@@ -707,7 +771,7 @@ int ksh_sum(svils_handle *h, svils_ksh_buffer which) {
   int rc = svils_ksh_buffer_ptr(h, which, &p, &n);
   if (rc || n == 0) return rc;
   Timed t(h, SVILS_KERNEL_EXCHANGE);
-  NCCLCHK(g_rccl.AllReduce(p, p, n, ncclDouble, which == SVILS_KSH_DMAX ? ncclMax : ncclSum, h->comm, h->stream));
+  NCCLCHK(g_rccl.AllReduce(p, p, n, ncclDouble, which == SVILS_KSH_DMAX ? ncclMax : which == SVILS_KSH_EARG ? ncclMin : ncclSum, h->comm, h->stream));
   return 0;
 }
 }  // namespace
@@ -734,6 +798,7 @@ int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
     }
     if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DEN))) return rc;
     if ((rc = ksh_sum(h, SVILS_KSH_DEN))) return rc;
+    if (h->d.ksh_lowt && (rc = ksh_sum(h, SVILS_KSH_EARG))) return rc;   // MIN
     if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_PHI))) return rc;
     if ((rc = ksh_sum(h, SVILS_KSH_ROWX))) return rc;
     if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_FIN))) return rc;
@@ -846,6 +911,9 @@ int svils_destroy(svils_handle *h) {
   comm_destroy(h);
   if (h->stage) (void)hipFree(h->stage);
   if (h->stage_flag) (void)hipFree(h->stage_flag);
+  if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  for (hipEvent_t e : h->ev_chunk) (void)hipEventDestroy(e);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1032,6 +1100,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     guard(dalloc(h, &d.elink, elink.size(), false));
     guard(dalloc(h, &d.den, std::max<uint64_t>(nlinks, 1)));
     guard(dalloc(h, &d.dmax, std::max<uint64_t>(nlinks, 1)));
+    if (d.ksh_lowt) guard(dalloc(h, &d.earg, std::max<uint64_t>(nlinks, 1)));
     guard(dalloc(h, &d.part_q2, d.nb_c));
   }
   if (rc) return rc;

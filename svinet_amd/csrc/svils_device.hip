@@ -589,8 +589,10 @@ __device__ __forceinline__ void unpack_flags(const Geometry &geo, const DeviceSt
 // all-gathered gamma instead of being exchanged.  gamma_new = (alpha + acc (n-1)/tl) * scale with
 // m = acc/tl (compute_mean_indicators, src/linksampling.cc:536-542)  =>  m = (gamma/scale - alpha)/(n-1).
 // Rows without a training link (gamma == alpha, unscaled) never enter the s3 pass; their mphi is written as 0.
+// [xb, xe): the rows, relative to the start of every OTHER rank's node block of `xblock` rows, that this launch expands
+// (the whole block, or one chunk of a pipelined exchange: svils_sweep_sharded expands chunk c while chunk c + 1 travels).
 template <int W, int V>
-__global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Params prm, uint32_t xb, uint32_t xe, uint32_t xblock) {
   const DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;
@@ -610,9 +612,20 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
     iscale[v] = (annealing && kval[v]) ? d.kvec_a[k] / (double)prm.ones : 1.0;   // 1 / (ones / sum[k])
   }
   const double inv_nm1 = 1.0 / ((double)geo.n - 1.0);
-  const uint32_t nown = geo.node_end - geo.node_begin, nother = geo.n - nown;
-  for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < nother; i += gridDim.x * 4 * G) {
-    const uint32_t p = i < geo.node_begin ? i : i + nown;
+  // xblock == 0: every row this handle does not own
+  const uint32_t nown = geo.node_end - geo.node_begin;
+  const uint32_t xlen = xe - xb, nblocks = xblock ? (geo.n_alloc + xblock - 1) / xblock : 0u, myblock = xblock ? geo.node_begin / xblock : 0u;
+  const uint32_t total = xblock ? xlen * (nblocks - 1u) : geo.n - nown;
+  for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < total; i += gridDim.x * 4 * G) {
+    uint32_t p;
+    if (xblock) {
+      uint32_t r = i / xlen;
+      if (r >= myblock) ++r;
+      p = r * xblock + xb + i % xlen;
+      if (p >= geo.n || p >= (r + 1u) * xblock) continue;
+    } else {
+      p = i < geo.node_begin ? i : i + nown;
+    }
     double gn[V];
     load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
     double rs = 0.0;
@@ -1365,15 +1378,28 @@ void launch_expand_window(const Geometry &g, const DeviceState &d, const Params 
   SVILS_DISPATCH(g, CALL);
 #undef CALL
 }
-void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-  const uint32_t nother = g.n - (g.node_end - g.node_begin);
-  if (nother == 0) return;
+// rows [xb, xe) of every other rank's node block of `block` rows (n_alloc = block * world, the owned block starts at a
+// multiple of it); block == 0: every row the handle does not own
+void launch_expand_chunk(const Geometry &g, const DeviceState &d, const Params &p, uint32_t xb, uint32_t xe, uint32_t block,
+                         hipStream_t s) {
+  const uint32_t nown = g.node_end - g.node_begin;
+  if (nown >= g.n) return;
+  uint64_t total;
+  if (block) {
+    if (xe <= xb) return;
+    total = (uint64_t)(xe - xb) * ((g.n_alloc + block - 1) / block - 1u);
+  } else {
+    total = g.n - nown;
+  }
+  if (total == 0) return;
   const int G = 64 / g.W;
-  uint32_t nb = (nother + 4 * G - 1) / (4 * G);
-  if (nb > 2048) nb = 2048;
-#define CALL(W_, V_) hipLaunchKernelGGL((k_expand<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, p)
+  uint32_t nb = (uint32_t)std::min<uint64_t>((total + 4 * G - 1) / (4 * G), 2048);
+#define CALL(W_, V_) hipLaunchKernelGGL((k_expand<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, p, xb, xe, block)
   SVILS_DISPATCH(g, CALL);
 #undef CALL
+}
+void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
+  launch_expand_chunk(g, d, p, 0, 0, 0, s);
 }
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const int G = 64 / g.W;

@@ -130,6 +130,8 @@ struct DeviceState {
   double *den;          // [L]   softmax denominators of the links (partial -> SUM -> total)
   int ksh_log;          // 1: log-domain denominators (max, then shifted sum): two L-sized exchanges, no underflow
   double *dmax;         // [L]   log-domain mode: max_k x_k of the links (partial -> MAX -> total)
+  int ksh_lowt;         // 1: link_thresh < 1/2 -- tags go to the first strict maximum of phi (argmax over ALL columns)
+  double *earg;         // [L]   ksh_lowt: lowest column (global index) attaining the link's max (partial -> MIN -> total)
   double *rowx;         // [n][3] row sum of the new gamma, active-community count, sum of (community + 1) over them
   double *q2v;          // [Kt]  quirk Q2 contributions that belong to another rank's column
   double *vdot;         // [nv]  partial sum_k gamma_p gamma_q beta_k of the held-out pairs
@@ -221,6 +223,8 @@ void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
                           uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s);
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_expand_chunk(const Geometry &g, const DeviceState &d, const Params &p, uint32_t xb, uint32_t xe, uint32_t block,
+                         hipStream_t s);
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s);

@@ -125,6 +125,18 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
           if (lane == 0) d.dmax[el] = m;
         } else {
           const double M = d.dmax[el];   // over ALL columns; -inf: empty active-set union
+          if (d.ksh_lowt) {
+            // the lowest own column attaining the maximum (global index; none: +inf) -- MODE 1 publishes it for the
+            // MIN over the ranks, MODE 2 compares its own columns with the result
+            double cand = __builtin_huge_val();
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+              if (kval[v] && M != NEG_INF && e[v] == M) cand = fmin(cand, (double)(geo.K0 + (uint32_t)kidx[v]));
+            if constexpr (MODE == 1) {
+              cand = -group_max<W>(-cand);
+              if (lane == 0) d.earg[el] = cand;
+            }
+          }
 #pragma unroll
           for (int v = 0; v < V; ++v) { e[v] = (M == NEG_INF) ? 0.0 : exp_neg(e[v] - M); s += e[v]; }
         }
@@ -153,10 +165,15 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
         if (s > 0.0) {   // 0: empty active-set union, contributes nothing (:642-664)
           const double inv = fast_rcp(s);
           const double ts = prm.link_thresh * s;
+          // link_thresh < 1/2: the tag goes to the first strict maximum (phi there is e^0 / s = 1 / s)
+          const double amax = (LOG && d.ksh_lowt) ? d.earg[el] : -1.0;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             acc[v] = fma(e[v], inv, acc[v]);
-            if (write_comm) cnt[v] += (e[v] > ts) ? 1u : 0u;
+            if (write_comm) {
+              if (LOG && d.ksh_lowt) cnt[v] += (kval[v] && (double)(geo.K0 + (uint32_t)kidx[v]) == amax && 1.0 > ts) ? 1u : 0u;
+              else cnt[v] += (e[v] > ts) ? 1u : 0u;
+            }
           }
         }
         if (count_me && lane == 0) { if (sparse) n_sparse++; else n_dense++; }

@@ -47,7 +47,7 @@ class KShard:
         if log_domain is not None:
             e.ksh_log_domain(log_domain)
         self.log_domain = e.ksh_log_domain()
-        for which in (_svils.KSH_DEN, _svils.KSH_ROWX, _svils.KSH_Q2, _svils.KSH_VDOT, _svils.KSH_DMAX):
+        for which in (_svils.KSH_DEN, _svils.KSH_ROWX, _svils.KSH_Q2, _svils.KSH_VDOT, _svils.KSH_DMAX, _svils.KSH_EARG):
             p, n = e.ksh_buffer(which)
             self.buf[which] = _as_tensor(torch, p, 8 * n, "<f8", dev) if n else None
 
@@ -57,8 +57,14 @@ _ORDER = ((_svils.KPHASE_DEN, _svils.KSH_DEN), (_svils.KPHASE_PHI, _svils.KSH_RO
 
 
 def _order(shard):
-    """(phase, buffer to reduce after it) of one sweep; the log-domain mode exchanges the per-link max first"""
-    return (((_svils.KPHASE_DENMAX, _svils.KSH_DMAX),) if shard.log_domain else ()) + _ORDER
+    """(phase, buffers to reduce after it) of one sweep; the log-domain mode exchanges the per-link max first, and a handle
+    with link_thresh < 1/2 (argmax tagging) the lowest column attaining it (MIN) next to the denominators"""
+    order = [(ph, (buf,) if buf is not None else ()) for ph, buf in _ORDER]
+    if shard.buf.get(_svils.KSH_EARG) is not None:
+        order[0] = (order[0][0], (_svils.KSH_DEN, _svils.KSH_EARG))
+    if shard.log_domain:
+        order.insert(0, (_svils.KPHASE_DENMAX, (_svils.KSH_DMAX,)))
+    return order
 
 
 def _sum_virtual(shards, which):
@@ -71,6 +77,8 @@ def _sum_virtual(shards, which):
     for t in ts[1:]:
         if which == _svils.KSH_DMAX:
             tot = shards[0].torch.maximum(tot, t)
+        elif which == _svils.KSH_EARG:
+            tot = shards[0].torch.minimum(tot, t)
         else:
             tot += t
     for t in ts:
@@ -89,10 +97,10 @@ def init_virtual(shards):
 def sweep_virtual(shards, nsweeps=1):
     """all ranks in ONE process (tests): the exchanges are plain tensor sums in rank order"""
     for _ in range(nsweeps):
-        for phase, which in _order(shards[0]):
+        for phase, bufs in _order(shards[0]):
             for s in shards:
                 s.engine.ksweep_phase(phase)
-            if which is not None:
+            for which in bufs:
                 _sum_virtual(shards, which)
 
 
@@ -107,7 +115,8 @@ class KShardedSweep:
         if t is None:
             return
         torch = self.s.torch
-        op = self.dist.ReduceOp.MAX if which == _svils.KSH_DMAX else self.dist.ReduceOp.SUM
+        op = (self.dist.ReduceOp.MAX if which == _svils.KSH_DMAX else
+              self.dist.ReduceOp.MIN if which == _svils.KSH_EARG else self.dist.ReduceOp.SUM)
         if self.dist.get_backend(self.group) == "gloo":
             self.s.engine.synchronize()
             h = t.cpu() if t.is_cuda else t
@@ -126,7 +135,7 @@ class KShardedSweep:
 
     def sweep(self, nsweeps=1):
         for _ in range(nsweeps):
-            for phase, which in _order(self.s):
+            for phase, bufs in _order(self.s):
                 self.s.engine.ksweep_phase(phase)
-                if which is not None:
+                for which in bufs:
                     self._sum(which)

@@ -5,7 +5,7 @@ tests/fakerccl (SVILS_RCCL_LIBRARY, set by the test), because RCCL refuses two r
 torch.distributed here: the ranks only share the 128-byte communicator id, which rank 0 leaves in a file.
 
 argv: path n k count out rank world mode
-mode: sweep | step:<windows per block>:<kappa> | kshard | kshard-log
+mode: sweep | step:<windows per block>:<kappa> | kshard | kshard-log | kshard-lowt (link_thresh = 0.3)
 """
 import os
 import sys
@@ -40,7 +40,7 @@ def main():
     from svinet_amd import _svils
     from svinet_amd.host_api import Setup
     from svinet_amd.sharded import block_size, node_block
-    setup = Setup(path, n, k)
+    setup = Setup(path, n, k, link_thresh=0.3 if mode == "kshard-lowt" else 0.5)
     extra = {}
     if mode.startswith("kshard"):
         from svinet_amd.ksharded import column_slices

@@ -193,9 +193,21 @@ def test_cli_kshard_refuses_what_it_cannot_do(graph_files, tmp_path):
     r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-kshard", "-minibatch", "64"],
              str(tmp_path))
     assert r.returncode != 0 and "-kshard" in r.stderr
-    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-gpus", "1", "-kshard",
-              "-link-thresh", "0.3", "-max-iterations", "2"], str(tmp_path))
-    assert r.returncode != 0 and "link_thresh" in r.stderr
+
+
+def test_cli_kshard_link_thresh_below_one_half(graph_files, tmp_path):
+    """`svinet -kshard -link-thresh 0.3`: argmax tagging on the K-sharded layout; communities.txt equals the oracle's"""
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop", "-gpus", "1", "-kshard",
+              "-link-thresh", "0.3", "-max-iterations", "20"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False, max_iterations=20, link_thresh=0.3)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
 
 
 def test_cli_sharded_code_path_world_of_one(graph_files, tmp_path):

@@ -212,14 +212,47 @@ def test_ksharded_log_domain_equals_product_form(graph_files):
         assert (lambda c: (c.links_dense, c.links_sparse, c.links_shortcut))(shards[0].engine.control()) == ref.link_counts()
 
 
+@pytest.mark.parametrize("world,k,sweeps,thresh,min_deg", [(2, 28, 40, 0.3, 0), (3, 100, 12, 0.2, 2), (4, 28, 25, 0.05, 0),
+                                                           (2, 300, 8, 0.3, 1)])
+def test_ksharded_argmax_tagging_below_one_half(graph_files, world, k, sweeps, thresh, min_deg):
+    """link_thresh < 1/2: a phi above the threshold need not be the link's maximum, so the tag goes to the first strict
+    maximum over ALL columns (src/linksampling.cc:704-717, src/matrix.hh:521-532) -- the per-link maximum travels in the
+    log-domain exchange, the lowest column attaining it next to the denominators (SVILS_KSH_EARG, MIN).  Tags, flags,
+    counters and state equal the oracle's; thresh = 0.05 tags nearly every link, so second-largest memberships above
+    the threshold (which the >= 1/2 rule would also tag) must NOT be tagged."""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
+    path, n = graph_files["lfr"], 1000
+    setup = Setup(path, n, k, link_thresh=thresh, lt_min_deg=min_deg)
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False) for r in range(world)]
+    assert all(s.log_domain for s in shards)       # forced: the maximum is what the log-domain exchange carries
+    init_virtual(shards)
+    sweep_virtual(shards, sweeps)
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False, link_thresh=thresh, lt_min_deg=min_deg)
+    for _ in range(sweeps):
+        ref.sweep()
+    states = [s.engine.state() for s in shards]
+    g = np.concatenate([st[0] for st in states], 1)
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    want = ref.communities()
+    assert want.sum() > 0
+    got = np.concatenate([s.engine.communities() for s in shards], 1)
+    assert np.array_equal(got, want)
+    for st in states:
+        assert np.array_equal(st[2], ref.converged)
+
+
 def test_ksharded_rejects_what_it_does_not_do(graph_files):
-    """link_thresh < 1/2 (argmax tagging over all columns) and mini-batch steps are refused, not approximated"""
+    """mini-batch steps and plain sweeps are refused on a K-sharded handle, not approximated; a handle with
+    link_thresh < 1/2 cannot leave the log-domain exchange"""
     from svinet_amd import _svils
     from svinet_amd.host_api import Setup
     setup = Setup(graph_files["lfr"], 1000, 100)
     kw = dict(ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, lt_min_deg=0, use_validation_stop=False, k_slice=(0, 50))
+    low = _svils.Engine(1000, 100, link_thresh=0.3, **kw)
+    assert low.ksh_log_domain() == 1
     with pytest.raises(_svils.SvilsError, match="link_thresh"):
-        _svils.Engine(1000, 100, link_thresh=0.3, **kw)
+        low.ksh_log_domain(False)
     eng = _svils.Engine(1000, 100, link_thresh=0.5, **kw)
     with pytest.raises(_svils.SvilsError, match="K-sharded"):
         eng.set_stochastic(batch_nodes=100)

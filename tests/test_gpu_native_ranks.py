@@ -38,10 +38,11 @@ def _env(tmp_path=None):
     return env
 
 
-def _run_ranks(tmp_path, path, n, k, count, world, mode):
+def _run_ranks(tmp_path, path, n, k, count, world, mode, extra_env=None):
     out = str(tmp_path / "state")
     worker = os.path.join(HERE, "native_rank_worker.py")
     env = _env(tmp_path)
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, worker, path, str(n), str(k), str(count), out, str(r), str(world), mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     errs = []
@@ -84,21 +85,26 @@ def _check_node_block(states, ref, n, world, tags=True):
     return B
 
 
-@pytest.mark.parametrize("graph,world,k,sweeps", [("lfr", 2, 28, 40), ("lfr", 3, 64, 6), ("lfr", 3, 28, 35),
-                                                   ("astroph", 2, 200, 3)])
-def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps):
+@pytest.mark.parametrize("graph,world,k,sweeps,chunks", [("lfr", 2, 28, 40, 1), ("lfr", 3, 64, 6, 1), ("lfr", 3, 28, 35, 1),
+                                                          ("astroph", 2, 200, 3, 1),
+                                                          # the pipelined row exchange (chunks on a stream of their own, each
+                                                          # expanded while the next one travels): 3 and 5 chunks of uneven size
+                                                          ("lfr", 3, 28, 35, 3), ("lfr", 2, 100, 8, 5), ("astroph", 3, 200, 3, 4)])
+def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps, chunks):
     """svils_sweep_sharded in `world` processes: all-reduce of sum[k], the grouped in-place all-gather of the
     gamma rows and packed flags at rank * B * ld, all-reduce of s1,s2,s3 (grouped with sum[k] once annealing is
     off: LFR K=28 leaves annealing at sweep 29, seen at sweep 32)"""
     path, n = graph_files[graph], {"lfr": 1000, "astroph": 17903}[graph]
-    states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, "sweep")
+    states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, "sweep", {"SVILS_XCHUNKS": str(chunks)})
     ref = _oracle(path, n, k, sweeps)
     _check_node_block(states, ref, n, world)
     late = sum(1 for i in range(sweeps) if i >= 32) if (graph, k) == ("lfr", 28) and not ref.annealing else 0
     for s in states:
         assert int(s["exchanges"]) == 3 * (sweeps - late) + 2 * late
-    # collectives on the wire: per sweep all-reduce + 2 (gathers) + all-reduce(s) [+1 when sum rides late], + the tag gather
-    assert stats[0][2] == 4 * (sweeps - late) + 4 * late + 1
+    # collectives on the wire: per sweep all-reduce + rows + all-reduce(s) [sum rides with them once annealing is off],
+    # + the tag gather; rows = 2 all-gathers, or chunks x world x 2 broadcasts when pipelined
+    rows = 2 if chunks == 1 else chunks * world * 2
+    assert stats[0][2] == (2 + rows) * sweeps + 1
 
 
 @pytest.mark.parametrize("world,k,steps,mode", [(2, 28, 30, "step:1:0"), (3, 64, 5, "step:1:0")])
@@ -141,20 +147,20 @@ def test_native_step_sharded_windows(graph_files, tmp_path, world):
 
 
 @pytest.mark.parametrize("world,k,sweeps,mode", [(2, 28, 40, "kshard"), (3, 100, 6, "kshard"), (3, 130, 5, "kshard-log"),
-                                                  (2, 28, 40, "kshard-log")])
+                                                  (2, 28, 40, "kshard-log"), (3, 28, 30, "kshard-lowt")])
 def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mode):
     """svils_ksh_init_state + svils_sweep_ksharded in `world` processes (uneven slices at K=100/3, 130/3): the column
     slices put together equal the oracle, flags / rows / counters replicated; svils_validation_row and
     svils_comm_allgather_host (collective staging) with rank > 0"""
     path, n = graph_files["lfr"], 1000
     states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, mode)
-    ref = _oracle(path, n, k, sweeps)
+    ref = _oracle(path, n, k, sweeps, **({"link_thresh": 0.3} if mode == "kshard-lowt" else {}))
     g = np.concatenate([s["gamma"] for s in states], 1)
     lam = np.concatenate([s["lam"] for s in states], 0)
     assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
     assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
     want = ref.communities()
-    per_sweep = 5 if mode == "kshard-log" else 4
+    per_sweep = {"kshard": 4, "kshard-log": 5, "kshard-lowt": 6}[mode]   # + the max, + the arg-max (MIN) of every link
     for r, s in enumerate(states):
         assert np.array_equal(s["conv"], ref.converged)
         assert int(s["iter"]) == ref.iter and bool(s["annealing"]) == ref.annealing

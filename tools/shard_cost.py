@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Multi-GPU cost model inputs, MEASURED on ONE GPU: what rank 0 of G computes per sweep in the two sharded layouts
+(all phases launched back to back, no exchange -- the exchange buffers keep whatever they hold, so this is timing
+only), next to the plain engine, plus the bytes each layout exchanges per sweep and a predicted sweep time on
+G = 2, 4, 8 GPUs from a stated link model.  Nothing here is a multi-GPU measurement.
+
+  python tools/shard_cost.py [workload] [G,G,...]
+
+Link model (MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point): a rank sends / receives over all
+its links at once at EFF = 300 GB/s aggregate when the collective uses them all (all-gather / broadcast of node blocks
+with G = 8: every peer is one hop away), EFF * (G - 1) / 7 with fewer peers; every collective costs LAT = 20 us on top.
+  all-gather of S bytes in total : S (G - 1) / G received per rank
+  all-reduce of M bytes          : 2 M (G - 1) / G moved per rank (reduce-scatter + all-gather)
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bench import _load_workload
+from svinet_amd import _svils
+from svinet_amd.sharded import block_size, node_block
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "astroph-k200"
+Gs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 4, 8]
+EFF, LAT = 300e9, 20e-6
+setup, _, _, n, k, _ = _load_workload(wl)
+L, V = int(setup.nlinks), int(setup.validation_sorted.shape[0])
+ld = (k + 15) // 16 * 16
+steps = 20 if n * k < 5e7 else 6
+
+
+def wall(fn, reps):
+    fn(2)
+    t0 = time.perf_counter()
+    fn(reps)
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def link_time(bytes_per_rank, G, ncoll):
+    bw = EFF * min(1.0, (G - 1) / 7.0)
+    return (bytes_per_rank / bw + ncoll * LAT) * 1e3
+
+
+plain = setup.engine(use_validation_stop=False)
+def run_plain(s):
+    plain.sweep(s); plain.synchronize()
+t_plain = wall(run_plain, steps)
+plain.close()
+print("# %s: n=%d k=%d links=%d held-out pairs=%d; plain engine on one GPU: %.3f ms per sweep" % (wl, n, k, L, V, t_plain))
+print("# layout      G   compute/rank (ms)  of which expand   bytes exchanged per sweep (total)         collectives  links (ms)  predicted ms/sweep  speed-up vs 1 GPU")
+for G in Gs:
+    # ---- node blocks: rank 0 of G
+    B = block_size(n, G)
+    e = setup.engine(use_validation_stop=False, node_block=node_block(n, G, 0), n_alloc=B * G)
+    def run_nb(s):
+        for _ in range(s):
+            for ph in (_svils.PHASE_A, _svils.PHASE_B, _svils.PHASE_EXPAND, _svils.PHASE_C, _svils.PHASE_D):
+                e.sweep_phase(ph)
+        e.synchronize()
+    t_nb = wall(run_nb, steps)
+    def run_exp(s):
+        for _ in range(s):
+            e.sweep_phase(_svils.PHASE_EXPAND)
+        e.synchronize()
+    t_exp = wall(run_exp, steps)
+    e.close()
+    rows_total = n * ld * 8 + n * 16            # gamma rows + packed flags (kw = ceil(k/64): 8 + 8 kw bytes)
+    kvec = 4 * k * 8
+    recv = rows_total * (G - 1) / G + 2 * kvec * (G - 1) / G
+    t_link = link_time(recv, G, 3)
+    # the row exchange is pipelined against the expansion of the rows already there: what stays exposed is the longer of the two
+    t_pred = (t_nb - t_exp) + max(t_exp, link_time(rows_total * (G - 1) / G, G, 1)) + link_time(2 * kvec * (G - 1) / G, G, 2)
+    print("node-block  %2d   %10.3f        %8.3f          %7.1f MB all-gather + %5.1f KB all-reduce   %6d    %8.3f    %10.3f        %6.2fx"
+          % (G, t_nb, t_exp, rows_total / 1e6, kvec / 1e3, 3, t_link, t_pred, t_plain / t_pred))
+    # ---- K-sharded: rank 0 of G
+    k0, k1 = 0, k // G
+    ks = _svils.Engine(n, k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, link_thresh=setup.link_thresh,
+                       lt_min_deg=setup.lt_min_deg, use_validation_stop=False, k_slice=(k0, k1))
+    ks.set_graph(setup.links); ks.set_validation(setup.validation_sorted)
+    ks.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+    ks.ksh_init_state()
+    log = ks.ksh_log_domain() == 1
+    def run_ks(s):
+        for _ in range(s):
+            if log:
+                ks.ksweep_phase(_svils.KPHASE_DENMAX)
+            for ph in range(5):
+                ks.ksweep_phase(ph)
+        ks.synchronize()
+    t_ks = wall(run_ks, steps)
+    ks.close()
+    ar = (L * (2 if log else 1) + 3 * n + k + V) * 8
+    ncoll = 5 if log else 4
+    t_link = link_time(2 * ar * (G - 1) / G, G, ncoll)
+    t_pred = t_ks + t_link
+    print("K-sharded   %2d   %10.3f        %8s          %7.1f MB all-reduce (den %s rowx q2 vdot)          %6d    %8.3f    %10.3f        %6.2fx"
+          % (G, t_ks, "-", ar / 1e6, "+dmax" if log else "", ncoll, t_link, t_pred, t_plain / t_pred))
