@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03i; mkdir -p $O
-timeout 2400 python -m pytest tests/test_gpu_native_ranks.py tests/test_gpu_sharded.py -q -m gpu --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-tail -30 $O/pytest.log
+O=gpurun_out/r03j; mkdir -p $O
+python tools/shard_cost.py astroph-k200 2,4,8 2>/dev/null | tee $O/shard_cost_config4.txt
+python tools/shard_cost.py mmsb:1000000:512:24 2,4,8 2>/dev/null | tee $O/shard_cost_config5.txt
