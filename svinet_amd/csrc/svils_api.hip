@@ -404,6 +404,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
   guard(dalloc(h, &d.active_cnt, g.n_alloc));
   guard(dalloc(h, &d.cflag, g.n_alloc));
+  guard(dalloc(h, &d.cls_epoch, 4));
   guard(dalloc(h, &d.amask, (size_t)g.n_alloc * g.kw));
   guard(dalloc(h, &d.member, (size_t)g.n_alloc * g.kw));
   d.xf_ld = 2u + 2u * g.kw;
@@ -1068,7 +1069,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     for (int l = 0; l < 3; ++l) guard(dalloc(h, &d.npos[l], (size_t)g.n_alloc + 1));
     const uint32_t tiles_all = (uint32_t)(d.ent_pad / d.cls_tile);
     guard(dalloc(h, &d.tcnt, tiles_all));
-    guard(dalloc(h, &d.cls_args, 4));
+    guard(dalloc(h, &d.cls_args, 8));
     guard(dalloc(h, &d.s3_ctl, 4));
     guard(dalloc(h, &d.cls_sync, 4));
     guard(dalloc(h, &d.tbase, tiles_all));

@@ -53,22 +53,41 @@ __device__ __forceinline__ void cls_record_args(const DeviceState &d, const Para
   d.cls_args[1] = (((long long)ctrl->iter + (next ? 1 : 0)) > (long long)prm.sparse_after) ? 1u : 0u;
   d.cls_args[2] = next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par;
   d.cls_args[3] = ctrl->sweeps_done + 1u;   // epoch of the in-launch prefix hand-off
+  // [4]: the classes change whatever the flags did -- a stand-alone classification, or the active-set regime switching
+  // on between this sweep and the next (:634)
+  const bool s_now = (long long)ctrl->iter > (long long)prm.sparse_after, s_next = (long long)ctrl->iter + 1 > (long long)prm.sparse_after;
+  d.cls_args[4] = (!next || s_now != s_next) ? 1u : 0u;
+}
+
+// does the classification of the NEXT sweep have to run?  (from the recorded arguments: launches that advance the
+// control block, or follow the one that did)
+__device__ __forceinline__ bool cls_next_needed_from_args(const DeviceState &d) {
+  return d.cls_args[4] != 0u || ld_agent(d.cls_epoch) == d.cls_args[3];
 }
 
 template <int NWORK, bool FROM_ARGS = false>
 __device__ __forceinline__ void cls_count_tiles(const Geometry &geo, const DeviceState &d, const Params &prm,
                                                 ClsWork (&shw)[NWORK], uint32_t rb, uint32_t nrb, bool next) {
-  if (!FROM_ARGS && rb == 0 && threadIdx.x == 0) cls_record_args(d, prm, next);
   uint32_t conv_idx, par;
-  bool sparse_iter;
+  bool sparse_iter, needed;
   if (FROM_ARGS) {
     conv_idx = d.cls_args[0]; sparse_iter = d.cls_args[1] != 0u; par = d.cls_args[2];
+    needed = cls_next_needed_from_args(d);
   } else {
+    // the control block is at rest during this launch: every block reaches the same verdict, worker 0 of block 0
+    // records it ([5]) for the scatter pass and for the launch that advances the control block
     const DevCtrl *ctrl = d.ctrl;
     conv_idx = next ? (ctrl->parity ^ 1u) : ctrl->parity;
     sparse_iter = ((long long)ctrl->iter + (next ? 1 : 0)) > (long long)prm.sparse_after;
     par = next ? (ctrl->cls_par ^ 1u) : ctrl->cls_par;
+    const bool s_now = (long long)ctrl->iter > (long long)prm.sparse_after;
+    needed = !next || s_now != sparse_iter || ld_agent(d.cls_epoch) == ctrl->sweeps_done + 1u;
+    if (rb == 0 && threadIdx.x == 0) {
+      cls_record_args(d, prm, next);
+      d.cls_args[5] = needed ? 1u : 0u;
+    }
   }
+  if (!needed) return;
   uint32_t *ltot = d.ltot + par * 8u;
   unsigned long long *shist = d.shist + (size_t)par * geo.K;
   const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
@@ -148,6 +167,8 @@ __device__ __forceinline__ void cls_scatter_tiles(const Geometry &geo, const Dev
   const uint32_t conv_idx = d.cls_args[0];
   const bool sparse_iter = d.cls_args[1] != 0u;
   const uint32_t par = d.cls_args[2];
+  // BASES: second half of an in-launch classification (the caller has checked); otherwise the count pass's verdict
+  if (!BASES && d.cls_args[5] == 0u) return;
   const uint32_t *__restrict__ conv = d.conv + (size_t)conv_idx * geo.n_alloc;
   uint32_t *ltot = d.ltot + par * 8u;
   unsigned long long *shist = d.shist + (size_t)par * geo.K;
@@ -316,6 +337,7 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
                                                        ClsWork (&shw)[NWORK], uint32_t rb, uint32_t nrb,
                                                        unsigned long long *scan_lds, uint32_t *flag_lds) {
   constexpr int T = 2;   // tiles per worker kept in registers
+  if (!cls_next_needed_from_args(d)) return;   // no flag changed in this sweep: the current lists stay current
   const uint32_t nrw = nrb * NWORK;
   if (d.cls_ntiles > T * nrw || d.cls_tile != 1024u || d.cls_ntiles == 0u) {
     cls_count_tiles<NWORK, true>(geo, d, prm, shw, rb, nrb, true);

@@ -579,7 +579,8 @@ __device__ __forceinline__ void unpack_flags(const Geometry &geo, const DeviceSt
   const uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;
   d.conv[(size_t)(ctrl->parity ^ 1u) * geo.n_alloc + p] = xf[0];
   d.active_cnt[p] = xf[1];
-  d.cflag[p] = xf[0] | (xf[1] < geo.k10 ? 0x80000000u : 0u);
+  const uint32_t cf = xf[0] | (xf[1] < geo.k10 ? 0x80000000u : 0u);
+  if (d.cflag[p] != cf) { d.cflag[p] = cf; d.cls_epoch[0] = ctrl->sweeps_done + 1u; }   // see k_finalize_lpl
 #pragma unroll
   for (int v = 0; v < V; ++v)
     d.amask[(size_t)p * geo.kw + v] = (unsigned long long)xf[2 + 2 * v] | ((unsigned long long)xf[3 + 2 * v] << 32);
@@ -1123,7 +1124,9 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     }
     if (exit_now) c.stopped = 1;  // do_on_stop(); exit(0): _iter is not advanced
     else c.iter = iter + 1;
-    c.cls_par ^= 1u;   // the classes k_s3_lpl computed for the next sweep become current
+    // the classes the count / scatter passes computed for the next sweep become current -- unless they did not run
+    // because no flag changed (cls_args[5], the count pass's verdict): then the current ones stay
+    if (!(d.lpl && d.cls_next && d.cls_args[5] == 0u)) c.cls_par ^= 1u;
     *d.ctrl = c;
   }
   STAMP(3, 6);
@@ -1131,8 +1134,10 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   // classification two sweeps ahead
   __syncthreads();
   if (d.lpl) {
-    if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
-    for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) d.shist[(size_t)cpar0 * K + k] = 0ull;
+    if (!(d.cls_next && d.cls_args[5] == 0u)) {
+      if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
+      for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) d.shist[(size_t)cpar0 * K + k] = 0ull;
+    }
     for (uint32_t k = threadIdx.x; k < 512u; k += blockDim.x) d.sumfx[(size_t)cpar0 * 512 + k] = 0;
   }
 }

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
       if (threadIdx.x < K) sh2[h] = d.shist[(size_t)h * K + threadIdx.x];
     }
   }
-  const uint32_t c_cpar = ctrl->cls_par;
+  const uint32_t c_cpar = ctrl->cls_par, c_epoch = ctrl->sweeps_done + 1u;
   load_logtab(logtab, d.logtab);
   if (stopped) return;
   STAMP(1, 1);
@@ -683,6 +683,7 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
         for (int j = 0; j < NC; ++j) acc[j] += (double)hh[lw + j * FW];
       }
     }
+    const uint32_t cf_old = (ok && lw == 0) ? d.cflag[p] : 0u;
     unsigned long long memb = 0ull;
     uint32_t fc[NC];
 #pragma unroll
@@ -813,7 +814,11 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
       const unsigned long long am = (active <= geo.k10) ? bits : 0ull;
       conv_new[p] = cnew;
       d.active_cnt[p] = active;
-      d.cflag[p] = cnew | (active < geo.k10 ? 0x80000000u : 0u);
+      const uint32_t cf_new = cnew | (active < geo.k10 ? 0x80000000u : 0u);
+      d.cflag[p] = cf_new;
+      // a classification-relevant word changed: the link classes of the next sweep have to be rebuilt (every writer
+      // stores the same epoch; nobody reads it during this launch)
+      if (cf_new != cf_old) d.cls_epoch[0] = c_epoch;
       d.amask[(size_t)p * geo.kw] = am;
 #ifndef FIN_SKIP_XFLAGS   // timing experiment only
       uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;   // the same flags, packed for the node-block exchange
@@ -1034,6 +1039,9 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
       DevCtrl *c = d.ctrl;   // field by field: a whole-struct copy goes through scratch
       const uint32_t cpar0 = c_cpar;
       uint32_t *ltot = d.ltot + cpar0 * 8u;
+      // did this launch's roles classify the next sweep's links?  If no flag changed they did not, and the current
+      // lists, totals and shortcut histogram stay current
+      const bool reclassified = cls_next_needed_from_args(d);
       if (threadIdx.x == 0) {
         const uint32_t iter = c_iter, sd = c_sd;
         c->parity = c_par ^ 1u;  // prune()'s flags become current
@@ -1047,13 +1055,15 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
         c->v_pending = (d.nv > 0 && iter % prm.reportfreq == 0) ? 1u : 0u;
         c->v_iter = iter;
         c->iter = iter + 1;
-        c->cls_par = cpar0 ^ 1u;   // the classes this launch's roles computed for the next sweep become current
+        if (reclassified) c->cls_par = cpar0 ^ 1u;   // the classes this launch's roles computed for the next sweep become current
       }
       // the link counts / shortcut histogram of the finished sweep are consumed: clear them for the
-      // classification two sweeps ahead
+      // classification two sweeps ahead (unless they stay in use); the sweep's column sums are consumed either way
       __syncthreads();
-      if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
-      if (threadIdx.x < K) d.shist[(size_t)cpar0 * K + threadIdx.x] = 0ull;
+      if (reclassified) {
+        if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
+        if (threadIdx.x < K) d.shist[(size_t)cpar0 * K + threadIdx.x] = 0ull;
+      }
       if (threadIdx.x < 512) d.sumfx[(size_t)cpar0 * 512 + threadIdx.x] = 0;
       STAMP(2, 5);
     }
