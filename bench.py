@@ -203,8 +203,7 @@ def hbm_bound_record(device, sweeps=10, workload=HBM_BOUND_WORKLOAD):
                 "ms_per_sweep": el / sweeps * 1e3, "edge_updates_per_s": L * sweeps / el,
                 "kernels_us": {kk: v[0] / max(v[1], 1) * 1e3 for kk, v in tm.items() if v[1]},
                 "setup_s": setup_s,
-                "kernel": ("k_phi<8,false,%s> (row-per-wavefront, %s)" % (("true", "product form on exp(Elogpi) rows")
-                           if n * ld * 8 <= 1536 << 20 else ("false", "exp form: no exp(Elogpi) array above 1.5 GB")))})
+                "kernel": "k_phi<8,false,true> (row-per-wavefront, product form on exp(Elogpi) rows)"})
     rec["frac_algorithmic"] = rec.pop("frac")
     rec["pull_model"] = _pull_model(rec, k, n)
     tr = _traffic(workload)

@@ -392,6 +392,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   d.ksh_lowt = (d.ksh && cfg->link_thresh < 0.5) ? 1 : 0;
   if (d.ksh_lowt) d.ksh_log = 1;
   if (const char *e = getenv("SVILS_DERIVE_M")) h->derive_ok = atoi(e) != 0;
+  if (const char *e = getenv("SVILS_FAULT_INJECT")) h->d.inject_fault = strcmp(e, "cls_handoff") == 0 ? 1 : 0;   // tests only
   const bool whole_graph = g.node_begin == 0 && g.node_end == g.n;
   uint64_t epi_max_mb = (whole_graph && h->derive_ok) ? ~0ull >> 21 : 1536;
   if (const char *e = getenv("SVILS_EPI_MAX_MB")) epi_max_mb = strtoull(e, nullptr, 10);   // A/B knob (profiles/r03*)

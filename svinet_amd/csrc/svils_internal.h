@@ -92,6 +92,7 @@ struct DeviceState {
   // otherwise the lists, totals and shortcut histogram of the current sweep simply stay current (cls_par does not flip).
   // Late in a run few sweeps change a flag; at n = 1e6, k = 20 the two passes are ~0.5 ms of a 2.8 ms sweep.
   uint32_t *cls_epoch;            // [1]
+  int inject_fault;               // test hook (SVILS_FAULT_INJECT=cls_handoff): one worker never publishes its tile
   uint32_t *ltot;                 // [2][8] per cls_par: entries of class 0,1,2; entries with q > p of class 0,1,2
   unsigned long long *shist;      // [2][K] per cls_par: class-2 entries per community column
   // `sum[k]` of whole sweeps driven by this library (fold): per-XCD fixed-point accumulators, [2][8][64] per cls_par.

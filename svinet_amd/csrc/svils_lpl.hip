@@ -820,10 +820,10 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
       // stores the same epoch; nobody reads it during this launch)
       if (cf_new != cf_old) d.cls_epoch[0] = c_epoch;
       d.amask[(size_t)p * geo.kw] = am;
-#ifndef FIN_SKIP_XFLAGS   // timing experiment only
-      uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;   // the same flags, packed for the node-block exchange
-      xf[0] = cnew; xf[1] = active; xf[2] = (uint32_t)am; xf[3] = (uint32_t)(am >> 32);
-#endif
+      if (nown < geo.n) {   // node-block handles only: the same flags, packed for the exchange (nobody reads them otherwise)
+        uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;
+        xf[0] = cnew; xf[1] = active; xf[2] = (uint32_t)am; xf[3] = (uint32_t)(am >> 32);
+      }
     }
   }
   STAMP(1, 3);

@@ -4,12 +4,15 @@ on the same seeded inputs.
 Bar (BASELINE.json north_star): gamma and lambda within 1e-5 relative after a
 fixed number of sweeps; discrete outputs (converged flags, communities) equal.
 """
+import os
+
 import numpy as np
 import pytest
 
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RTOL = 1e-5  # north_star tolerance on gamma/lambda
 
@@ -245,3 +248,29 @@ def test_lfr_long_run_into_the_active_set_regime(graph_files):
     assert sparse_total > 100000 and ref.link_counts()[1] > 0
     assert np.array_equal(eng.communities(), ref.communities())
     np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+
+
+def test_in_launch_handoff_timeout_is_loud(graph_files, tmp_path):
+    """The classification of a three-launch sweep hands tile counts from worker to worker inside ONE launch, with a
+    bounded wait.  A worker that never publishes (test hook SVILS_FAULT_INJECT=cls_handoff; in the field: role blocks
+    that are not co-resident, e.g. under CU masking) must not hang the device or corrupt the run: the waiters give up,
+    the run freezes where it is and the next call reports SVILS_ERR_DEVICE."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from svinet_amd.host_api import Setup\n"
+        "from svinet_amd import _svils\n"
+        "s = Setup(%r, 1000, 28)\n"
+        "e = s.engine(use_validation_stop=False)\n"
+        "try:\n"
+        "    e.sweep(40); e.synchronize(); c = e.control()\n"
+        "    print('NOFAULT', c.iter)\n"
+        "except _svils.SvilsError as exc:\n"
+        "    print('FAULT', exc.code, str(exc)[:120])\n"
+    ) % (ROOT_DIR, graph_files["lfr"])
+    env = dict(os.environ, SVILS_FAULT_INJECT="cls_handoff")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FAULT" in r.stdout and "NOFAULT" not in r.stdout, r.stdout
+    assert "hand-off" in r.stdout
