@@ -321,6 +321,12 @@ int svils_ksh_init_state(svils_handle *h);           /* collective: the two INIT
  * A handle without a communicator (world of one) copies send to recv. */
 int svils_comm_allgather_host(svils_handle *h, const void *send, void *recv, size_t bytes);
 int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps);   /* collective, asynchronous */
+/* Mini-batch steps on a K-sharded handle (svils_set_stochastic with shard_block = 0: every rank holds all nodes and steps
+ * through the SAME windows on its own columns).  The phases and exchanges are those of a sweep restricted to the window:
+ * while a step is open svils_ksh_buffer_ptr returns the window's share of SVILS_KSH_DEN / DMAX / EARG (indexed by CSR entry
+ * in this mode: the entries of the window's rows are one contiguous range) and of SVILS_KSH_ROWX.  With your own
+ * collectives: svils_ksweep_phase in the order of a sweep; the first phase opens the step, SVILS_KPHASE_STOP closes it. */
+int svils_step_ksharded(svils_handle *h, uint32_t nsteps);      /* collective, asynchronous */
 
 const char *svils_last_error(void);
 int svils_abi_version(void);

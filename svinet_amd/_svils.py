@@ -28,7 +28,7 @@ EXPORTS = (
     "svils_get_sweep_stats", "svils_get_timed_links",
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
     "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
-    "svils_comm_allgather_host", "svils_step_sharded",
+    "svils_comm_allgather_host", "svils_step_sharded", "svils_step_ksharded",
 )
 
 
@@ -213,6 +213,10 @@ class Engine:
 
     def ksh_init_state(self):
         _chk(load().svils_ksh_init_state(self._h))
+
+    def step_ksharded(self, nsteps=1):
+        """mini-batch steps of a K-sharded handle, the exchanges issued by the library (collective)"""
+        _chk(load().svils_step_ksharded(self._h, int(nsteps)))
 
     def sweep_ksharded(self, nsweeps=1):
         _chk(load().svils_sweep_ksharded(self._h, int(nsweeps)))

@@ -728,6 +728,9 @@ int svils_step_sharded(svils_handle *h, uint32_t nsteps) {
 }
 
 // ---------------------------------------------------------------- K-sharded sweeps (svils_ksh.h)
+namespace {
+int open_step(svils_handle *h);
+}
 int svils_ksweep_phase(svils_handle *h, svils_kphase phase) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: not a K-sharded handle (svils_config.k_total)");
@@ -735,6 +738,27 @@ int svils_ksweep_phase(svils_handle *h, svils_kphase phase) {
   if ((int)phase < 0 || (int)phase > 7) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: unknown phase %d", (int)phase);
   if (phase == SVILS_KPHASE_DENMAX && !h->d.ksh_log) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: DENMAX belongs to the log-domain mode (svils_ksh_log_domain)");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->stoch && ((int)phase <= 4 || phase == SVILS_KPHASE_DENMAX)) {
+    // mini-batch step over the window of nodes every rank shares (open_step: window geometry, item ranges, the
+    // factors that turn window sums into estimates, this step's step sizes).  The first phase of a step opens it
+    // (DENMAX in the log-domain mode, else DEN), STOP closes it.
+    const svils_kphase first = h->d.ksh_log ? SVILS_KPHASE_DENMAX : SVILS_KPHASE_DEN;
+    if (phase == first) {
+      if (h->step_open) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: the previous step was not closed with phase STOP");
+      int rc = open_step(h);
+      if (rc) return rc;
+    } else if (!h->step_open) {
+      return fail(SVILS_ERR_ARG, "svils_ksweep_phase: a mini-batch step starts with phase %s", h->d.ksh_log ? "DENMAX" : "DEN");
+    }
+    launch_ksh_phase(h->sg, h->sd, h->sp, (int)phase, h->stream);
+    HIPCHK(hipGetLastError());
+    if (phase == SVILS_KPHASE_STOP) {
+      h->step_open = false;
+      ++h->steps_done;
+      ++h->sweeps_issued;
+    }
+    return 0;
+  }
   launch_ksh_phase(h->geo, h->d, h->prm, (int)phase, h->stream);
   HIPCHK(hipGetLastError());
   if (phase == SVILS_KPHASE_STOP) ++h->sweeps_issued;
@@ -745,6 +769,19 @@ int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, s
   if (!h || !dptr || !ndoubles) return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: null argument");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: not a K-sharded handle");
   const DeviceState &d = h->d;
+  if (h->stoch && h->step_open) {
+    // a mini-batch step: what crosses the ranks is the window's share -- the CSR entries of its rows (one contiguous
+    // range of the entry-indexed per-link buffers) and its rows of rowx
+    const size_t e0 = (size_t)h->sd.ent_begin, ne = (size_t)(h->sd.ent_end - h->sd.ent_begin);
+    const size_t r0 = h->sg.node_begin, nr = h->sg.node_end - h->sg.node_begin;
+    switch (which) {
+      case SVILS_KSH_DEN: *dptr = d.den + e0; *ndoubles = ne; return 0;
+      case SVILS_KSH_DMAX: *dptr = d.dmax + e0; *ndoubles = ne; return 0;
+      case SVILS_KSH_EARG: *dptr = d.ksh_lowt ? d.earg + e0 : nullptr; *ndoubles = d.ksh_lowt ? ne : 0; return 0;
+      case SVILS_KSH_ROWX: *dptr = d.rowx + 3 * r0; *ndoubles = 3 * nr; return 0;
+      default: break;
+    }
+  }
   switch (which) {
     case SVILS_KSH_DEN: *dptr = d.den; *ndoubles = (size_t)d.nlinks; return 0;
     case SVILS_KSH_ROWX: *dptr = d.rowx; *ndoubles = 3 * (size_t)h->geo.n; return 0;
@@ -793,6 +830,36 @@ int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
     return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: at most %llu sweeps per call",
                 (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
   for (uint32_t i = 0; i < nsweeps; ++i) {
+    int rc;
+    if (h->d.ksh_log) {
+      if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DENMAX))) return rc;
+      if ((rc = ksh_sum(h, SVILS_KSH_DMAX))) return rc;   // MAX
+    }
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DEN))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_DEN))) return rc;
+    if (h->d.ksh_lowt && (rc = ksh_sum(h, SVILS_KSH_EARG))) return rc;   // MIN
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_PHI))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_ROWX))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_FIN))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_Q2))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_LAMBDA))) return rc;
+    if ((rc = ksh_sum(h, SVILS_KSH_VDOT))) return rc;
+    if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_STOP))) return rc;
+  }
+  return 0;
+}
+
+// Mini-batch (Robbins-Monro) steps on the K-sharded layout: every rank steps through the SAME window of nodes on its own
+// column slice; the exchanges are those of a sweep, restricted to the window's share of the buffers.
+int svils_step_ksharded(svils_handle *h, uint32_t nsteps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_step_ksharded: null handle");
+  if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_step_ksharded: not a K-sharded handle");
+  if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_ksharded: call svils_set_stochastic first");
+  if (!h->comm && h->geo.K != h->geo.Kt) return fail(SVILS_ERR_ARG, "svils_step_ksharded: call svils_comm_init first");
+  if (nsteps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
+    return fail(SVILS_ERR_ARG, "svils_step_ksharded: at most %llu steps per call",
+                (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
+  for (uint32_t i = 0; i < nsteps; ++i) {
     int rc;
     if (h->d.ksh_log) {
       if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_DENMAX))) return rc;
@@ -1100,9 +1167,11 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   if (d.ksh) {
     if (nlinks >= (1ull << 32)) return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handles index links with 32 bits");
     guard(dalloc(h, &d.elink, elink.size(), false));
-    guard(dalloc(h, &d.den, std::max<uint64_t>(nlinks, 1)));
-    guard(dalloc(h, &d.dmax, std::max<uint64_t>(nlinks, 1)));
-    if (d.ksh_lowt) guard(dalloc(h, &d.earg, std::max<uint64_t>(nlinks, 1)));
+    // one value per link on full sweeps; mini-batch steps index the same buffers by CSR entry (2 per link: ksh_ent)
+    if (2 * nlinks >= (1ull << 32)) return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handles index CSR entries with 32 bits");
+    guard(dalloc(h, &d.den, std::max<uint64_t>(2 * nlinks, 1)));
+    guard(dalloc(h, &d.dmax, std::max<uint64_t>(2 * nlinks, 1)));
+    if (d.ksh_lowt) guard(dalloc(h, &d.earg, std::max<uint64_t>(2 * nlinks, 1)));
     guard(dalloc(h, &d.part_q2, d.nb_c));
   }
   if (rc) return rc;
@@ -1377,7 +1446,7 @@ void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes) {
 
 int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
   if (!h || !cfg) return fail(SVILS_ERR_ARG, "svils_set_stochastic: null argument");
-  if (h->d.ksh) return fail(SVILS_ERR_UNSUPPORTED, "svils_set_stochastic: K-sharded handles run full sweeps only");
+  if (h->d.ksh && cfg->shard_block) return fail(SVILS_ERR_ARG, "svils_set_stochastic: a K-sharded handle holds every node (shard_block must be 0)");
   if (!(cfg->tau0 >= 1.0) || !(cfg->kappa >= 0.0) || cfg->kappa > 1.0 || !(cfg->node_tau0 >= 1.0) ||
       !(cfg->node_kappa >= 0.0) || cfg->node_kappa > 1.0)
     return fail(SVILS_ERR_ARG, "svils_set_stochastic: need tau0 >= 1 and 0 <= kappa <= 1");
@@ -1410,6 +1479,7 @@ int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
   }
   h->stoch = true;
   h->scfg = *cfg;
+  if (d.ksh) d.ksh_ent = 1;   // per-link exchange buffers by CSR entry from now on (svils_ksh.h)
   return 0;
 }
 

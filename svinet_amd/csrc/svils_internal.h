@@ -138,6 +138,7 @@ struct DeviceState {
   double *den;          // [L]   softmax denominators of the links (partial -> SUM -> total)
   int ksh_log;          // 1: log-domain denominators (max, then shifted sum): two L-sized exchanges, no underflow
   double *dmax;         // [L]   log-domain mode: max_k x_k of the links (partial -> MAX -> total)
+  int ksh_ent;          // 1 (mini-batch steps): den / dmax / earg are indexed by CSR entry, every entry of the window computes its own
   int ksh_lowt;         // 1: link_thresh < 1/2 -- tags go to the first strict maximum of phi (argmax over ALL columns)
   double *earg;         // [L]   ksh_lowt: lowest column (global index) attaining the link's max (partial -> MIN -> total)
   double *rowx;         // [n][3] row sum of the new gamma, active-community count, sum of (community + 1) over them

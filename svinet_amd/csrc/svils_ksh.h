@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
     if ((uint32_t)lane < len) {
       mycol = d.col[base + lane];
       myconv = conv[mycol];
-      myel = d.elink[base + lane];
+      // mini-batch steps (ksh_ent): the per-link buffers are indexed by CSR ENTRY and every entry of the window's rows
+      // computes its own value -- a link whose other endpoint lies outside the window has no lower-endpoint row in
+      // this step, and the window's entries are one contiguous range to exchange
+      myel = d.ksh_ent ? (uint32_t)(base + lane) : d.elink[base + lane];
     }
     const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)conv[p]);
     double ap[V];
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
     // the next one that does is in flight while the current one is reduced
     auto needs_row = [&](uint32_t jj) {
       const uint32_t qq = __builtin_amdgcn_readlane(mycol, jj), cc = __builtin_amdgcn_readlane(myconv, jj);
-      return ((pc != 0) == (cc != 0)) && (MODE == 2 || qq > p);   // MODE 0 and 1: one value per undirected link
+      return ((pc != 0) == (cc != 0)) && (MODE == 2 || qq > p || d.ksh_ent);   // MODE 0 and 1: one value per undirected link
     };
     double r[V], rnext[V];
     if (len > 0 && needs_row(0)) load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, 0) * ld, lw, ld, r);
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
           if (count_me && lane == 0) n_short++;
         }
         handled = true;
-      } else if (MODE != 2 && !count_me) {
+      } else if (MODE != 2 && !count_me && !d.ksh_ent) {
         handled = true;   // one denominator per undirected link
       }
       if (!handled) {   // (body kept at loop depth)
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
     if ((uint32_t)lane < len) {
       mycol = d.col[base + lane];
       myconv = conv[mycol];
-      myel = d.elink[base + lane];
+      myel = d.ksh_ent ? (uint32_t)(base + lane) : d.elink[base + lane];   // see k_phi_ksh
     }
     const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)conv[p]);
     double ap[V];
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
       qc = (uint32_t)__shfl((int)myconv, src, 64);
       el = (uint32_t)__shfl((int)myel, src, 64);
       const bool valid = jj < len;
-      need = valid && ((pc != 0) == (qc != 0)) && (MODE == 2 || q > p);
+      need = valid && ((pc != 0) == (qc != 0)) && (MODE == 2 || q > p || d.ksh_ent);
       return valid;
     };
     double r[V], rnext[V];
@@ -389,12 +392,14 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
 // compute_mean_indicators + swap (src/linksampling.cc:526-545,751-755) on the own columns; what set_dir_exp and
 // prune need from the WHOLE row goes to rowx[p] as this rank's partial: sum_k gamma, |{k: gamma - alpha >= 1}|,
 // sum of (community + 1) over that set (the community itself when the set has one element).
-template <int V>
+template <int V, bool STOCH>
 __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, Params prm, int init) {
   constexpr int W = 64;
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double lds[2 * V * 64];
+  __shared__ double2 logtab[128];
+  if constexpr (STOCH) { load_logtab(logtab, d.logtab); __syncthreads(); }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lw = lane;
   const uint32_t K = geo.K, ld = geo.ld;
@@ -407,12 +412,14 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
   for (int v = 0; v < V; ++v) {
     kidx[v] = kmap<W, V>(lw, v);
     kval[v] = (uint32_t)kidx[v] < K;
-    scale[v] = (!init && annealing && kval[v]) ? (double)prm.ones / d.kvec_a[kidx[v]] : 1.0;
+    // (mini-batch step: kvec_a is the window's sum, scaled to an estimate of the full one)
+    scale[v] = (!init && annealing && kval[v]) ? (double)prm.ones / (STOCH ? d.kvec_a[kidx[v]] * prm.scale_a : d.kvec_a[kidx[v]]) : 1.0;
   }
   double s12[2][V];
 #pragma unroll
   for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
-  for (uint32_t p = blockIdx.x * 4 + wave; p < geo.n; p += gridDim.x * 4) {
+  // full sweeps: every node; mini-batch steps: the window [node_begin, node_end)
+  for (uint32_t p = geo.node_begin + blockIdx.x * 4 + wave; p < geo.node_end; p += gridDim.x * 4) {
     double gn[V];
     if (init) {
       load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
@@ -456,6 +463,23 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
           if (kval[v]) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; }
           else { m[v] = 0.0; gn[v] = 0.0; }
         }
+        if constexpr (STOCH) {
+          // Robbins-Monro step of this node (k_finalize<W,V,true>): gamma <- (1 - rho) gamma + rho gamma_hat with
+          // rho = (tau0 + c)^-kappa; s1/s2 are running sums over the stored mphi rows: this row contributes (new - old)
+          const uint32_t c = d.ncnt[p];
+          const double rho = exp_neg(-prm.kappa * log_tab(prm.tau0 + (double)c, logtab));
+          double gold[V], mold[V];
+          load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gold);
+          load_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, mold);
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kval[v]) {
+              gn[v] = (1.0 - rho) * gold[v] + rho * gn[v];
+              s12[0][v] -= mold[v];
+              s12[1][v] -= mold[v] * mold[v];
+            }
+          if (lane == 0) d.ncnt[p] = c + 1u;
+        }
         store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
       } else {
 #pragma unroll
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(256) void k_fin2_ksh(Geometry geo, DeviceState d, P
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
   uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
-  for (uint32_t p = blockIdx.x * 4 + wave; p < geo.n; p += gridDim.x * 4) {
+  for (uint32_t p = geo.node_begin + blockIdx.x * 4 + wave; p < geo.node_end; p += gridDim.x * 4) {
     double gn[V];
     load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
     const double rs = d.rowx[3 * (size_t)p];
@@ -661,10 +685,24 @@ __global__ __launch_bounds__(256) void k_lam_ksh(Geometry geo, DeviceState d, Pa
   __syncthreads();
   const uint32_t K = geo.K;
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-    const double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k];
-    const double s3 = d.kvec_c[2 * (size_t)K + k] + d.q2v[geo.K0 + k];   // the summed q2v: what the other ranks found for this column
-    const double l0 = prm.eta0 + d.kvec_a[k];
-    const double l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+    double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k];
+    double s3 = d.kvec_c[2 * (size_t)K + k] + d.q2v[geo.K0 + k];   // the summed q2v: what the other ranks found for this column
+    double l0 = prm.eta0 + d.kvec_a[k];
+    double l1;
+    if (prm.stoch) {
+      // mini-batch step (lambda_of_sweep<true>): sum and s3 are window sums scaled to estimates of the full ones, s1/s2
+      // running totals (previous total + this window's change), the result blended into the old lambda
+      s1 += d.s12run[k];
+      s2 += d.s12run[K + k];
+      s3 *= prm.scale_c;
+      const double h0 = prm.eta0 + d.kvec_a[k] * prm.scale_a, h1 = prm.eta1 + (s1 * s1 - s2 - s3);
+      l0 = (1.0 - prm.rho_lambda) * d.lambda[2 * k] + prm.rho_lambda * h0;
+      l1 = (1.0 - prm.rho_lambda) * d.lambda[2 * k + 1] + prm.rho_lambda * h1;
+      d.s12run[k] = s1;
+      d.s12run[K + k] = s2;
+    } else {
+      l1 = prm.eta1 + (s1 * s1 - s2 - s3);
+    }
     d.lambda[2 * k] = l0;
     d.lambda[2 * k + 1] = l1;
     const double ps = digamma(l0 + l1, logtab);
@@ -760,7 +798,8 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
     st[0] = c.links_dense; st[1] = c.links_sparse; st[2] = c.links_shortcut; st[3] = c.sweeps_done;
   }
   c.sweeps_done++;
-  c.write_comm = (iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
+  // (mini-batch steps tag on every step: a window is only visited once per pass over the nodes)
+  c.write_comm = (prm.stoch || iter % prm.reportfreq == prm.reportfreq - 1) ? 1 : 0;
   bool exit_now = false;
   if (do_val) {
     const uint32_t kzeros = (uint32_t)kzd, kones = d.nv - kzeros;
@@ -806,7 +845,8 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
   } while (0)
 
 void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, int phase, hipStream_t s) {
-  const uint32_t nbn = (g.n + 3) / 4 > 2048 ? 2048 : (g.n + 3) / 4;   // node loops: one node per wavefront
+  const uint32_t nodes = g.node_end - g.node_begin;                   // every node, or the window of a mini-batch step
+  const uint32_t nbn = std::max(1u, (nodes + 3) / 4 > 2048 ? 2048 : (nodes + 3) / 4);   // node loops: one node per wavefront
   switch (phase) {
     case 0: {   // DEN
       if (g.V == 1 && KSH_NARROW && !d.ksh_log) { hipLaunchKernelGGL((k_phi_ksh16<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break; }
@@ -832,7 +872,11 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
 #undef CALL
       }
       launch_reduce_a(g, d, s);
-#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0)
+#define CALL(V_)                                                                                        \
+  do {                                                                                                  \
+    if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);  \
+    else hipLaunchKernelGGL((k_fin1_ksh<V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);        \
+  } while (0)
       KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
@@ -840,6 +884,7 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
 #define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 0)
       KSH_DISPATCH(g, CALL);
 #undef CALL
+      if (p.stoch) launch_carry_flags(g, d, s);   // rows outside the window keep their converged flag across the parity flip
       if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL(k_s3_ksh16, dim3(d.nb_c), dim3(256), 0, s, g, d);
       else {
 #define CALL(V_) hipLaunchKernelGGL((k_s3_ksh<V_>), dim3(d.nb_c), dim3(256), 0, s, g, d)
@@ -865,7 +910,7 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
       hipLaunchKernelGGL(k_stop_ksh, dim3(1), dim3(256), 0, s, g, d, p, nvb);
     } break;
     case 5: {   // initial state: partial row sums of the gamma just set
-#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
+#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
       KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;

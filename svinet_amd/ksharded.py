@@ -37,6 +37,7 @@ class KShard:
                     link_thresh=setup.link_thresh, lt_min_deg=setup.lt_min_deg, device=device_index,
                     k_slice=(self.k0, self.k1))
         args.update(engine_kw)
+        self.device_index = device_index
         self.engine = e = Engine(setup.n, setup.k, **args)
         e.set_graph(setup.links)
         e.set_validation(setup.validation_sorted)
@@ -104,6 +105,46 @@ def sweep_virtual(shards, nsweeps=1):
                 _sum_virtual(shards, which)
 
 
+def _window_tensor(shard, which):
+    """the window's share of an exchange buffer while a mini-batch step is open (svils_ksh_buffer_ptr returns the
+    sub-range; the tensors cached at construction alias the whole buffers)"""
+    p, n = shard.engine.ksh_buffer(which)
+    if not n:
+        return None
+    dev = shard.torch.device("cuda", shard.device_index)
+    return _as_tensor(shard.torch, p, 8 * n, "<f8", dev)
+
+
+def _reduce_virtual(shards, which, tensors):
+    if tensors[0] is None:
+        return
+    torch = shards[0].torch
+    for s in shards:
+        s.engine.synchronize()
+    tot = tensors[0].clone()
+    for t in tensors[1:]:
+        if which == _svils.KSH_DMAX:
+            tot = torch.maximum(tot, t)
+        elif which == _svils.KSH_EARG:
+            tot = torch.minimum(tot, t)
+        else:
+            tot += t
+    for t in tensors:
+        t.copy_(tot)
+    torch.cuda.synchronize()
+
+
+def step_virtual(shards, nsteps=1):
+    """mini-batch steps (svils_set_stochastic on every shard first) with all ranks in ONE process (tests): the phases of
+    a sweep over the window every rank shares, the exchanges restricted to the window's share of the buffers"""
+    for _ in range(nsteps):
+        for phase, bufs in _order(shards[0]):
+            for s in shards:
+                s.engine.ksweep_phase(phase)
+            for which in bufs:
+                _reduce_virtual(shards, which, [_window_tensor(s, which) for s in shards])
+
+
 class KShardedSweep:
     """one rank per process: the exchanges are torch.distributed all-reduces on the engine's stream"""
 
@@ -139,3 +180,28 @@ class KShardedSweep:
                 self.s.engine.ksweep_phase(phase)
                 for which in bufs:
                     self._sum(which)
+
+
+class KShardedStep(KShardedSweep):
+    """mini-batch steps, one rank per process (the caller-driven form of svils_step_ksharded)"""
+
+    def step(self, nsteps=1):
+        torch = self.s.torch
+        for _ in range(nsteps):
+            for phase, bufs in _order(self.s):
+                self.s.engine.ksweep_phase(phase)
+                for which in bufs:
+                    t = _window_tensor(self.s, which)
+                    if t is None:
+                        continue
+                    op = (self.dist.ReduceOp.MAX if which == _svils.KSH_DMAX else
+                          self.dist.ReduceOp.MIN if which == _svils.KSH_EARG else self.dist.ReduceOp.SUM)
+                    if self.dist.get_backend(self.group) == "gloo":
+                        self.s.engine.synchronize()
+                        h = t.cpu()
+                        self.dist.all_reduce(h, op=op, group=self.group)
+                        t.copy_(h)
+                        torch.cuda.synchronize()
+                    else:
+                        with torch.cuda.stream(self.s.stream):
+                            self.dist.all_reduce(t, op=op, group=self.group)

@@ -5,7 +5,8 @@ tests/fakerccl (SVILS_RCCL_LIBRARY, set by the test), because RCCL refuses two r
 torch.distributed here: the ranks only share the 128-byte communicator id, which rank 0 leaves in a file.
 
 argv: path n k count out rank world mode
-mode: sweep | step:<windows per block>:<kappa> | kshard | kshard-log | kshard-lowt (link_thresh = 0.3)
+mode: sweep | step:<windows per block>:<kappa> | kshard | kshard-log | kshard-lowt (link_thresh = 0.3) |
+      kstep:<windows>:<kappa> (mini-batch steps on the K-sharded layout)
 """
 import os
 import sys
@@ -42,7 +43,7 @@ def main():
     from svinet_amd.sharded import block_size, node_block
     setup = Setup(path, n, k, link_thresh=0.3 if mode == "kshard-lowt" else 0.5)
     extra = {}
-    if mode.startswith("kshard"):
+    if mode.startswith("kshard") or mode.startswith("kstep"):
         from svinet_amd.ksharded import column_slices
         k0, k1 = column_slices(k, world)[rank]
         eng = _svils.Engine(setup.n, setup.k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta,
@@ -55,9 +56,15 @@ def main():
             eng.ksh_log_domain(True)
         eng.comm_init(comm_id(out, rank), rank, world)
         eng.enable_timing(1 << _svils.KERNEL_EXCHANGE)
+        if mode.startswith("kstep"):
+            _, nwin, kappa = mode.split(":")
+            eng.set_stochastic(batch_nodes=(n + int(nwin) - 1) // int(nwin), tau0=4.0, kappa=float(kappa), node_tau0=2.0, node_kappa=0.5)
         eng.ksh_init_state()
         row0 = eng.validation_row()           # collective: the constructor-time likelihood row
-        eng.sweep_ksharded(count)
+        if mode.startswith("kstep"):
+            eng.step_ksharded(count)
+        else:
+            eng.sweep_ksharded(count)
         extra = dict(k0=k0, k1=k1, row0=row0)
         # the host-staged gather the CLI uses for its files: every rank's slice of the tags, rank by rank
         mine = np.ascontiguousarray(eng.communities(), dtype=np.uint8)

@@ -242,9 +242,71 @@ def test_ksharded_argmax_tagging_below_one_half(graph_files, world, k, sweeps, t
         assert np.array_equal(st[2], ref.converged)
 
 
+@pytest.mark.parametrize("world,k,sweeps,log_domain", [(2, 28, 30, None), (3, 100, 8, None), (2, 300, 5, None), (3, 28, 30, True)])
+def test_ksharded_minibatch_full_window_is_a_sweep(graph_files, world, k, sweeps, log_domain):
+    """mini-batch steps on K-sharded handles with ONE window (all nodes) and step size 1 (kappa = 0) are full sweeps:
+    the entry-indexed denominators (every CSR entry its own value), the window ranges of the exchanges, the blended
+    finalise and lambda at rho = 1 -- against the oracle"""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, step_virtual
+    path, n = graph_files["lfr"], 1000
+    setup = Setup(path, n, k)
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False, log_domain=log_domain) for r in range(world)]
+    for s in shards:
+        s.engine.set_stochastic(batch_nodes=0, tau0=1.0, kappa=0.0)
+    init_virtual(shards)
+    step_virtual(shards, sweeps)
+    ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    states = [s.engine.state() for s in shards]
+    g = np.concatenate([st[0] for st in states], 1)
+    lam = np.concatenate([st[1] for st in states], 0)
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    for st in states:
+        assert np.array_equal(st[2], ref.converged)
+    for s in shards:
+        c = s.engine.control()
+        assert c.iter == ref.iter and bool(c.annealing) == ref.annealing
+        np.testing.assert_allclose(s.engine.rows()[:, 1:], np.asarray(ref.rows)[1:sweeps + 1, 1:], rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("world,k,nwin,steps,thresh", [(2, 28, 3, 60, 0.5), (3, 100, 4, 24, 0.5), (2, 64, 5, 25, 0.3)])
+def test_ksharded_minibatch_windows_equal_the_plain_engine(graph_files, world, k, nwin, steps, thresh):
+    """windows of n / nwin nodes with damped steps: the column slices of the K-sharded ranks, put together, equal
+    svils_step on ONE plain handle with the same windows and step sizes (state, flags, likelihood rows, tags) -- the
+    same algorithm, sharded by columns; link_thresh = 0.3 runs the arg-max tagging in steps"""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, step_virtual
+    path, n = graph_files["lfr"], 1000
+    setup = Setup(path, n, k, link_thresh=thresh)
+    bn = (n + nwin - 1) // nwin
+    kw = dict(batch_nodes=bn, tau0=4.0, kappa=0.6, node_tau0=2.0, node_kappa=0.5)
+    shards = [KShard(setup, r, world, 0, use_validation_stop=False) for r in range(world)]
+    for s in shards:
+        s.engine.set_stochastic(**kw)
+    init_virtual(shards)
+    step_virtual(shards, steps)
+    plain = setup.engine(use_validation_stop=False)
+    plain.set_stochastic(**kw)
+    plain.step(steps)
+    pg, pl, pc = plain.state()
+    states = [s.engine.state() for s in shards]
+    g = np.concatenate([st[0] for st in states], 1)
+    lam = np.concatenate([st[1] for st in states], 0)
+    assert np.max(np.abs(g - pg) / np.abs(pg)) < 1e-9
+    assert np.max(np.abs(lam - pl) / np.abs(pl)) < 1e-9
+    for st in states:
+        assert np.array_equal(st[2], pc)
+    np.testing.assert_allclose(shards[0].engine.rows()[:, 1:], plain.rows()[:, 1:], rtol=1e-8, atol=1e-11)
+    assert np.array_equal(np.concatenate([s.engine.communities() for s in shards], 1), plain.communities())
+    assert shards[0].engine.control().iter == steps
+
+
 def test_ksharded_rejects_what_it_does_not_do(graph_files):
-    """mini-batch steps and plain sweeps are refused on a K-sharded handle, not approximated; a handle with
-    link_thresh < 1/2 cannot leave the log-domain exchange"""
+    """plain sweeps / steps and node-block mini-batches are refused on a K-sharded handle, not approximated; a handle
+    with link_thresh < 1/2 cannot leave the log-domain exchange"""
     from svinet_amd import _svils
     from svinet_amd.host_api import Setup
     setup = Setup(graph_files["lfr"], 1000, 100)
@@ -255,7 +317,7 @@ def test_ksharded_rejects_what_it_does_not_do(graph_files):
         low.ksh_log_domain(False)
     eng = _svils.Engine(1000, 100, link_thresh=0.5, **kw)
     with pytest.raises(_svils.SvilsError, match="K-sharded"):
-        eng.set_stochastic(batch_nodes=100)
+        eng.set_stochastic(batch_nodes=100, shard_block=500)
     eng.set_graph(setup.links)
     eng.set_validation(setup.validation_sorted)
     eng.set_state(np.ascontiguousarray(setup.gamma[:, :50]), np.ascontiguousarray(setup.lam[:50]))

@@ -177,6 +177,30 @@ def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mo
     assert stats[0][2] == per_sweep * sweeps + 2 + 2
 
 
+@pytest.mark.parametrize("world,k,nwin,steps", [(2, 28, 3, 45), (3, 100, 4, 16)])
+def test_native_step_ksharded_ranks(graph_files, tmp_path, world, k, nwin, steps):
+    """svils_step_ksharded in `world` processes: every rank steps through the same windows on its own columns, the
+    exchanges carry the window's share of the buffers (svils_ksh_buffer_ptr's sub-ranges).  The slices put together equal
+    svils_step on one plain handle with the same windows and step sizes."""
+    from svinet_amd.host_api import Setup
+    path, n = graph_files["lfr"], 1000
+    states, stats = _run_ranks(tmp_path, path, n, k, steps, world, "kstep:%d:0.6" % nwin)
+    setup = Setup(path, n, k)
+    plain = setup.engine(use_validation_stop=False)
+    plain.set_stochastic(batch_nodes=(n + nwin - 1) // nwin, tau0=4.0, kappa=0.6, node_tau0=2.0, node_kappa=0.5)
+    plain.step(steps)
+    pg, pl, pc = plain.state()
+    g = np.concatenate([s["gamma"] for s in states], 1)
+    lam = np.concatenate([s["lam"] for s in states], 0)
+    assert np.max(np.abs(g - pg) / np.abs(pg)) < 1e-9
+    assert np.max(np.abs(lam - pl) / np.abs(pl)) < 1e-9
+    for s in states:
+        assert np.array_equal(s["conv"], pc)
+        assert int(s["iter"]) == steps
+        np.testing.assert_allclose(s["rows"][:, 1:], plain.rows()[:, 1:], rtol=1e-8, atol=1e-11)
+    assert stats[0][2] == 4 * steps + 2 + 2        # per step den, rowx, q2v, vdot; + init rows, the constructor row, the staged gather
+
+
 # ----------------------------------------------------------------------------------------- the CLI, forked ranks
 def _cli(tmp_path, args, world, timeout=900, env=None):
     env = env or _env(tmp_path)
