@@ -224,8 +224,8 @@ void LinkSampling::attach() {
   if (env_.kshard) {
     const uint32_t w = k1_ - k0_;
     std::vector<double> g((size_t)n_ * w);
-    for (uint32_t i = 0; i < n_; ++i)
-      std::copy(&gamma_[(size_t)i * k_ + k0_], &gamma_[(size_t)i * k_ + k0_] + w, &g[(size_t)i * w]);
+    for (uint32_t i = 0; i < n_; ++i)   // (-minibatch: rows in the relabelled order)
+      std::copy(&gamma_[(size_t)i * k_ + k0_], &gamma_[(size_t)i * k_ + k0_] + w, &g[(size_t)(dev_of_.empty() ? i : dev_of_[i]) * w]);
     if (svils_set_state(h_, g.data(), &lambda_[2 * (size_t)k0_], nullptr)) die_svils("svils_set_state");
     if (svils_ksh_init_state(h_)) die_svils("svils_ksh_init_state");
   } else if (dev_of_.empty()) {
@@ -657,7 +657,9 @@ int LinkSampling::sweep_loop() {
     if (env_.max_iterations) batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - c.iter);
     printf("\riteration %d: processing %d links", c.iter, (int)nlinks);
     fflush(stdout);
-    if (env_.minibatch && env_.sharded) {
+    if (env_.minibatch && env_.kshard) {
+      if (svils_step_ksharded(h_, batch)) die_svils("svils_step_ksharded");
+    } else if (env_.minibatch && env_.sharded) {
       if (svils_step_sharded(h_, batch)) die_svils("svils_step_sharded");
     } else if (env_.minibatch) {
       if (svils_step(h_, batch)) die_svils("svils_step");

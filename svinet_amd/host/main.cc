@@ -73,7 +73,8 @@ static void usage() {
           "\t-sharded\ttake the -gpus N code path with one GPU as well (a communicator of one rank)\n\n"
           "\t-kshard\t\twith -gpus N: shard the K communities over the N GPUs (every GPU holds K/N columns of all rows;\n"
           "\t\t\tper sweep four all-reduces of O(links) doubles instead of an all-gather of the rows) -- the\n"
-          "\t\t\tlayout for large K (-link-thresh < 0.5 adds two exchanges of one double per link: the arg-max tagging rule)\n\n"
+          "\t\t\tlayout for large K (-link-thresh < 0.5 adds two exchanges of one double per link: the arg-max tagging rule);\n"
+          "\t\t\twith -minibatch <m> every GPU steps through the same windows of m nodes on its own columns\n\n"
           "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
           "\t-sparse-after <i>\tthe active-set branch of the phi pass is used once the iteration count exceeds i\n"
           "\t\t\t(default 1000, the reference's constant)\n\n"
@@ -167,8 +168,8 @@ int main(int argc, char **argv) {
             unsupported ? "; unsupported option " : "", unsupported ? unsupported_flag.c_str() : "");
     return 2;
   }
-  if (a.kshard && (a.minibatch || !a.link_sampling)) {
-    fprintf(stderr, "error: -kshard belongs to full-sweep -link-sampling runs\n");
+  if (a.kshard && !a.link_sampling) {
+    fprintf(stderr, "error: -kshard belongs to -link-sampling runs\n");
     return -1;
   }
   if (a.n == 0 || a.k == 0) {

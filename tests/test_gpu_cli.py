@@ -189,10 +189,22 @@ def test_cli_kshard_world_of_one(graph_files, tmp_path):
     np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
 
 
-def test_cli_kshard_refuses_what_it_cannot_do(graph_files, tmp_path):
-    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-kshard", "-minibatch", "64"],
-             str(tmp_path))
-    assert r.returncode != 0 and "-kshard" in r.stderr
+def test_cli_kshard_minibatch_world_of_one(graph_files, tmp_path):
+    """`svinet -gpus 1 -kshard -minibatch m`: svils_step_ksharded behind the command line (relabelling, slice hand-over in
+    the relabelled order, the gathers behind the files); the same files as the plain mini-batch run"""
+    args = ["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-rfreq", "5", "-no-stop",
+            "-max-iterations", "99", "-minibatch", "200", "-tau0", "1", "-kappa", "0.5", "-nodetau0", "1",
+            "-nodekappa", "0.5", "-sweep-batch", "5"]
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = _run(args, str(tmp_path / "a"))
+    rb = _run(args + ["-gpus", "1", "-kshard"], str(tmp_path / "b"))
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    da, db = tmp_path / "a" / "n1000-k28-mmsb-linksampling", tmp_path / "b" / "n1000-k28-mmsb-linksampling"
+    _cmp_numeric(da / "gamma.txt", db / "gamma.txt", 2, 2.1e-5)
+    _cmp_numeric(da / "lambda.txt", db / "lambda.txt", 1, 2.1e-5)
+    assert (da / "communities.txt").read_text() == (db / "communities.txt").read_text()
+    va, vb = np.loadtxt(da / "validation.txt"), np.loadtxt(db / "validation.txt")
+    np.testing.assert_allclose(np.delete(va, 1, axis=1), np.delete(vb, 1, axis=1), rtol=0, atol=2e-9)
 
 
 def test_cli_kshard_link_thresh_below_one_half(graph_files, tmp_path):

@@ -256,6 +256,25 @@ def test_cli_gpus_minibatch_ranks(graph_files, tmp_path):
     assert v.shape[0] >= 20 and v[-1, 10] > v[1, 10]
 
 
+def test_cli_gpus_kshard_minibatch_ranks(graph_files, tmp_path):
+    """`svinet -gpus 2 -kshard -minibatch m`: two forked ranks, every one a column slice, stepping through the same
+    windows -- the files equal those of the plain one-process mini-batch run (same windows, same step sizes)"""
+    path, n, k = graph_files["lfr"], 1000, 28
+    args = ["-file", path, "-n", str(n), "-k", str(k), "-link-sampling", "-rfreq", "5", "-no-stop", "-max-iterations", "59",
+            "-minibatch", "250", "-tau0", "2", "-kappa", "0.5", "-nodetau0", "2", "-nodekappa", "0.5", "-sweep-batch", "5"]
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = subprocess.run([SVINET] + args, cwd=str(tmp_path / "a"), capture_output=True, text=True, timeout=600)
+    assert ra.returncode == 0, ra.stderr[-2000:]
+    rb = _cli(tmp_path / "b", args + ["-kshard"], 2, env=_env(tmp_path))
+    assert rb.returncode == 0, (rb.stdout[-2000:], rb.stderr[-3000:])
+    da, db = tmp_path / "a" / "n1000-k28-mmsb-linksampling", tmp_path / "b" / "n1000-k28-mmsb-linksampling"
+    _cmp_numeric(da / "gamma.txt", db / "gamma.txt", 2, 2.1e-5)
+    _cmp_numeric(da / "lambda.txt", db / "lambda.txt", 1, 2.1e-5)
+    assert (da / "communities.txt").read_text() == (db / "communities.txt").read_text()
+    va, vb = np.loadtxt(da / "validation.txt"), np.loadtxt(db / "validation.txt")
+    np.testing.assert_allclose(np.delete(va, 1, axis=1), np.delete(vb, 1, axis=1), rtol=0, atol=2e-9)
+
+
 def test_cli_gpus_rank_failure_does_not_hang(graph_files, tmp_path):
     """a rank that dies (here: a device ordinal that does not exist) takes the others with it instead of leaving
     them in a collective for ever; the parent returns non-zero (reaping in completion order)"""
