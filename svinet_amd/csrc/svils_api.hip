@@ -114,7 +114,7 @@ namespace {
 template <class T>
 int dalloc(svils_handle *h, T **p, size_t count, bool zero = true) {
   *p = nullptr;
-  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 512;   // slack: chunked row loads may run past the last row
   void *q = nullptr;
   HIPCHK(hipMalloc(&q, bytes));
   h->allocs.push_back(q);
@@ -342,6 +342,17 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   g.n_alloc = std::max(cfg->n_alloc, cfg->n);
   g.K = cfg->k;
   g.ld = (cfg->k + 15u) & ~15u;  // rows are 128-byte aligned
+  // Lane-per-link layout (K <= 56): rows packed at ld = K rounded to even (16-byte aligned, which is all the chunked
+  // double2 loads need): 160-byte rows at K = 20 instead of a 256-byte stride.  The finalise pass leaves fewer bytes
+  // dirty (the boundary behind it drains them), a phi row's two lines carry no padding and the n-by-k state fits one
+  // XCD's L2 (2.9 instead of 4.6 MB per array on ca-AstroPh).  profiles/r03r_packed_rows.txt: ca-AstroPh K=20
+  // 54.7 -> 53.7 us per sweep (phi 24.3 -> 22.6), LFR K=28 35.4 -> 34.5, ca-AstroPh K=28 76.7 -> 75.4.  A kernel
+  // instantiated for more columns than K reads a few doubles of the next row (masked: Elogbeta = -inf there); every
+  // allocation carries slack for the last row.  SVILS_PACK_ROWS=0 restores the padded stride (A/B).
+  {
+    const char *e = getenv("SVILS_PACK_ROWS");
+    if ((!e || atoi(e)) && use_lpl(cfg->k) && !cfg->k_total) g.ld = (cfg->k + 1u) & ~1u;
+  }
   g.k10 = cfg->k / 10;           // integer division, src/linksampling.cc:465,634
   g.node_begin = nb;
   g.node_end = ne;
