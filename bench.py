@@ -535,8 +535,9 @@ def main():
             "data": data,
             "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
-                       "parallelism": ("one chain, node-block sharding x%d: per sweep one grouped RCCL all-gather (gamma rows n*ld*8 B + packed "
-                                       "flags) and one grouped all-reduce (K + 3K doubles) -- while annealing (the first ~20 sweeps "
+                       "parallelism": ("one chain, node-block sharding x%d: per sweep the gamma rows (n*ld*8 B) + packed flags of every block (one "
+                                       "grouped RCCL all-gather; above 128 MB in chunks on a stream of their own, each expanded while the next "
+                                       "travels) and one grouped all-reduce (K + 3K doubles) -- while annealing (the first ~20 sweeps "
                                        "here) the K-vector sum[k] is all-reduced on its own before the finalise pass, a third "
                                        "exchange point -- issued by the device library between the phases (svils_sweep_sharded)" % world) if world > 1 else "single GPU",
                        "converged_nodes_at_end": int((conv > 0).sum()),
