@@ -175,3 +175,31 @@ def test_softmax_rows_that_underflow(k):
         np.testing.assert_allclose(gg, ref.gamma, rtol=1e-7)
         np.testing.assert_allclose(ll, ref.lam, rtol=1e-7)
         assert np.array_equal(conv, ref.converged)
+
+
+@pytest.mark.parametrize("graph,n,k,sweeps", [("lfr", 1000, 28, 40), ("astroph", 17903, 20, 6), ("lfr", 1000, 8, 12)])
+def test_small_k_on_a_graph_too_large_for_the_class_lists(graph_files, graph, n, k, sweeps, monkeypatch):
+    """The class lists of the lane-per-link layout pack an entry index into 27 bits; a graph of 2^26 training links or
+    more takes the row-per-wavefront kernels at small K too instead of being refused.  SVILS_LPL_MAX_ENTRIES
+    lowers the switch-over point so that the fallback runs on the example graphs: against the oracle."""
+    from svinet_amd.host_api import Setup
+    monkeypatch.setenv("SVILS_LPL_MAX_ENTRIES", "1000")
+    setup = Setup(graph_files[graph], n, k)
+    eng = setup.engine(use_validation_stop=False)
+    monkeypatch.delenv("SVILS_LPL_MAX_ENTRIES")
+    eng.sweep(sweeps)
+    ref = O.LinkSampling(O.Network(graph_files[graph], n), k, use_validation_stop=False)
+    for _ in range(sweeps):
+        ref.sweep()
+    g, lam, conv = eng.state()
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    assert np.array_equal(conv, ref.converged)
+    c = eng.control()
+    assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
+    assert np.array_equal(eng.communities(), ref.communities())
+    np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-8, atol=1e-11)
+    # ... and it really was the other layout: the same run on the lane-per-link kernels differs in the last bits
+    lpl = setup.engine(use_validation_stop=False)
+    lpl.sweep(sweeps)
+    assert not np.array_equal(lpl.state()[0], g)
