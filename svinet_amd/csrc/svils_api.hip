@@ -1113,13 +1113,20 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     d.nb_a = cap((phi_items + nw - 1) / nw, std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_phi_resident_blocks(g.K, h->cfg.device)));
     // finalise pass: 12-wave blocks of 64 / lpl_finalize_group(K) nodes per wavefront, as many as the device holds at
     // once (one per CU at its register budget); larger graphs loop inside the blocks
-    const uint32_t fnodes = lpl_finalize_waves() * (64u / (uint32_t)lpl_finalize_group(g.K));
+    const uint32_t fnodes = lpl_finalize_waves(g.K) * (64u / (uint32_t)lpl_finalize_group(g.K));
     d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fnodes - 1) / fnodes,
                  std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_finalize_resident_blocks(g.K, h->cfg.device)));
     d.s3_threads = lpl_s3_threads(g.K);
     d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 classification blocks
   }
 
+  {
+    // fixed-point scale of sum[k] <= 2 L (lane-per-link layout, svils_devutil.h: fx_add): 2^shift * (2 L + 2) < 2^61
+    int bits = 1;
+    while ((1ull << bits) < 2 * nlinks + 2) ++bits;
+    d.fx_scale = std::ldexp(1.0, 61 - bits);
+    d.fx_inv = std::ldexp(1.0, bits - 61);
+  }
   int rc = 0;
   auto guard = [&](int r) { if (r && !rc) rc = r; };
   guard(dalloc(h, &d.rowptr, (size_t)n + 1, false));
@@ -1156,7 +1163,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     if (g.K <= 32) guard(dalloc(h, &d.gacc0, (size_t)g.n_alloc * g.ld));   // three-launch sweeps accumulate beside gamma
     // ltot [2][8] u32 | shist [2][K] u64, cleared together before a stand-alone classification
     const size_t shist_bytes = ((2 * (size_t)g.K * sizeof(unsigned long long)) + 63) / 64 * 64;
-    h->cls_zero_bytes = 64 + shist_bytes + 2 * 8 * 64 * sizeof(long long);   // ... | sumfx [2][8][64] i64
+    h->cls_zero_bytes = 64 + shist_bytes + 2 * 8 * 2 * 64 * sizeof(long long);   // ... | sumfx [2][8][hi|lo][64] i64
     unsigned char *cz = nullptr;
     guard(dalloc(h, &cz, h->cls_zero_bytes));
     h->cls_zero = cz;
@@ -1164,11 +1171,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
       d.ltot = reinterpret_cast<uint32_t *>(cz);
       d.shist = reinterpret_cast<unsigned long long *>(cz + 64);
       d.sumfx = reinterpret_cast<long long *>(cz + 64 + shist_bytes);
-      // sum[k] <= 2 * nlinks: 2^fx_shift * (2 * nlinks + 2) < 2^61
-      int bits = 1;
-      while ((1ull << bits) < 2 * nlinks + 2) ++bits;
-      d.fx_scale = std::ldexp(1.0, 61 - bits);
-      d.fx_inv = std::ldexp(1.0, bits - 61);
+
     }
   }
   guard(dalloc(h, &d.part_a, (size_t)d.nb_a * g.K));
@@ -1546,7 +1549,7 @@ int open_step(svils_handle *h) {
       const int nw = lpl_phi_waves(g.K);
       const uint64_t items = ((d.ent_end - d.ent_begin + 63) >> 6) + 1;
       d.nb_a = fit((items + nw - 1) / nw, h->d.nb_a);
-      const uint32_t fnodes = lpl_finalize_waves() * (64u / (uint32_t)lpl_finalize_group(g.K));
+      const uint32_t fnodes = lpl_finalize_waves(g.K) * (64u / (uint32_t)lpl_finalize_group(g.K));
       d.nb_b = fit(((uint64_t)(e - b) + fnodes - 1) / fnodes, h->d.nb_b);
       d.nb_c = fit((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, h->d.nb_c);
     } else {

@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
       if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
       for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) d.shist[(size_t)cpar0 * K + k] = 0ull;
     }
-    for (uint32_t k = threadIdx.x; k < 512u; k += blockDim.x) d.sumfx[(size_t)cpar0 * 512 + k] = 0;
+    for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) d.sumfx[(size_t)cpar0 * 1024 + k] = 0;
   }
 }
 

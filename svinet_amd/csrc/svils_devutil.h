@@ -294,6 +294,22 @@ __device__ __forceinline__ bool last_block_arrives(uint32_t *ticket, uint32_t nb
   return *lds_flag != 0u;
 }
 
+// ------------------------------------------ fixed-point accumulation of block partials (integer atomics: order-free)
+// A double s with |s| * scale < 2^61 (scale a power of two) is split into hi = rint(s * scale) and
+// lo = rint((s * scale - hi) * 2^40): both exact except for bits of s below 2^-40 / scale, so the sum of the pairs over
+// any number of blocks, in any order, is the correctly rounded sum of the block partials to ~1e-12 ulp-of-scale --
+// tiny columns (a dead community's sum[k]) keep their relative accuracy.  |lo| <= 2^39 per block.
+constexpr double SVILS_FX_LO = 1099511627776.0;   // 2^40
+__device__ __forceinline__ void fx_add(long long *hi, long long *lo, double s, double scale) {
+  const double t = s * scale, q = rint(t);
+  const long long qh = (long long)q, ql = (long long)rint((t - q) * SVILS_FX_LO);
+  if (qh) __hip_atomic_fetch_add(hi, qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ql) __hip_atomic_fetch_add(lo, ql, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fx_value(long long hi, long long lo, double inv) {
+  return ((double)hi + (double)lo * (1.0 / SVILS_FX_LO)) * inv;
+}
+
 // ------------------------------------------ column sums of a few per-block partial rows
 // out[c] = sum_r part[r][c], r < nrows (<= SVILS_FOLD_ROWS), c < ncols <= CW, by the whole block in
 // a fixed order (row groups of NT/CW, NT = blockDim.x, then the groups in order): every block that folds the

@@ -201,8 +201,11 @@ __global__ __launch_bounds__(256) void k_validate_lpl(Geometry geo, DeviceState 
 #ifndef LPL_MID_OCC
 #define LPL_MID_OCC 2
 #endif
+#ifndef LPL_MID_KC   // smallest KC that takes the LPL_MID_* shape
+#define LPL_MID_KC 14
+#endif
 template <int KC, int NW, bool PIPE>
-__global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID_OCC : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ? LPL_MID_OCC : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(0, 0);
   DevCtrl *ctrl = d.ctrl;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
@@ -515,8 +518,8 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID
       // whole sweeps driven by the library: one fixed-point integer atomic per column into this XCD's accumulator
       // (k_finalize_lpl adds the eight of them and the shortcut histogram)
       const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID, bits [3:0]
-      __hip_atomic_fetch_add(&d.sumfx[((size_t)cpar * 8 + xcc) * 64 + threadIdx.x], (long long)rint(t * d.fx_scale),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long *w = &d.sumfx[(((size_t)cpar * 8 + xcc) * 2) * 64 + threadIdx.x];   // [parity][xcc][hi | lo][64]
+      fx_add(w, w + 64, t, d.fx_scale);
     } else {
       if (blockIdx.x == 0) t += (double)d.shist[(size_t)cpar * K + threadIdx.x];
       d.part_a[(size_t)blockIdx.x * K + threadIdx.x] = t;
@@ -542,10 +545,9 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= 14 ? LPL_MID
 template <int W>
 __device__ __forceinline__ unsigned long long group_mask() { return W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull); }
 
-constexpr int FIN_THREADS = 768, FIN_WAVES = FIN_THREADS / 64;
-#ifndef FIN_OCC
-#define FIN_OCC 3
-#endif
+// 12-wave blocks at three waves per SIMD (<= 168 VGPRs); four communities per lane (K = 25..32, 49..56) need a few more
+// than that: 8-wave blocks at two per SIMD
+constexpr int fin_threads(int nc) { return nc >= 4 ? 512 : 768; }
 
 struct FinIdx {
   uint32_t r[3][2];   // npos[l][p], npos[l][p + 1]
@@ -561,12 +563,13 @@ __device__ __forceinline__ FinIdx fin_load_idx(const DeviceState &d, uint32_t p,
 }
 
 template <int FW, int NC, bool STOCH>
-__global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
+__global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(1, 0);
   DevCtrl *ctrl = d.ctrl;
   constexpr int G = 64 / FW;
   __shared__ double2 logtab[128];
   __shared__ double ksum[64];
+  constexpr int FIN_WAVES = fin_threads(NC) / 64;
   __shared__ double s12l[FIN_WAVES][FW][2 * NC];
   __shared__ uint32_t shh[FIN_WAVES][G * FW * NC];   // per-group histogram of shortcut columns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -580,15 +583,18 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
   const uint32_t stopped = ctrl->stopped, c_ann = (uint32_t)ctrl->annealing, c_wc = ctrl->write_comm, c_par = ctrl->parity;
   // `sum` of a whole sweep (fold): the eight per-XCD fixed-point accumulators + the shortcut histogram, both halves
   // requested now (the half in use is known once the control block has landed)
-  long long fx[2][8];
-  unsigned long long sh2[2] = {0ull, 0ull};
+  // (summed per half right away: four live words instead of 32 until the control block says which half it is)
+  long long ah0 = 0, al0 = 0, ah1 = 0, al1 = 0;
+  unsigned long long sh0 = 0ull, sh1 = 0ull;
   if (d.fold && threadIdx.x < 64) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int x = 0; x < 8; ++x) fx[h][x] = d.sumfx[((size_t)h * 8 + x) * 64 + threadIdx.x];
-      if (threadIdx.x < K) sh2[h] = d.shist[(size_t)h * K + threadIdx.x];
+    for (int x = 0; x < 8; ++x) {   // [parity][xcc][hi | lo][64]
+      ah0 += d.sumfx[(size_t)(2 * x) * 64 + threadIdx.x];
+      al0 += d.sumfx[(size_t)(2 * x + 1) * 64 + threadIdx.x];
+      ah1 += d.sumfx[(size_t)(16 + 2 * x) * 64 + threadIdx.x];
+      al1 += d.sumfx[(size_t)(16 + 2 * x + 1) * 64 + threadIdx.x];
     }
+    if (threadIdx.x < K) { sh0 = d.shist[threadIdx.x]; sh1 = d.shist[(size_t)K + threadIdx.x]; }
   }
   const uint32_t c_cpar = ctrl->cls_par, c_epoch = ctrl->sweeps_done + 1u;
   load_logtab(logtab, d.logtab);
@@ -714,10 +720,7 @@ __global__ __launch_bounds__(FIN_THREADS, FIN_OCC) void k_finalize_lpl(Geometry 
       if (threadIdx.x < 64) {
         double t = 1.0;
         if (d.fold) {
-          long long a = 0;
-#pragma unroll
-          for (int x = 0; x < 8; ++x) a += fx[c_cpar & 1u][x];
-          t = (double)a * d.fx_inv + (double)sh2[c_cpar & 1u];
+          t = (c_cpar & 1u) ? fx_value(ah1, al1, d.fx_inv) + (double)sh1 : fx_value(ah0, al0, d.fx_inv) + (double)sh0;
           if (blockIdx.x == 0 && threadIdx.x < K) d.kvec_a[threadIdx.x] = t;
         } else if (threadIdx.x < K) {
           t = d.kvec_a[threadIdx.x];
@@ -1064,7 +1067,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
         if (threadIdx.x < 8) ltot[threadIdx.x] = 0;
         if (threadIdx.x < K) d.shist[(size_t)cpar0 * K + threadIdx.x] = 0ull;
       }
-      if (threadIdx.x < 512) d.sumfx[(size_t)cpar0 * 512 + threadIdx.x] = 0;
+      for (uint32_t i = threadIdx.x; i < 1024u; i += NTH) d.sumfx[(size_t)cpar0 * 1024 + i] = 0;   // (blocks of 512 or 1024 threads)
       STAMP(2, 5);
     }
   }
@@ -1086,8 +1089,8 @@ bool use_lpl(uint32_t K) { return K <= 56; }
 #define LPL_PIPE 0
 #endif
 constexpr bool lpl_pipe(int kc) { return LPL_PIPE && kc <= 16; }
-constexpr int lpl_waves(int kc) { return lpl_pipe(kc) ? LPL_PIPE_WAVES : kc >= 18 ? 4 : kc >= 14 ? LPL_MID_NW : 8; }
-int lpl_phi_waves(uint32_t K) { return LPL_PIPE && K <= 32 ? LPL_PIPE_WAVES : K > 32 ? 4 : K > 24 ? LPL_MID_NW : 8; }
+constexpr int lpl_waves(int kc) { return lpl_pipe(kc) ? LPL_PIPE_WAVES : kc >= 18 ? 4 : kc >= LPL_MID_KC ? LPL_MID_NW : 8; }
+int lpl_phi_waves(uint32_t K) { return LPL_PIPE && K <= 32 ? LPL_PIPE_WAVES : K > 32 ? 4 : K > (LPL_MID_KC == 12 ? 20 : 24) ? LPL_MID_NW : 8; }
 
 #define LPL_DISPATCH(K_, CALL)                 \
   do {                                         \
@@ -1135,7 +1138,7 @@ uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K) {
 void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   hipLaunchKernelGGL(k_validate_lpl, dim3(d.nvb ? d.nvb : 1u), dim3(256), 0, s, g, d, p);
 }
-uint32_t lpl_finalize_waves() { return FIN_WAVES; }
+uint32_t lpl_finalize_waves(uint32_t K) { return (uint32_t)fin_threads((K > 24 && K <= 32) || K > 48 ? 4 : 3) / 64u; }
 // classification blocks riding on the s3 launch (one worker per 256 threads, ideally one tile each)
 uint32_t lpl_cls_blocks(const DeviceState &d) {
   if (!d.cls_next) return 0;
@@ -1183,7 +1186,7 @@ int lpl_finalize_group(uint32_t K) { return K <= 32 ? 8 : 16; }
 // blocks of k_finalize_lpl the device holds at once (the full-sweep instantiation)
 uint32_t lpl_finalize_resident_blocks(uint32_t K, int device) {
   int per_cu = 0, cus = 0;
-#define FIN(W_, NC_) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_finalize_lpl<W_, NC_, false>, FIN_THREADS, 0)
+#define FIN(W_, NC_) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_finalize_lpl<W_, NC_, false>, fin_threads(NC_), 0)
   FIN_DISPATCH(K, FIN);
 #undef FIN
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -1193,8 +1196,8 @@ uint32_t lpl_finalize_resident_blocks(uint32_t K, int device) {
 void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define FIN(W_, NC_)                                                                                \
   do {                                                                                              \
-    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, true>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p); \
-    else hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false>), dim3(d.nb_b), dim3(FIN_THREADS), 0, s, g, d, p);  \
+    if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, true>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p); \
+    else hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p);  \
   } while (0)
   FIN_DISPATCH(g.K, FIN);
 #undef FIN

@@ -1,4 +1,9 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03u; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_fuzz.py -q -m gpu --timeout 900 -k "too_large" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-tail -30 $O/pytest.log
+O=gpurun_out/r03y; mkdir -p $O
+for rep in 1 2; do
+for wl in astroph-k20 astroph-k200 lfr-k28; do
+python bench.py --no-hbm-bound --no-config5 --no-cpu-baseline --reps 30 --workload $wl 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$wl', d['ms_per_step'], d['repeat']['min_ms_per_step'], d['roofline']['avg_launch_us'])" | tee -a $O/bench2.txt
+done
+done
+python bench.py --steps 2000 --warmup 200 > $O/bench_driver.json 2>$O/bench_driver.err; tail -c 600 $O/bench_driver.json
