@@ -33,6 +33,29 @@ class _Config(C.Structure):
 
 
 _lib = None
+_lib_omp = None
+_SO_OMP = os.path.join(_HERE, "libsvinet_oracle_omp.so")
+
+
+def lib_omp():
+    """libsvinet_oracle_omp.so: the threaded sweep behind bench.py's cpu_baseline_allcores (NOT the reference's
+    summation order -- see svinet_oracle_omp.c).  Handles come from lib(); the struct layout is the same translation unit."""
+    global _lib_omp
+    if _lib_omp is not None:
+        return _lib_omp
+    srcs = [os.path.join(_HERE, f) for f in ("svinet_oracle_omp.c", "svinet_oracle.c", "svinet_oracle.h")]
+    try:
+        if not os.path.exists(_SO_OMP) or os.path.getmtime(_SO_OMP) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "libsvinet_oracle_omp.so"], stdout=subprocess.DEVNULL)
+    except Exception:
+        if not os.path.exists(_SO_OMP):
+            raise
+    L = C.CDLL(_SO_OMP)
+    L.orc_ls_sweep_omp.restype = C.c_int
+    L.orc_ls_sweep_omp.argtypes = [C.c_void_p, C.c_int]
+    L.orc_omp_max_threads.restype = C.c_int
+    _lib_omp = L
+    return L
 
 ETA_TYPES = {"uniform": 0, "fromdata": 1, "sparse": 2, "dense": 3}
 
@@ -198,6 +221,10 @@ class LinkSampling:
 
     def sweep(self):
         return lib().orc_ls_sweep(self._h)
+
+    def sweep_omp(self, nthreads):
+        """threaded sweep (all-cores CPU figure only; rounding differs from sweep())"""
+        return lib_omp().orc_ls_sweep_omp(self._h, int(nthreads))
 
     def set_skip_validation(self, skip):
         lib().orc_ls_set_skip_validation(self._h, int(skip))
