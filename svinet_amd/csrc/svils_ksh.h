@@ -392,16 +392,19 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
 // compute_mean_indicators + swap (src/linksampling.cc:526-545,751-755) on the own columns; what set_dir_exp and
 // prune need from the WHOLE row goes to rowx[p] as this rank's partial: sum_k gamma, |{k: gamma - alpha >= 1}|,
 // sum of (community + 1) over that set (the community itself when the set has one element).
-template <int V, bool STOCH>
+// W = 64: one node per wavefront, V columns per lane.  W = 16, V = 4 (slices of <= 64 columns, see k_phi_ksh16): FOUR
+// nodes per wavefront, one per 16-lane row, so that a 512-byte row does not pay a wavefront's fixed costs alone and
+// every lane carries four independent chains.
+template <int W, int V, bool STOCH>
 __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, Params prm, int init) {
-  constexpr int W = 64;
+  constexpr int G = 64 / W;
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double lds[2 * V * 64];
   __shared__ double2 logtab[128];
   if constexpr (STOCH) { load_logtab(logtab, d.logtab); __syncthreads(); }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lw = lane;
+  const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
   const bool annealing = ctrl->annealing != 0;
   const bool write_comm = ctrl->write_comm != 0;
@@ -419,7 +422,9 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
 #pragma unroll
   for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
   // full sweeps: every node; mini-batch steps: the window [node_begin, node_end)
-  for (uint32_t p = geo.node_begin + blockIdx.x * 4 + wave; p < geo.node_end; p += gridDim.x * 4) {
+  for (uint32_t p0 = geo.node_begin + (blockIdx.x * 4 + wave) * G; p0 < geo.node_end; p0 += gridDim.x * 4 * G) {
+    const bool ok = p0 + (uint32_t)g < geo.node_end;       // (G > 1: the last wavefront's rows past the end idle on p0's node)
+    const uint32_t p = ok ? p0 + (uint32_t)g : p0;
     double gn[V];
     if (init) {
       load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
@@ -441,7 +446,11 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
 #pragma unroll
           for (int v = 0; v < V; ++v) acc[v] += part[v];
         }
-        if (write_comm) {
+      }
+      // tags of a node whose entries were split over several wave-items (the others were tagged by the phi pass)
+      if constexpr (W == 64) {
+        if (sf >= 0 && write_comm) {
+          const uint32_t sc = d.split_cnt[p];
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             uint32_t c = 0;
@@ -451,6 +460,21 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
             if (lw == 0) d.member[(size_t)p * geo.kw + v] = b;
           }
         }
+      } else if (write_comm) {          // one word per node (bit k = column k of the slice); wave-uniform branch
+        unsigned long long w = 0ull;
+        if (sf >= 0) {
+          const uint32_t sc = d.split_cnt[p];
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            uint32_t c = 0;
+            if (kval[v])
+              for (uint32_t t = 0; t < sc; ++t) c += d.part_cnt[(size_t)(sf + t) * ld + kidx[v]];
+            if (kval[v] && c > prm.lt_min_deg) w |= 1ull << kidx[v];
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < W; o <<= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, 64);
+        if (sf >= 0 && ok && lw == 0) d.member[p] = w;
       }
       if (tl > 0.0) {
         double m[V];
@@ -460,7 +484,7 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
           m[v] = (g0 - prm.alpha) / tl;
           gn[v] = g0 + ((double)geo.n - tl - 1.0) * m[v];
           if (annealing) gn[v] *= scale[v];
-          if (kval[v]) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; }
+          if (kval[v]) { if (ok) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; } }
           else { m[v] = 0.0; gn[v] = 0.0; }
         }
         if constexpr (STOCH) {
@@ -475,17 +499,16 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
           for (int v = 0; v < V; ++v)
             if (kval[v]) {
               gn[v] = (1.0 - rho) * gold[v] + rho * gn[v];
-              s12[0][v] -= mold[v];
-              s12[1][v] -= mold[v] * mold[v];
+              if (ok) { s12[0][v] -= mold[v]; s12[1][v] -= mold[v] * mold[v]; }
             }
-          if (lane == 0) d.ncnt[p] = c + 1u;
+          if (lw == 0 && ok) d.ncnt[p] = c + 1u;
         }
-        store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+        if (ok) store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
       } else {
 #pragma unroll
         for (int v = 0; v < V; ++v) gn[v] = kval[v] ? prm.alpha : 0.0;
       }
-      store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+      if (ok) store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
     }
     double rs = 0.0, na = 0.0, ix = 0.0;
 #pragma unroll
@@ -496,28 +519,30 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
       ix += act ? (double)(geo.K0 + (uint32_t)kidx[v] + 1u) : 0.0;
     }
     rs = group_sum<W>(rs); na = group_sum<W>(na); ix = group_sum<W>(ix);
-    if (lane == 0) { d.rowx[3 * (size_t)p] = rs; d.rowx[3 * (size_t)p + 1] = na; d.rowx[3 * (size_t)p + 2] = ix; }
+    if (lw == 0 && ok) { d.rowx[3 * (size_t)p] = rs; d.rowx[3 * (size_t)p + 1] = na; d.rowx[3 * (size_t)p + 2] = ix; }
   }
   if (!init) block_reduce_store<W, V, 2>(s12, d.part_b + (size_t)blockIdx.x * 2 * K, K, lds);
 }
 
 // ---------------------------------------------- node finalise, second half: from the summed rowx
 // set_dir_exp (src/linksampling.hh:170-187) and prune (src/linksampling.cc:455-491) with the row sum and
-// the active set of the whole row; the flags come out identical on every rank.
-template <int V>
+// the active set of the whole row; the flags come out identical on every rank.  (W, V) as in k_fin1_ksh.
+template <int W, int V>
 __global__ __launch_bounds__(256) void k_fin2_ksh(Geometry geo, DeviceState d, Params prm, int init) {
-  constexpr int W = 64;
+  constexpr int G = 64 / W;
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double2 logtab[128];
   load_logtab(logtab, d.logtab);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lw = lane;
+  const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
   const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
   uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
-  for (uint32_t p = geo.node_begin + blockIdx.x * 4 + wave; p < geo.node_end; p += gridDim.x * 4) {
+  for (uint32_t p0 = geo.node_begin + (blockIdx.x * 4 + wave) * G; p0 < geo.node_end; p0 += gridDim.x * 4 * G) {
+    const bool ok = p0 + (uint32_t)g < geo.node_end;
+    const uint32_t p = ok ? p0 + (uint32_t)g : p0;
     double gn[V];
     load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
     const double rs = d.rowx[3 * (size_t)p];
@@ -529,18 +554,32 @@ __global__ __launch_bounds__(256) void k_fin2_ksh(Geometry geo, DeviceState d, P
       el[v] = kv ? digamma(gn[v], logtab) - psi_rs : 0.0;
       ep[v] = kv ? exp_neg(el[v]) : 0.0;
     }
-    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
-    store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, ep);
+    if (ok) {
+      store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+      store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, ep);
+    }
     if (init) continue;
     const uint32_t active = (uint32_t)d.rowx[3 * (size_t)p + 1];
     const uint32_t idx = (uint32_t)d.rowx[3 * (size_t)p + 2];
+    if constexpr (W == 64) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const bool act = (uint32_t)kmap<W, V>(lw, v) < K && (gn[v] - prm.alpha >= 1.0);
-      const unsigned long long bits = __ballot(act);
-      if (lane == 0) d.amask[(size_t)p * geo.kw + v] = (active <= geo.k10) ? bits : 0ull;
+      for (int v = 0; v < V; ++v) {
+        const bool act = (uint32_t)kmap<W, V>(lw, v) < K && (gn[v] - prm.alpha >= 1.0);
+        const unsigned long long bits = __ballot(act);
+        if (lw == 0) d.amask[(size_t)p * geo.kw + v] = (active <= geo.k10) ? bits : 0ull;
+      }
+    } else {                            // one word per node: bit k = column k of the slice
+      unsigned long long w = 0ull;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int k = kmap<W, V>(lw, v);
+        if ((uint32_t)k < K && (gn[v] - prm.alpha >= 1.0)) w |= 1ull << k;
+      }
+#pragma unroll
+      for (int o = 1; o < W; o <<= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, 64);
+      if (lw == 0 && ok) d.amask[p] = (active <= geo.k10) ? w : 0ull;
     }
-    if (lane == 0) {
+    if (lw == 0 && ok) {
       conv_new[p] = (active == 1u) ? idx : conv_old[p];
       d.active_cnt[p] = active;
     }
@@ -846,7 +885,9 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
 
 void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, int phase, hipStream_t s) {
   const uint32_t nodes = g.node_end - g.node_begin;                   // every node, or the window of a mini-batch step
-  const uint32_t nbn = std::max(1u, (nodes + 3) / 4 > 2048 ? 2048 : (nodes + 3) / 4);   // node loops: one node per wavefront
+  const bool narrow = g.V == 1 && KSH_NARROW;                         // slices of <= 64 columns: rows over 16 lanes x 4 doubles
+  const uint32_t npb = narrow ? 16u : 4u;                             // nodes per block of the node loops
+  const uint32_t nbn = std::max(1u, (nodes + npb - 1) / npb > 2048 ? 2048 : (nodes + npb - 1) / npb);
   switch (phase) {
     case 0: {   // DEN
       if (g.V == 1 && KSH_NARROW && !d.ksh_log) { hipLaunchKernelGGL((k_phi_ksh16<1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); break; }
@@ -872,17 +913,21 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
 #undef CALL
       }
       launch_reduce_a(g, d, s);
-#define CALL(V_)                                                                                        \
-  do {                                                                                                  \
-    if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);  \
-    else hipLaunchKernelGGL((k_fin1_ksh<V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);        \
+#define CALL(V_)                                                                                            \
+  do {                                                                                                      \
+    if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<64, V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);  \
+    else hipLaunchKernelGGL((k_fin1_ksh<64, V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);        \
   } while (0)
-      KSH_DISPATCH(g, CALL);
+      if (narrow) {
+        if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<16, 4, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);
+        else hipLaunchKernelGGL((k_fin1_ksh<16, 4, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);
+      } else KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
     case 2: {   // second half of the finalise pass, s3
-#define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 0)
-      KSH_DISPATCH(g, CALL);
+#define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<64, V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 0)
+      if (narrow) hipLaunchKernelGGL((k_fin2_ksh<16, 4>), dim3(nbn), dim3(256), 0, s, g, d, p, 0);
+      else KSH_DISPATCH(g, CALL);
 #undef CALL
       if (p.stoch) launch_carry_flags(g, d, s);   // rows outside the window keep their converged flag across the parity flip
       if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL(k_s3_ksh16, dim3(d.nb_c), dim3(256), 0, s, g, d);
@@ -910,13 +955,15 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
       hipLaunchKernelGGL(k_stop_ksh, dim3(1), dim3(256), 0, s, g, d, p, nvb);
     } break;
     case 5: {   // initial state: partial row sums of the gamma just set
-#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<V_, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
-      KSH_DISPATCH(g, CALL);
+#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<64, V_, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
+      if (narrow) hipLaunchKernelGGL((k_fin1_ksh<16, 4, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1);
+      else KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
     case 6: {   // initial state: Elogpi from the summed row sums
-#define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
-      KSH_DISPATCH(g, CALL);
+#define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<64, V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
+      if (narrow) hipLaunchKernelGGL((k_fin2_ksh<16, 4>), dim3(nbn), dim3(256), 0, s, g, d, p, 1);
+      else KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
     case 7: {   // log-domain mode: per-link max over the own columns (then MAX over the ranks, then DEN)
