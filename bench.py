@@ -262,9 +262,20 @@ def cpu_baseline_allcores(path, pairs, n, k, warmup, steps, budget_s=12.0):
     threaded with OpenMP (oracle/svinet_oracle_omp.c -- the reference's path itself has no threads; sums are taken in
     another order, results equal to rounding: tests/test_oracle_omp.py).  The thread count that is fastest on this
     box among a few tried is reported, with all tried counts listed."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")    # before libgomp loads: idle threads sleep instead of spinning
     from oracle import oracle as O
     net = O.Network(path, n) if path else O.Network(n=n, pairs=pairs)
     ncpu = os.cpu_count() or 1
+    quota = None                                            # CPU-time limit of the container, in cores (None: no limit found)
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):        # cgroup v2
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+        else:                                               # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+    except Exception:
+        pass
     tried, t_all0 = {}, time.perf_counter()
     for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, 256)}):
         if time.perf_counter() - t_all0 > budget_s:
@@ -281,7 +292,8 @@ def cpu_baseline_allcores(path, pairs, n, k, warmup, steps, budget_s=12.0):
     return {"value": tried[best], "unit": "edge-updates/s", "cores": best, "kind": "port-openmp",
             "sample": "oracle sweep threaded with OpenMP (not the reference's code path, which is single-threaded; results "
                       "equal to rounding), first sweeps of the same seeded run, a few sweeps per thread count",
-            "threads_tried": {str(t): v for t, v in tried.items()}, "host_cpus": ncpu}
+            "threads_tried": {str(t): v for t, v in tried.items()}, "host_cpus": ncpu,
+            "cpu_affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota_cores": quota}
 
 
 def _load_workload(name):

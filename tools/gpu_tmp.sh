@@ -1,6 +1,10 @@
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03z; mkdir -p $O
-cd $R
-timeout 1500 python -m pytest tests/test_gpu_ksharded.py tests/test_gpu_native_ranks.py tests/test_gpu_cli.py -q -m gpu --timeout 900 -k "ksh or kshard or kstep" > $O/pytest_ksh.log 2>&1; tail -5 $O/pytest_ksh.log
-python tools/shard_cost.py mmsb:1000000:512:24 8 2>/dev/null | tee $O/cost2_mmsb.txt
-python tools/shard_cost.py astroph-k200 4,8 2>/dev/null | tee $O/cost2_astroph.txt
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03z; mkdir -p $O
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_astroph_k20_steps20.json 2> $O/bench2.err
+python bench.py --no-hbm-bound --no-config5 > $O/bench_astroph_k20.json 2>> $O/bench2.err
+python - <<'PY'
+import json
+for f in ('bench_astroph_k20_steps20','bench_astroph_k20'):
+    d=json.loads(open('gpurun_out/r03z/%s.json'%f).read().strip().split('\n')[-1])
+    print(f,d['ms_per_step'],d['cpu_baseline']['value'],d['cpu_baseline_allcores'])
+PY
