@@ -83,6 +83,10 @@ struct svils_handle {
   // hipGraph replay of whole sweeps (host launch cost: 8 launches x ~7 us per sweep eager)
   static constexpr uint32_t kGraphSweeps = 8;
   hipGraphExec_t gexec1 = nullptr, gexecN = nullptr;   // 1 sweep / kGraphSweeps sweeps
+  // other powers of two up to kGraphMax sweeps, captured on first use: 20 sweeps replay as 16 + 4, 100 as 64 + 32 + 4
+  // (every graph launch is ~4.5 us of idle device: profiles/r03zb_graph_granularity.txt)
+  static constexpr uint32_t kGraphMaxLog = 6;
+  hipGraphExec_t gexecP[kGraphMaxLog + 1] = {};        // [i]: 2^i sweeps (i = 0 and 3 stay null: gexec1, gexecN)
   bool graphs_ok = true;                               // false after a capture failure: stay eager
   std::vector<void *> allocs;
   double *row_scratch = nullptr;  // device [10]
@@ -257,6 +261,7 @@ int run_phase(svils_handle *h, svils_phase ph, bool fused) { return run_phase(h,
 void drop_graphs_of(svils_handle *h) {
   if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
   if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
+  for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
 }
 
 // chunk a row segment [off, off+len) of node p into items of <= ch neighbours
@@ -988,6 +993,7 @@ int svils_destroy(svils_handle *h) {
   for (auto &ev : h->freelist) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
   if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
+  for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
   comm_destroy(h);
   if (h->stage) (void)hipFree(h->stage);
   if (h->stage_flag) (void)hipFree(h->stage_flag);
@@ -1217,6 +1223,7 @@ int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) 
   (void)hipStreamSynchronize(h->stream);
   if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
   if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
+  for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
   h->gexec1 = h->gexecN = nullptr;
 
   if (nv > 0xffffffffull) return fail(SVILS_ERR_UNSUPPORTED, "too many validation pairs");
@@ -1329,6 +1336,7 @@ int eager_sweeps(svils_handle *h, uint32_t nsweeps) {
 void drop_graphs(svils_handle *h) {
   if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
   if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
+  for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
 }
 
 // capture `nsweeps` sweeps of the library's own stream into an executable graph; every kernel
@@ -1395,6 +1403,23 @@ int graph_sweeps(svils_handle *h, uint32_t n) {
   }
   h->sweeps_issued += n;
   if (n) h->v_flush_needed = h->v_flush_capture;   // what a captured sweep leaves behind
+  // as few replays as possible: powers of two from 2^kGraphMaxLog down (SVILS_GRAPH_POW2=0: 8-sweep graphs + singles)
+  static const bool pow2 = !(getenv("SVILS_GRAPH_POW2") && atoi(getenv("SVILS_GRAPH_POW2")) == 0);
+  if (pow2) {
+    for (int i = (int)svils_handle::kGraphMaxLog; i >= 1; --i) {
+      const uint32_t m = 1u << i;
+      if (n < m) continue;
+      hipGraphExec_t *ge = (m == svils_handle::kGraphSweeps) ? &h->gexecN : &h->gexecP[i];
+      if (!*ge) {
+        const uint32_t saved = h->tmask;
+        h->tmask = 0;
+        *ge = capture_sweeps(h, m);
+        h->tmask = saved;
+        if (!*ge) continue;               // (smaller graphs carry the sweeps)
+      }
+      for (; n >= m; n -= m) HIPCHK(hipGraphLaunch(*ge, h->stream));
+    }
+  }
   for (; n >= svils_handle::kGraphSweeps; n -= svils_handle::kGraphSweeps) HIPCHK(hipGraphLaunch(h->gexecN, h->stream));
   for (; n > 0; --n) HIPCHK(hipGraphLaunch(h->gexec1, h->stream));
   return 0;
