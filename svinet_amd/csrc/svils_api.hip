@@ -454,7 +454,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   guard(dalloc(h, &d.sweep_stats, (size_t)d.sweep_stats_cap * 4));
   guard(dalloc(h, &d.stamps, 4 * 1024 * 8));
   guard(dalloc(h, &d.tail_ctl, 4));
-  guard(dalloc(h, &d.tail_part, 256 * 4));
+  guard(dalloc(h, &d.tail_part, SVILS_TAIL_BLOCKS * 4));
   d.nb_t = 1;
   if (rc) { svils_destroy(h); return rc; }
   DevCtrl c;

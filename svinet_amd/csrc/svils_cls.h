@@ -26,16 +26,16 @@ struct ClsWork {
 };
 
 // class of the CSR entry (p, q): 0 softmax, 1 active-set softmax, 2 exactly one endpoint converged
-__device__ __forceinline__ int classify_entry(const uint32_t *__restrict__ cflag, bool sparse_iter, uint32_t p, uint32_t q,
+__device__ __forceinline__ int classify_entry(const uint8_t *__restrict__ cflag, bool sparse_iter, uint32_t p, uint32_t q,
                                               uint32_t *col2) {
-  const uint32_t fp = cflag[p], fq = cflag[q];   // converged flag | "active_cnt < K / 10" << 31 (svils_internal.h)
-  const uint32_t pc = fp & 0x7fffffffu, qc = fq & 0x7fffffffu;
+  const uint32_t fp = cflag[p], fq = cflag[q];   // converged flag | "active_cnt < K / 10" << 7 (svils_internal.h)
+  const uint32_t pc = fp & 0x7fu, qc = fq & 0x7fu;
   if ((pc != 0) != (qc != 0)) {          // :622-631
     *col2 = (pc ? pc : qc) - 1u;
     return 2;
   }
   *col2 = 0;
-  return (sparse_iter && ((fp & fq) >> 31)) ? 1 : 0;   // :634
+  return (sparse_iter && ((fp & fq) >> 7)) ? 1 : 0;   // :634
 }
 
 // next = false: classes of the sweep about to run (flags conv[parity], _iter);

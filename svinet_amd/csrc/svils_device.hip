@@ -426,6 +426,8 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
   }
 
   const uint32_t nown = geo.node_end - geo.node_begin;
+  // (prefetching the next node's index words and accumulator row was measured at no gain -- ca-AstroPh K=200 40.5 -> 41.4 us,
+  //  n=1e6 K=512 3.78 -> 4.12 ms with the occupancy it costs at V = 8: the launch is bound by the rows it writes)
   for (uint32_t i = (blockIdx.x * 4 + wave) * G + g; i < nown; i += gridDim.x * 4 * G) {
     const uint32_t p = geo.node_begin + i;
     const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
@@ -579,7 +581,7 @@ __device__ __forceinline__ void unpack_flags(const Geometry &geo, const DeviceSt
   const uint32_t *xf = d.xflags + (size_t)p * d.xf_ld;
   d.conv[(size_t)(ctrl->parity ^ 1u) * geo.n_alloc + p] = xf[0];
   d.active_cnt[p] = xf[1];
-  const uint32_t cf = xf[0] | (xf[1] < geo.k10 ? 0x80000000u : 0u);
+  const uint8_t cf = cflag_pack(xf[0], xf[1] < geo.k10);
   if (d.cflag[p] != cf) { d.cflag[p] = cf; d.cls_epoch[0] = ctrl->sweeps_done + 1u; }   // see k_finalize_lpl
 #pragma unroll
   for (int v = 0; v < V; ++v)
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
 __global__ __launch_bounds__(256) void k_cflag_rebuild(Geometry geo, DeviceState d) {
   const uint32_t *__restrict__ conv = d.conv + (size_t)d.ctrl->parity * geo.n_alloc;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < geo.n; p += gridDim.x * blockDim.x)
-    d.cflag[p] = conv[p] | (d.active_cnt[p] < geo.k10 ? 0x80000000u : 0u);
+    d.cflag[p] = cflag_pack(conv[p], d.active_cnt[p] < geo.k10);
 }
 void launch_cflag_rebuild(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const uint32_t nb = std::min<uint32_t>((g.n + 255u) / 256u, 1024u);
@@ -682,6 +684,9 @@ void launch_mphi_from_gamma(const Geometry &g, const DeviceState &d, const Param
 // ================================================================ s3 pass (A8)
 // src/linksampling.cc:731-746 over the upper half (q > p) of each owned row,
 // including quirk Q2 (mphi[q][pc], one past the converged community).
+#ifndef S3_PIPE_MAXV   // largest V whose k_s3 keeps the next neighbour's row in flight (V more doubles per lane)
+#define S3_PIPE_MAXV 4
+#endif
 template <int W, int V, bool DERIVE>
 __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
@@ -726,30 +731,78 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d, Params 
 #pragma unroll
       for (int v = 0; v < V; ++v) mp[v] = (uint32_t)kidx[v] < K ? (mp[v] * isc[v] - alpha) * inv_nm1 : 0.0;
     }
-    for (uint32_t j = g; j < item.len; j += G) {
-      const uint32_t q = d.col[base + j];
-      const uint32_t qc = conv[q];
-      if (pc && !qc) {
-        double val = pc < K ? mphi[(size_t)q * ld + pc] : 0.0;
-        if (derive && pc < K) val = (val * d.iscale[pc] - alpha) * inv_nm1;
+    if constexpr (W == 64 && V <= S3_PIPE_MAXV) {
+      // One neighbour at a time was a chain of three dependent misses (column id -> converged flag -> row).  An item has
+      // at most 32 neighbours: their ids and flags arrive with ONE coalesced load each (lane j <-> neighbour j), and the
+      // row of neighbour j + 1 travels while neighbour j is multiplied (as k_phi does it).
+      uint32_t qv = 0, qcv = 0;
+      if ((uint32_t)lane < item.len) { qv = d.col[base + lane]; qcv = conv[qv]; }
+      auto wants_row = [&](uint32_t qc) { return (pc != 0) == (qc != 0); };   // wave-uniform: pc, qc are
+      double mqn[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v)
-          if (kidx[v] == (int)pc - 1) s3[0][v] += val;
-      } else if (!pc && qc) {
-        double val = qc < K ? mphi[(size_t)p * ld + qc] : 0.0;
-        if (derive && qc < K) val = (val * d.iscale[qc] - alpha) * inv_nm1;
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-          if (kidx[v] == (int)qc - 1) s3[0][v] += val;
-      } else {
+      for (int v = 0; v < V; ++v) mqn[v] = 0.0;
+      if (item.len > 0) {
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)qv, 0), qc0 = (uint32_t)__builtin_amdgcn_readlane((int)qcv, 0);
+        if (wants_row(qc0)) load_row<W, V>(mphi + (size_t)q0 * ld, lw, ld, mqn);
+      }
+      for (uint32_t j = 0; j < item.len; ++j) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qv, (int)j);
+        const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qcv, (int)j);
         double mq[V];
-        load_row<W, V>(mphi + (size_t)q * ld, lw, ld, mq);
-        if (derive) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) mq[v] = (mq[v] * isc[v] - alpha) * inv_nm1;   // padding columns: mp is 0 there
+        for (int v = 0; v < V; ++v) mq[v] = mqn[v];
+        if (j + 1 < item.len) {
+          const uint32_t qn = (uint32_t)__builtin_amdgcn_readlane((int)qv, (int)j + 1);
+          const uint32_t qcn = (uint32_t)__builtin_amdgcn_readlane((int)qcv, (int)j + 1);
+          if (wants_row(qcn)) load_row<W, V>(mphi + (size_t)qn * ld, lw, ld, mqn);
         }
+        if (pc && !qc) {
+          double val = pc < K ? mphi[(size_t)q * ld + pc] : 0.0;
+          if (derive && pc < K) val = (val * d.iscale[pc] - alpha) * inv_nm1;
 #pragma unroll
-        for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
+          for (int v = 0; v < V; ++v)
+            if (kidx[v] == (int)pc - 1) s3[0][v] += val;
+        } else if (!pc && qc) {
+          double val = qc < K ? mphi[(size_t)p * ld + qc] : 0.0;
+          if (derive && qc < K) val = (val * d.iscale[qc] - alpha) * inv_nm1;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kidx[v] == (int)qc - 1) s3[0][v] += val;
+        } else {
+          if (derive) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) mq[v] = (mq[v] * isc[v] - alpha) * inv_nm1;   // padding columns: mp is 0 there
+          }
+#pragma unroll
+          for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
+        }
+      }
+    } else {
+      for (uint32_t j = g; j < item.len; j += G) {
+        const uint32_t q = d.col[base + j];
+        const uint32_t qc = conv[q];
+        if (pc && !qc) {
+          double val = pc < K ? mphi[(size_t)q * ld + pc] : 0.0;
+          if (derive && pc < K) val = (val * d.iscale[pc] - alpha) * inv_nm1;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kidx[v] == (int)pc - 1) s3[0][v] += val;
+        } else if (!pc && qc) {
+          double val = qc < K ? mphi[(size_t)p * ld + qc] : 0.0;
+          if (derive && qc < K) val = (val * d.iscale[qc] - alpha) * inv_nm1;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kidx[v] == (int)qc - 1) s3[0][v] += val;
+        } else {
+          double mq[V];
+          load_row<W, V>(mphi + (size_t)q * ld, lw, ld, mq);
+          if (derive) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) mq[v] = (mq[v] * isc[v] - alpha) * inv_nm1;   // padding columns: mp is 0 there
+          }
+#pragma unroll
+          for (int v = 0; v < V; ++v) s3[0][v] += mp[v] * mq[v];
+        }
       }
     }
   }
@@ -1043,14 +1096,14 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   STAMP(3, 5);
 
   // ---- last block only ----
-  // the blocks' partial sums: one thread per block, then a fixed-order tree (nb_t <= 256)
+  // the blocks' partial sums: thread t adds blocks t, t + 256, ..., then a fixed-order tree
   sz = 0.0; so = 0.0;
   double kzd = 0.0;
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  if (threadIdx.x < d.nb_t) {
-    sz = ld_agent(d.tail_part + (size_t)threadIdx.x * 4);
-    so = ld_agent(d.tail_part + (size_t)threadIdx.x * 4 + 1);
-    kzd = ld_agent(d.tail_part + (size_t)threadIdx.x * 4 + 2);
+  for (uint32_t b = threadIdx.x; b < d.nb_t; b += 256u) {   // (one round up to 256 blocks)
+    sz += ld_agent(d.tail_part + (size_t)b * 4);
+    so += ld_agent(d.tail_part + (size_t)b * 4 + 1);
+    kzd += ld_agent(d.tail_part + (size_t)b * 4 + 2);
   }
   red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = (unsigned long long)kzd;
   const uint32_t cpar0 = c.cls_par;
@@ -1354,7 +1407,10 @@ uint32_t tail_blocks(const Geometry &g, uint32_t nv) {
   const uint32_t per_block = 4u * (uint32_t)(64 / g.W);
   uint32_t nb = (nv + 2 * per_block - 1) / (2 * per_block);
   if (nb < 1) nb = 1;
-  if (nb > 256) nb = 256;   // one thread of the last block per block partial
+  // Up to 256 blocks: one thread of the last block per block partial.  A large held-out set (n = 1e6: ~2.4e5 pairs) is a
+  // chain of dependent row gathers per group, so it gets up to SVILS_TAIL_BLOCKS blocks (four per CU) and the last
+  // block's threads add four partials each, in block order.
+  if (nb > 256) nb = nb > SVILS_TAIL_BLOCKS ? SVILS_TAIL_BLOCKS : (nb + 255u) / 256u * 256u;
   return nb;
 }
 void launch_tail(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {

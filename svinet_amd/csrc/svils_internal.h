@@ -120,7 +120,7 @@ struct DeviceState {
   uint32_t sweep_stats_cap;
   unsigned long long *stamps;   // [4][1024][8] wall-clock stamps of blocks (builds with -DSVILS_STAMPS only)
   uint32_t *tail_ctl;   // [4] arrival ticket of k_tail's blocks
-  double *tail_part;    // [nb_t][4] per-block held-out partial sums of k_tail
+  double *tail_part;    // [nb_t][4] per-block held-out partial sums of k_tail (nb_t <= SVILS_TAIL_BLOCKS)
   uint32_t nb_t;
   unsigned long long *member_acc; // [n_alloc] tag bits OR-ed during the phi pass (lt_min_deg == 0)
   uint32_t *fcnt;       // [n_alloc][ld] tag counts (lt_min_deg > 0), else null
@@ -158,10 +158,13 @@ struct DeviceState {
   double *iscale;       // [K]
   uint32_t *conv;       // [2][n_alloc]
   uint32_t *active_cnt; // [n_alloc]
-  // What the link classification needs of an endpoint, in ONE word: the latest converged flag (what prune() wrote last)
-  // | 0x80000000 when active_cnt < K / 10.  Written next to conv / active_cnt by whoever writes those; a second random
-  // gather per endpoint (active_cnt) cost the classification passes 4 us per sweep on ca-AstroPh once _iter > 1000.
-  uint32_t *cflag;      // [n_alloc]
+  // What the link classification needs of an endpoint, in ONE BYTE: the latest converged flag (what prune() wrote last;
+  // 0 or community + 1 <= 56 where a classification exists) | 0x80 when active_cnt < K / 10 (cflag_pack).  Written next to
+  // conv / active_cnt by whoever writes those; a second random gather per endpoint (active_cnt) cost the classification
+  // passes 4 us per sweep on ca-AstroPh once _iter > 1000.  One byte, not a word: the passes gather it at random for
+  // every CSR entry, and a table of n bytes (1 MB at n = 1e6) stays in every XCD's L2 next to the s3 / tail launch's own
+  // row traffic where a table of words does not.
+  uint8_t *cflag;       // [n_alloc]
   uint64_t *amask;      // [n_alloc][kw] lane-layout bitmask of _active_k
   uint64_t *member;     // [n_alloc][kw] lane-layout bitmask of communities
   uint32_t *xflags;     // [n_alloc][xf_ld] conv (new), active_cnt, amask words of every row, packed: ONE buffer to
@@ -204,6 +207,7 @@ struct Params {
 
 // launchers (svils_device.hip); all asynchronous on `s`
 constexpr uint32_t SVILS_FOLD_ROWS = 512;   // most per-block partial rows a consumer folds itself
+constexpr uint32_t SVILS_TAIL_BLOCKS = 1024;   // most blocks of k_tail (held-out pairs); its last block adds their partials
 bool use_lpl(uint32_t K);
 int lpl_phi_waves(uint32_t K);
 uint32_t lpl_phi_resident_blocks(uint32_t K, int device);
@@ -237,6 +241,10 @@ void launch_expand_chunk(const Geometry &g, const DeviceState &d, const Params &
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_lambda_exp(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_debug_eval(const DeviceState &d, int which, const double *in, double *out, uint32_t n, hipStream_t s);
+// the byte of cflag[]: flag values beyond 127 only occur for K > 127, where nothing reads the table
+__host__ __device__ inline uint8_t cflag_pack(uint32_t conv, bool few_active) {
+  return (uint8_t)((conv < 127u ? conv : 127u) | (few_active ? 0x80u : 0u));
+}
 void launch_cflag_rebuild(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_mphi_from_gamma(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 void launch_row_only(const Geometry &g, const DeviceState &d, const Params &p, double *row_out,

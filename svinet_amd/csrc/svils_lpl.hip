@@ -627,7 +627,6 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     const bool ok = i < nown;
     if (!first && !__any(ok)) break;
     const uint32_t p = geo.node_begin + (ok ? i : 0u);
-    if (!first) ix = fin_load_idx(d, p, ok);
     const double tl = 2.0 * (double)(ix.rp1 - ix.rp0);  // quirk Q3
     const size_t rowoff = (size_t)p * ld + lw;
     double acc[NC];
@@ -689,7 +688,11 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
         for (int j = 0; j < NC; ++j) acc[j] += (double)hh[lw + j * FW];
       }
     }
-    const uint32_t cf_old = (ok && lw == 0) ? d.cflag[p] : 0u;
+    const uint32_t cf_old = (ok && lw == 0) ? (uint32_t)d.cflag[p] : 0u;
+    // graphs of more nodes than resident groups: the NEXT node's index words travel while this one is finalised (a
+    // round is a chain of dependent misses -- index words -> pieces -> stores -- and at n = 1e6 a wave runs ~40 of them)
+    const bool ok_next = (uint64_t)i + stride < nown;
+    const FinIdx ix_next = fin_load_idx(d, geo.node_begin + (ok_next ? i + stride : 0u), ok_next);
     unsigned long long memb = 0ull;
     uint32_t fc[NC];
 #pragma unroll
@@ -817,8 +820,8 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
       const unsigned long long am = (active <= geo.k10) ? bits : 0ull;
       conv_new[p] = cnew;
       d.active_cnt[p] = active;
-      const uint32_t cf_new = cnew | (active < geo.k10 ? 0x80000000u : 0u);
-      d.cflag[p] = cf_new;
+      const uint32_t cf_new = cflag_pack(cnew, active < geo.k10);
+      d.cflag[p] = (uint8_t)cf_new;
       // a classification-relevant word changed: the link classes of the next sweep have to be rebuilt (every writer
       // stores the same epoch; nobody reads it during this launch)
       if (cf_new != cf_old) d.cls_epoch[0] = c_epoch;
@@ -828,6 +831,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
         xf[0] = cnew; xf[1] = active; xf[2] = (uint32_t)am; xf[3] = (uint32_t)(am >> 32);
       }
     }
+    ix = ix_next;
   }
   STAMP(1, 3);
   // per-block partials of s1, s2: the groups of a wave (butterfly over the group index), then the waves in order
@@ -1157,7 +1161,9 @@ uint32_t lpl_cls_blocks(const DeviceState &d) {
 // scatter-pass blocks (one worker each) riding on the tail launch
 uint32_t lpl_scatter_blocks(const DeviceState &d) {
   if (!d.cls_next) return 0;
-  uint32_t nb = d.cls_ntiles < 512u ? d.cls_ntiles : 512u;
+  // (a worker walks its tiles' 1024-entry sub-tiles one after the other, each a chain of dependent accesses: at most
+  //  2048 tiles exist, and with one block per tile the pass is 4x shorter at n = 1e6 than with 512 blocks)
+  uint32_t nb = d.cls_ntiles < 2048u ? d.cls_ntiles : 2048u;
   return nb ? nb : 1u;
 }
 void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
