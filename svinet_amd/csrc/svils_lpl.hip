@@ -867,17 +867,43 @@ constexpr int s3_threads(int kc) { return kc >= 12 ? 512 : 1024; }
 template <int KC>
 __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
-  if (ctrl->stopped) return;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
   constexpr int NTH = s3_threads(KC), NWV = NTH / 64, NWORK = NTH / 256;
+  constexpr bool PEEL = KC >= 12 && KC <= 20;   // see below
+  if constexpr (!PEEL) {
+    if (ctrl->stopped) return;   // (the instantiations without the first-link form keep the order of accesses they had)
+  }
+  // three-launch sweeps: the very last block only folds s1, s2 from k_finalize_lpl's partial rows, from the
+  // start of the launch, so that nobody on the critical path has to (it arrives on the s3 ticket like an s3 block)
+  const bool fold_role = d.fused3 && blockIdx.x == gridDim.x - 1u;
+  // The s3 blocks' path through this launch is a chain of dependent misses: control block -> link -> converged flags ->
+  // rows -> (block partial, ticket) -> the last block's serial stage.  On three-launch sweeps (graphs of a few hundred
+  // thousand links: about ONE link per lane) the first link of a lane, whose address depends on nothing, is requested
+  // together with the control block (a relaxed wavefront-scope atomic = a plain load the compiler leaves in place), and
+  // its two rows are requested together with the flags instead of behind them (below): two hops less.
+  // (where the registers allow: 512-thread blocks, K = 21..40.  At K <= 20 the 1024-thread block leaves 128 registers per
+  //  lane, the peeled form spills, and it measured slower -- ca-AstroPh K=20 52.1 -> 53.0 us per sweep -- while LFR K=28 gains
+  //  32.2 -> 31.5 us; K > 40 spills as well.  profiles/r03q_s3_first_link.txt.  The other instantiations compile to what
+  //  they were.)
+  bool peel = false;
+  unsigned long long first_link = 0ull;
+  uint32_t c_parity0 = 0;
+  if constexpr (PEEL) {
+    const uint64_t nl0 = (fold_role || blockIdx.x >= d.nb_c) ? 0 : d.link_end - d.link_begin;
+    const uint64_t i0 = (uint64_t)blockIdx.x * NTH + threadIdx.x;
+    peel = d.fused3 != 0 && i0 < nl0;
+    if (peel)
+      first_link = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(d.links) + (d.link_begin + i0),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t c_stopped0 = ctrl->stopped;
+    c_parity0 = ctrl->parity;
+    if (c_stopped0) return;
+  }
   __shared__ __attribute__((aligned(16))) double lds[NWV][32 * SROW];
   __shared__ double red[NWV][64];
   __shared__ ClsWork shw[NWORK];
   STAMP(2, 0);
   __shared__ uint32_t hflag;
-  // three-launch sweeps: the very last block only folds s1, s2 from k_finalize_lpl's partial rows, from the
-  // start of the launch, so that nobody on the critical path has to (it arrives on the s3 ticket like an s3 block)
-  const bool fold_role = d.fused3 && blockIdx.x == gridDim.x - 1u;
   if (blockIdx.x >= d.nb_c && !fold_role) {   // the blocks after the s3 blocks: link classes of the NEXT sweep
     const uint32_t rb = blockIdx.x - d.nb_c, nrb = gridDim.x - d.nb_c - (d.fused3 ? 1u : 0u);
     if (d.fused3) {
@@ -891,32 +917,63 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
     STAMP(2, 7);
     return;
   }
-  // the log table for the serial stage of a three-launch sweep: fetched now, used by the last block only
+  // the log table for the serial stage of a three-launch sweep: fetched ahead of its use, used by the last block only
   double2 ltv = make_double2(0.0, 0.0);
   double suma = 0.0;   // sum[k] of this sweep (k_finalize_lpl's block 0 left it in kvec_a)
   // ... and what its thread 0 needs from the control block and the class totals: all of it is at rest
-  // until that block itself writes, so every block fetches it up front and only the last one uses it
+  // until that block itself writes, so every block fetches it and only the last one uses it
   uint32_t c_iter = 0, c_sd = 0, c_cpar = 0, c_par = 0;
   unsigned long long c_l0 = 0, c_l1 = 0, c_l2 = 0;
-  if (d.fused3) {
-    if (threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
-    if (threadIdx.x < geo.K) suma = d.kvec_a[threadIdx.x];
-    c_cpar = ctrl->cls_par;
-    if (threadIdx.x == 0) {
-      c_iter = ctrl->iter; c_sd = ctrl->sweeps_done; c_par = ctrl->parity;
-      const uint32_t *lt = d.ltot + c_cpar * 8u;
-      c_l0 = lt[3]; c_l1 = lt[4]; c_l2 = lt[5];
+  auto load_tail_inputs = [&]() {
+    if (d.fused3) {
+      if (threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
+      if (threadIdx.x < geo.K) suma = d.kvec_a[threadIdx.x];
+      c_cpar = ctrl->cls_par;
+      if (threadIdx.x == 0) {
+        c_iter = ctrl->iter; c_sd = ctrl->sweeps_done; c_par = ctrl->parity;
+        const uint32_t *lt = d.ltot + c_cpar * 8u;
+        c_l0 = lt[3]; c_l1 = lt[4]; c_l2 = lt[5];
+      }
     }
-  }
+  };
+  if constexpr (!PEEL) load_tail_inputs();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = geo.K, ld = geo.ld;
-  const uint32_t *__restrict__ conv = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  const uint32_t *__restrict__ conv = d.conv + (size_t)(PEEL ? c_parity0 : ctrl->parity) * geo.n_alloc;
   const double *__restrict__ mphi = d.mphi;
   double s3[KR];
 #pragma unroll
   for (int k = 0; k < KR; ++k) s3[k] = 0.0;
+  if (peel) {
+    // the lane's first link, rows requested with the flags; a link with exactly one converged endpoint picks its one
+    // element out of the row registers (src/linksampling.cc:739-742, quirk Q2: element index pc, column pc - 1; an
+    // index of K reads nothing).  Products straight into the accumulators: nothing else is live yet.
+    const uint32_t p = (uint32_t)first_link, q = (uint32_t)(first_link >> 32);   // links[2 l], links[2 l + 1]
+    const double *rp = mphi + (size_t)p * ld, *rq = mphi + (size_t)q * ld;
+    const uint32_t pc = conv[p], qc = conv[q];
+    const bool dense = (pc != 0) == (qc != 0);
+    const uint32_t one = pc ? pc : qc;                   // the converged endpoint's flag (dense: unused)
+    const int sel = (!dense && one < K) ? (int)one : -1;
+    const int tgt = dense ? -1 : (int)one - 1;
+    const bool from_q = pc != 0;                         // pc && !qc: the element comes from q's row
+    double val = 0.0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const double2 a = *reinterpret_cast<const double2 *>(rp + 2 * c);
+      const double2 b = *reinterpret_cast<const double2 *>(rq + 2 * c);
+      s3[2 * c] = dense ? a.x * b.x : 0.0;
+      s3[2 * c + 1] = dense ? a.y * b.y : 0.0;
+      const double e0 = from_q ? b.x : a.x, e1 = from_q ? b.y : a.y;
+      val = (sel == 2 * c) ? e0 : val;
+      val = (sel == 2 * c + 1) ? e1 : val;
+    }
+    if (__any(!dense)) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k) s3[k] += (k == tgt) ? val : 0.0;
+    }
+  }
   const uint64_t nl = fold_role ? 0 : d.link_end - d.link_begin;
-  for (uint64_t i = (uint64_t)blockIdx.x * NTH + threadIdx.x; i < nl; i += (uint64_t)d.nb_c * NTH) {
+  for (uint64_t i = (uint64_t)blockIdx.x * NTH + threadIdx.x + (peel ? (uint64_t)d.nb_c * NTH : 0ull); i < nl; i += (uint64_t)d.nb_c * NTH) {
     const uint64_t l = d.link_begin + i;
     const uint32_t p = d.links[2 * l], q = d.links[2 * l + 1];
     const uint32_t pc = conv[p], qc = conv[q];
@@ -940,6 +997,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
       }
     }
   }
+  if constexpr (PEEL) load_tail_inputs();   // behind the link loop, whose row registers they would otherwise share
   STAMP(2, 1);
   // wave total per column: the 64 rows go through LDS in two passes of 32; lane (part, k) adds the
   // rows r = part, part + NP, ... of column k (NP = 64 / KR lanes share a column), then the parts
