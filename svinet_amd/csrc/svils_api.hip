@@ -1148,7 +1148,8 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     guard(dalloc(h, &d.erow, erow.size(), false));
     guard(dalloc(h, &d.links, std::max<uint64_t>(2 * nlinks, 1), false));
     guard(dalloc(h, &d.slot_f, 2 * (size_t)d.lpl_nitems * g.ld));
-    guard(dalloc(h, &d.slot_l, 2 * (size_t)d.lpl_nitems * g.ld));
+    guard(dalloc(h, &d.ghead, 2 * (size_t)g.n_alloc * g.ld));
+    guard(dalloc(h, &d.gtail, 2 * (size_t)g.n_alloc * g.ld));
     guard(dalloc(h, &d.gacc1, (size_t)g.n_alloc * g.ld));
     guard(dalloc(h, &d.member_acc, g.n_alloc));
     if (h->prm.lt_min_deg > 0) guard(dalloc(h, &d.fcnt, (size_t)g.n_alloc * g.ld));

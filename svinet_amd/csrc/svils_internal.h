@@ -74,8 +74,16 @@ struct DeviceState {
   uint64_t link_begin, link_end; // owned links (first endpoint in the node block)
   uint64_t lpl_w0;      // first wave-item (ent_begin / 64)
   uint32_t lpl_nitems;  // capacity: wave-items per class list
-  double *slot_f;       // [2][lpl_nitems][ld] run that starts at lane 0 of a wave-item (per class list)
-  double *slot_l;       // [2][lpl_nitems][ld] run that ends at lane 63 (and does not start at lane 0)
+  // Where k_phi_lpl leaves the pieces of a node's gammanext row (per class list), by the lanes [a, b] the piece covers in
+  // its wave-item: a > 0, b < 63 (interior) -> gacc / gacc1 [node]; a > 0, b = 63 (the run goes on in the next item, or
+  // ends exactly there) -> ghead[list][node]; a = 0, b < 63 (the rest of a run, or one that starts exactly there) ->
+  // gtail[list][node]; a = 0, b = 63 (a whole item of a hub's run) -> slot_f[list][item].  A node has one run per list,
+  // hence at most one head and one tail piece: three of the four kinds sit at addresses that depend on the node alone,
+  // so k_finalize_lpl requests them before it has seen the run boundaries (one dependent miss less per launch); until
+  // the last session of round 3 head and tail pieces lived in per-item slots (slot_f / slot_l).
+  double *slot_f;       // [2][lpl_nitems][ld] whole-item pieces
+  double *ghead;        // [2][n_alloc][ld]
+  double *gtail;        // [2][n_alloc][ld]
   double *gacc1;        // [n_alloc][ld] interior runs of class list 1 (list 0 writes gacc)
   // Per-sweep link classes (k_classify, src/linksampling.cc:622-634): every owned CSR entry is
   //   0 dense  (full softmax), 1 sparse (active-set softmax, _iter > 1000), 2 shortcut (exactly one

@@ -17,9 +17,10 @@
 // entries of ONE list, so every lane does the same amount of work), and the
 // shortcut entries cost one 2-byte column id each, added per node by
 // k_finalize_lpl.  Because compaction is stable, the entries of a node stay
-// contiguous in every list: a node's run can straddle wave-items; the piece that
-// starts at lane 0 of an item goes to slot_f[list][item], a piece that ends at
-// lane 63 to slot_l[list][item], interior pieces straight to the node's row;
+// contiguous in every list: a node's run can straddle wave-items; interior pieces
+// go straight to the node's accumulator row, the piece that ends at lane 63 of an
+// item to ghead[list][node], the piece that starts at lane 0 to gtail[list][node],
+// a whole item of a hub's run to slot_f[list][item] (svils_internal.h);
 // k_finalize_lpl re-derives the same rule from npos[list][] and adds the pieces in
 // item order.  No floating-point atomics, bit-reproducible, perfectly balanced.
 #include "svils_cls.h"
@@ -421,8 +422,10 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ?
         tmask = (lane == k) ? mk : tmask;
       }
     }
+    // where a piece goes by the lanes it covers (svils_internal.h): whole item -> slot of the item, else by node
     double *const slotf = d.slot_f + ((size_t)list * d.lpl_nitems + w) * ld;
-    double *const slotl = d.slot_l + ((size_t)list * d.lpl_nitems + w) * ld;
+    double *const head = d.ghead + (size_t)list * geo.n_alloc * ld;
+    double *const tail = d.gtail + (size_t)list * geo.n_alloc * ld;
     double *const direct = list ? d.gacc1 : d.gacc;
     double acc = 0.0;
     int a = 0;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ?
             for (int j = 0; j < 16; ++j) {
               const int r = pass * RP + rb0 + j;
               if (r > 0 && ((heads >> r) & 1ull)) {      // run [a, r-1] ends (wave-uniform branch)
-                LPL_FLUSH((a == 0) ? slotf : direct + (size_t)cur * ld, r - 1);
+                LPL_FLUSH(((a == 0) ? tail : direct) + (size_t)cur * ld, r - 1);
                 a = r;
               }
               acc += v[j];
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ?
           }
         }
         // last run ends at lane 63
-        if (pass == NPASS - 1) LPL_FLUSH((a == 0) ? slotf : slotl, 63);
+        if (pass == NPASS - 1) LPL_FLUSH((a == 0) ? slotf : head + (size_t)cur * ld, 63);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -629,6 +632,16 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     const uint32_t p = geo.node_begin + (ok ? i : 0u);
     const double tl = 2.0 * (double)(ix.rp1 - ix.rp0);  // quirk Q3
     const size_t rowoff = (size_t)p * ld + lw;
+    // The by-node pieces of list 0 (interior, head, tail: svils_internal.h) sit at addresses that depend on the node alone:
+    // requested before the run boundaries are looked at, they travel with the index words instead of behind them.
+    double sp_d[NC], sp_h[NC], sp_t[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const bool on = kv[j] && ok;
+      sp_d[j] = on ? d.gacc[rowoff + j * FW] : 0.0;
+      sp_h[j] = on ? d.ghead[rowoff + j * FW] : 0.0;
+      sp_t[j] = on ? d.gtail[rowoff + j * FW] : 0.0;
+    }
     double acc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[j] = 0.0;
@@ -636,33 +649,53 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     for (int l = 0; l < 2; ++l) {
       const uint32_t r0 = ix.r[l][0], r1 = ix.r[l][1];
       if (r1 > r0) {
-        const double *sf = d.slot_f + (size_t)l * d.lpl_nitems * ld, *sl = d.slot_l + (size_t)l * d.lpl_nitems * ld;
+        const double *sf = d.slot_f + (size_t)l * d.lpl_nitems * ld;
+        const double *hd = d.ghead + (size_t)l * geo.n_alloc * ld, *tp = d.gtail + (size_t)l * geo.n_alloc * ld;
         const double *direct = l ? d.gacc1 : d.gacc;
         const uint32_t w0 = r0 >> 6, w1 = (r1 - 1u) >> 6;
+        const bool a0 = (r0 & 63u) == 0u, b63 = ((r1 - 1u) & 63u) == 63u;   // the run starts at lane 0 / ends at lane 63
         if (w0 == w1) {
-          const double *src = ((r0 & 63u) == 0u) ? sf + (size_t)w0 * ld
-                              : (((r1 - 1u) & 63u) == 63u) ? sl + (size_t)w0 * ld
-                                                           : direct + (size_t)p * ld;
+          if (l == 0 && !(a0 && b63)) {
 #pragma unroll
-          for (int j = 0; j < NC; ++j) acc[j] += kv[j] ? src[lw + j * FW] : 0.0;
+            for (int j = 0; j < NC; ++j) acc[j] += a0 ? sp_t[j] : b63 ? sp_h[j] : sp_d[j];
+          } else {
+            const double *src = (a0 && b63) ? sf + (size_t)w0 * ld
+                                : a0 ? tp + (size_t)p * ld
+                                : b63 ? hd + (size_t)p * ld
+                                      : direct + (size_t)p * ld;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) acc[j] += kv[j] ? src[lw + j * FW] : 0.0;
+          }
         } else {
-          // a hub's run spans many items: HP pieces in flight at a time, added in item order
-          constexpr uint32_t HP = NC >= 4 ? 1 : 2;
+          // the run spans items: its first piece (head, or a whole item), whole items of a hub in between, its last
+          // piece (tail, or a whole item) -- added in item order
+          double fp[NC], lp[NC];
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            fp[j] = a0 ? (kv[j] ? sf[(size_t)w0 * ld + lw + j * FW] : 0.0)
+                       : (l == 0 ? sp_h[j] : (kv[j] ? hd[rowoff + j * FW] : 0.0));
+            lp[j] = b63 ? (kv[j] ? sf[(size_t)w1 * ld + lw + j * FW] : 0.0)
+                        : (l == 0 ? sp_t[j] : (kv[j] ? tp[rowoff + j * FW] : 0.0));
+          }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) acc[j] += fp[j];
+          constexpr uint32_t HP = NC >= 4 ? 1 : 2;   // whole-item pieces in flight at a time
 #pragma unroll 1
-          for (uint32_t wb = w0; wb <= w1; wb += HP) {
+          for (uint32_t wb = w0 + 1u; wb < w1; wb += HP) {
             double pv[HP][NC];
 #pragma unroll
             for (uint32_t t = 0; t < HP; ++t) {
               const uint32_t w = wb + t;
-              const double *src = (w == w0 && (r0 & 63u) != 0u) ? sl : sf;
 #pragma unroll
-              for (int j = 0; j < NC; ++j) pv[t][j] = (w <= w1 && kv[j]) ? src[(size_t)w * ld + lw + j * FW] : 0.0;
+              for (int j = 0; j < NC; ++j) pv[t][j] = (w < w1 && kv[j]) ? sf[(size_t)w * ld + lw + j * FW] : 0.0;
             }
 #pragma unroll
             for (uint32_t t = 0; t < HP; ++t)
 #pragma unroll
               for (int j = 0; j < NC; ++j) acc[j] += pv[t][j];
           }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) acc[j] += lp[j];
         }
       }
     }
