@@ -2,6 +2,7 @@
 """bench.py -- edge-updates/sec of the link-sampling sweep on MI355X.
 
   python bench.py --gpus 1 --steps 100 --warmup 5
+  python bench.py --gpus N --steps K --warmup W            # bare: spawns its own N ranks (one process per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -53,18 +54,72 @@ def _synthetic_pairs(n, mean_deg, seed):
     return np.concatenate([ring, np.stack([a, b], 1)]).astype(np.int32)
 
 
-def _traffic(workload):
-    """HBM bytes per phi launch from the committed rocprofv3 --pmc summary of this workload, with its
-    provenance (which profile file, which commit's kernels it was measured on); None if there is none."""
+# the sources a phi kernel is compiled from: a PMC measurement is valid for the tree only while these are unchanged
+KERNEL_SOURCES = {
+    "lpl": ("svinet_amd/csrc/svils_lpl.hip", "svinet_amd/csrc/svils_cls.h", "svinet_amd/csrc/svils_devutil.h",
+            "svinet_amd/csrc/svils_internal.h"),                                   # K <= 56: k_phi_lpl & co
+    "row": ("svinet_amd/csrc/svils_device.hip", "svinet_amd/csrc/svils_devutil.h", "svinet_amd/csrc/svils_internal.h"),
+}
+
+
+def kernel_source_hashes(k):
+    import hashlib
+    out = {}
+    for rel in KERNEL_SOURCES["lpl" if k <= 56 else "row"]:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            out[rel] = hashlib.sha256(f.read()).hexdigest()[:16]
+    return out
+
+
+def _traffic(workload, k):
+    """HBM bytes per phi launch (and per whole sweep) from the committed rocprofv3 --pmc summary of this workload, with
+    its provenance.  -> (record or None, reason).  A record measured on OTHER kernel sources than the ones in this tree
+    is refused: tools/pmc_traffic.py stores the hashes of the kernel's source files (KERNEL_SOURCES) next to the bytes,
+    and they must equal the hashes of the files this run was built from (there is no .git on the GPU box to ask)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f).get(workload)
-    except Exception:
-        return None
+    except Exception as exc:
+        return None, "profiles/traffic.json unreadable (%r)" % (exc,)
     if not rec or "phi_hbm_bytes_per_launch" not in rec:
-        return None
-    return rec
+        return None, "no PMC record for this workload"
+    have = kernel_source_hashes(k)
+    if rec.get("source_hashes") != have:
+        changed = sorted(f for f in have if (rec.get("source_hashes") or {}).get(f) != have[f])
+        return None, ("PMC record of commit %s refused: %s changed since it was measured -- re-run tools/evidence.sh pmc"
+                      % (rec.get("commit"), ", ".join(changed)))
+    return rec, "source hashes match"
+
+
+def _roofline_fields(rec, k, n_nodes, workload):
+    """Turns a _phi_record into the line's roofline fields.  `frac` is the fraction of the 8 TB/s HBM peak by the bytes
+    that REALLY crossed the L2's memory side per launch (PMC counters, valid for this tree's kernel sources) -- it cannot
+    exceed 1.  Without a valid counter record it is the fraction by the pull design's own byte model.  SURVEY 8d's
+    32*K-per-link figure stays beside it as frac_survey_model: it charges a push-style scatter this pull-style kernel
+    never performs and counts cache-fed bytes as HBM bytes, so it may exceed 1."""
+    out = dict(rec)
+    out["achieved_survey_model"] = out.pop("achieved")
+    out["frac_survey_model"] = out.pop("frac")
+    out["survey_model"] = "32*K bytes x (dense + active-set links of the timed sweeps) / phi time (SURVEY 8d)"
+    out["pull_model"] = _pull_model(rec, k, n_nodes)
+    t = rec["avg_launch_us"] * 1e-6
+    tr, why = _traffic(workload, k)
+    if tr:
+        out["traffic"] = tr["phi_hbm_bytes_per_launch"]
+        out["traffic_source"] = {kk: tr.get(kk) for kk in ("source", "commit", "counters", "source_hashes")}
+        out["achieved"] = tr["phi_hbm_bytes_per_launch"] / t / 1e9
+        out["frac_basis"] = "hbm_counter"
+        out["frac_hbm_counter"] = out["achieved"] / HBM_PEAK_GBS
+        if tr.get("sweep_hbm_bytes"):
+            out["sweep_traffic"] = tr["sweep_hbm_bytes"]
+    else:
+        out["traffic"] = None
+        out["traffic_source"] = {"refused": why}
+        out["achieved"] = out["pull_model"]["achieved"]
+        out["frac_basis"] = "pull_model"
+    out["frac"] = out["achieved"] / HBM_PEAK_GBS
+    return out
 
 
 def _phi_record(eng, k, label):
@@ -196,30 +251,23 @@ def hbm_bound_record(device, sweeps=10, workload=HBM_BOUND_WORKLOAD):
     tm = eng.timing()
     rec = _phi_record(eng, k, "sweeps %d..%d of the seeded run" % (2 + sweeps, 2 + 2 * sweeps))
     L = int(setup.nlinks)
-    ld = (k + 15) // 16 * 16
+    row_bytes = eng.device_buffer(_svils.BUF_GAMMA)[2]          # the engine's own row stride
     rec.update({"workload": "%s: n=%d k=%d links/sweep=%d, state %.2f GB per n-by-k array (3 resident)"
-                            % (workload, n, k, L, n * ld * 8 / 1e9),
+                            % (workload, n, k, L, n * row_bytes / 1e9),
                 "data": data,
                 "ms_per_sweep": el / sweeps * 1e3, "edge_updates_per_s": L * sweeps / el,
                 "kernels_us": {kk: v[0] / max(v[1], 1) * 1e3 for kk, v in tm.items() if v[1]},
                 "setup_s": setup_s,
                 "kernel": "k_phi<8,false,true> (row-per-wavefront, product form on exp(Elogpi) rows)"})
-    rec["frac_algorithmic"] = rec.pop("frac")
-    rec["pull_model"] = _pull_model(rec, k, n)
-    tr = _traffic(workload)
-    if tr:
-        real = tr["phi_hbm_bytes_per_launch"] / (rec["avg_launch_us"] * 1e-6) / 1e9
-        rec["traffic"] = tr["phi_hbm_bytes_per_launch"]
-        rec["traffic_source"] = {kk: tr.get(kk) for kk in ("source", "commit", "counters")}
-        rec["achieved_counter_traffic"] = real
-        rec["frac_counter_traffic"] = real / HBM_PEAK_GBS
-        rec["note"] = ("pull-style phi reads one neighbour row per directed entry and writes each gammanext row once, so the "
-                       "PMC-counted HBM bytes are close to pull_model and below the 32*K-per-link model (which also counts the "
-                       "push-style scatter: frac_algorithmic may exceed 1); frac_counter_traffic is the honest HBM utilisation"
-                       + ("" if n * ld * 8 * 3 > 1e9 * 4 else " -- at this size part of it is fed by the 256 MB Infinity Cache "
-                          "(FETCH_SIZE counts those hits): config5 is the all-HBM figure"))
-    else:
-        rec["traffic"] = None
+    rec = _roofline_fields(rec, k, n, workload)
+    if rec.get("sweep_traffic"):
+        # every kernel of the sweep, not only phi: PMC bytes of one whole sweep over the measured sweep time
+        rec["sweep_achieved_counter"] = rec["sweep_traffic"] / (rec["ms_per_sweep"] * 1e-3) / 1e9
+        rec["sweep_frac_hbm_counter"] = rec["sweep_achieved_counter"] / HBM_PEAK_GBS
+    rec["note"] = ("pull-style phi reads one neighbour row per directed entry and writes each gammanext row once: the PMC-counted "
+                   "HBM bytes sit within a few per cent of pull_model and below the 32*K-per-link model"
+                   + ("" if n * row_bytes * 3 > 1e9 * 4 else "; at this size part of the traffic is fed by the 256 MB Infinity Cache "
+                      "(FETCH_SIZE counts those hits): config5 is the all-HBM figure"))
     eng.close()
     setup.close()
     return rec
@@ -392,10 +440,66 @@ def _timed(runner, eng, steps, dist, torch):
     eng.synchronize(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     return el
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process (which has not touched HIP or torch) becomes the
+    launcher -- N children of the same command line, one per GPU, with the environment torch.distributed.run would
+    have given them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1, a free port).  Rank 0
+    owns stdout (the one JSON line); a rank that dies takes the others with it (exact PIDs, no patterns)."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "BENCH_SELF_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what this pool's host driver supports
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with %d; ending the other ranks\n" % (r, code))
+                for q in sorted(live):
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def _rccl_evidence(eng, dist, rank, world, local_rank, torch):
+    """Did RCCL see N ranks on N devices?  Every rank asks the bound library about ITS communicator
+    (svils_comm_query: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion + the device's PCI bus
+    id + the path the nccl* symbols came from); rank 0 puts the answers side by side."""
+    mine = eng.comm_query()
+    mine.update({"pid": os.getpid(), "local_rank": local_rank, "gpu": torch.cuda.get_device_name(local_rank),
+                 "visible_devices": torch.cuda.device_count()})
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    if rank != 0:
+        return None
+    return {"nranks": sorted({a["nranks"] for a in allr}), "rccl_version": sorted({a["rccl_version"] for a in allr}),
+            "library": sorted({a["library"] for a in allr}),
+            "distinct_devices": len({a["pci_bus_id"] for a in allr}),
+            "ranks": [{kk: a[kk] for kk in ("rank", "hip_device", "pci_bus_id", "pid", "gpu", "row_communicator")} for a in allr],
+            "control_plane": "torch.distributed gloo over 127.0.0.1 (communicator id, barriers, max-over-ranks of the "
+                             "timings); every byte of the sweep's exchanges goes through the library's own RCCL "
+                             "communicator(s), created by svils_comm_init from the broadcast id"}
 
 
 def main():
@@ -428,14 +532,16 @@ def main():
                     help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: be the launcher (before anything touches HIP in this process)
+        raise SystemExit(_spawn_ranks(args.gpus))
+
     import torch
     from svinet_amd import _svils
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     if args.test_one_gpu:
@@ -452,11 +558,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if args.test_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600),
-                                    device_id=torch.device("cuda", local_rank))
+        # control plane only (communicator id, barriers, max-over-ranks of the timings): gloo.  The data path's RCCL
+        # communicators are the library's own (svils_comm_init) -- no second set of RCCL communicators in this process.
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
 
     # N > 1: RCCL has never carried more than one rank of this code on the hardware available to its builders.
     # If the communicator set-up or the timed sharded sweeps ever block, rank 0 still owes the driver a JSON
@@ -556,6 +660,24 @@ def main():
                                       % (nev, args.warmup + args.steps, args.warmup + args.steps + nev))
         eng.enable_timing(0, 1)
 
+    rccl = n1_same_box = cpu_rec = None
+    if multi:
+        rccl = _rccl_evidence(eng, dist, rank, world, local_rank, torch)
+        if rank == 0:
+            # the SAME window on ONE GPU of this box (rank 0's), plain engine: what the N = 1 run of this box gives,
+            # for the consistency check of the N > 1 value -- the other ranks wait at the barrier below
+            e1 = setup.engine(use_validation_stop=False, device=local_rank)
+            times1, rep1 = repeated_windows(e1, setup, args.warmup, args.steps, 10, torch)
+            import numpy as np
+            el1 = float(np.median(np.asarray(times1)))
+            n1_same_box = {"value": L * args.steps / el1, "unit": "edge-updates/s", "ms_per_step": el1 / args.steps * 1e3,
+                           "reps": 10, "what": "the same sweep window on rank 0's GPU alone (plain engine, hipGraph replay), "
+                                               "median of 10 repetitions -- bench.py --gpus 1 measures exactly this"}
+            e1.close()
+            if not args.no_cpu_baseline:
+                cpu_rec = cpu_baseline(path, pairs, n, k, args.warmup, args.steps, min_s=8.0, budget_s=15.0)
+        dist.barrier()
+
     out = None
     if rank == 0:
         g, lam, conv = eng.state()
@@ -593,20 +715,34 @@ def main():
                                        "first_window_ms_per_step is the single first window" % (repeat["reps"], args.steps, args.warmup))
         if args.test_one_gpu:
             out["test_mode"] = "all ranks on GPU 0 over the tests' transport: a code-path check, not a measurement"
-        tr = _traffic(args.workload) if not multi else None
-        roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 64 else "k_phi (phi pass, A6)"}
-        roof.update(same_window)
+        roof = {"bound": "hbm", "kernel": "k_phi_lpl (phi pass, A6)" if k <= 56 else "k_phi (phi pass, A6)"}
+        if not multi:
+            roof.update(_roofline_fields(same_window, k, n, args.workload))
+        else:   # this rank's node block: no PMC record describes it
+            roof.update(same_window)
+            roof["achieved_survey_model"], roof["frac_survey_model"] = roof.pop("achieved"), roof.pop("frac")
+            roof["pull_model"] = _pull_model(same_window, k, (n + world - 1) // world)
+            roof["traffic"], roof["frac_basis"] = None, "pull_model"
+            roof["achieved"], roof["frac"] = roof["pull_model"]["achieved"], roof["pull_model"]["frac"]
         roof["timing"] = ("hipEvents around the phi launch on the engine's own stream, in an event pass of its own after the "
                           "timed region" + ("; sampled sweeps launch eagerly, the rest replay hipGraphs" if not multi else ""))
-        roof["pull_model"] = _pull_model(same_window, k, n if not multi else (n + world - 1) // world)
-        roof["traffic"] = tr["phi_hbm_bytes_per_launch"] if tr else None
-        roof["traffic_source"] = ({kk: tr.get(kk) for kk in ("source", "commit", "counters")} if tr else None)
-        roof["note"] = ("achieved = 32*K bytes x (dense + active-set links of the timed sweeps) / phi time.  The state of this "
-                        "workload (%.1f MB per n-by-k array) is %s" % (
-                            n * ((k + 15) // 16 * 16) * 8 / 1e6,
-                            "resident in the 256 MB Infinity Cache, so this is a cache-fed rate, not HBM traffic: see hbm_bound "
-                            "for the HBM figure" if n * k * 8 < 200e6 else "larger than the 256 MB Infinity Cache"))
+        row_bytes = eng.device_buffer(_svils.BUF_GAMMA)[2]
+        resident = n * row_bytes < 200e6
+        roof["note"] = ("frac = HBM bytes per phi launch (%s) / launch time / 8 TB/s.  The state of this workload (%.1f MB per n-by-k "
+                        "array) is %s" % (
+                            "PMC counters 2*FETCH_SIZE + WRITE_SIZE" if roof["frac_basis"] == "hbm_counter" else "pull_model, no valid PMC record",
+                            n * row_bytes / 1e6,
+                            "resident in the 4 MB-per-XCD L2s / 256 MB Infinity Cache: the launch is bound by the dependent-miss chain, "
+                            "not by HBM (frac_survey_model is a cache-fed rate) -- the HBM-bound figures are hbm_bound and config5"
+                            if resident else "larger than the 256 MB Infinity Cache"))
         out["roofline"] = roof
+        if rccl is not None:
+            out["rccl"] = rccl
+            out["n1_same_box"] = n1_same_box
+            out["speedup_vs_n1_same_box"] = out["value"] / n1_same_box["value"]
+            if cpu_rec is not None:
+                out["cpu_baseline"] = cpu_rec
+                out["speedup_vs_cpu_1core"] = out["value"] / cpu_rec["value"]
         if exch is not None:
             out["exchange"] = {"ms_per_sweep": exch[0] / exch[1],
                                "note": "hipEvent time of the RCCL collectives on the engine stream (3 event brackets per sweep), "
@@ -694,7 +830,8 @@ def main():
                     extra[name] = {"value": per_step * wsteps / el2, "unit": "edge-updates/s", "steps": wsteps,
                                    "ms_per_step": el2 / wsteps * 1e3, "n": n2, "k": k2, "links": int(s2.nlinks),
                                    "phi_us_rank0": tm["phi"][0] / max(tm["phi"][1], 1) * 1e3,
-                                   "exchange_ms_per_sweep_rank0": tm["exchange"][0] / nev2}
+                                   "exchange_ms_per_sweep_rank0": tm["exchange"][0] / nev2,
+                                   "row_communicator": r2.eng.comm_query()["row_communicator"]}
                 r2.eng.close()
                 s2.close()
                 if p2:

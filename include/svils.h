@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 3   /* 3: svils_config gained k_begin / k_total (K-sharded handles) */
+#define SVILS_ABI_VERSION 4   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info */
 
 typedef enum {
   SVILS_OK = 0,
@@ -271,12 +271,30 @@ int svils_stream(svils_handle *h, void **stream);
  * Once the annealing flag is off (it is replicated, only goes 1 -> 0 inside a run, and is read when a call
  * starts and every 16 sweeps until then) sum[k] has one reader left, lambda[k][0] in the tail: its all-reduce
  * is grouped with the one of s1,s2,s3 -- two exchange points per sweep instead of three.
+ * The K-vector all-reduces run on the handle's stream.  When the n-by-k payload is large enough to be pipelined
+ * (chunks on a communication stream of their own, each expanded while the next one travels) the row chunks use a
+ * SECOND communicator, formed by the same ranks the first time it is needed (rank 0 draws another unique id and
+ * broadcasts it over the first one): RCCL serialises the operations of one communicator, so sharing it would put
+ * every K-vector all-reduce behind the broadcasts still in flight.
  * librccl is loaded at run time (dlopen) the first time one of these entry points is used. */
 #define SVILS_COMM_ID_BYTES 128
 /* rank 0: a fresh ncclUniqueId to hand to every rank (any transport: pipe, file, MPI, torch store) */
 int svils_comm_unique_id(void *id128);
 /* collective over all ranks: ncclCommInitRank on the handle's device */
 int svils_comm_init(svils_handle *h, const void *id128, int rank, int world);
+/* What the communicator of this handle looks like FROM RCCL'S SIDE (ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice / ncclGetVersion asked of the library that was bound, not echoed from svils_comm_init's
+ * arguments): the evidence a launcher prints to show that N ranks on N devices really formed one communicator. */
+typedef struct {
+  int32_t nranks;        /* ncclCommCount                                                             */
+  int32_t rank;          /* ncclCommUserRank                                                          */
+  int32_t device;        /* ncclCommCuDevice: the HIP ordinal RCCL bound the communicator to          */
+  int32_t version;       /* ncclGetVersion (e.g. 22203), -1 if the bound library has no such entry    */
+  int32_t row_comm;      /* 1 once the second communicator (pipelined row exchange) exists            */
+  char pci_bus_id[32];   /* hipDeviceGetPCIBusId of `device`                                          */
+  char library[256];     /* path of the shared object the nccl* entry points were bound from          */
+} svils_comm_info;
+int svils_comm_query(svils_handle *h, svils_comm_info *out);
 /* Enqueue `nsweeps` sharded sweeps (asynchronous, like svils_sweep).  Collective. */
 int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps);
 /* Mini-batch steps (svils_set_stochastic with shard_block = B) over the node-block shards, the exchanges issued

@@ -28,7 +28,7 @@ EXPORTS = (
     "svils_get_sweep_stats", "svils_get_timed_links",
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
     "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
-    "svils_comm_allgather_host", "svils_step_sharded", "svils_step_ksharded",
+    "svils_comm_allgather_host", "svils_step_sharded", "svils_step_ksharded", "svils_comm_query",
 )
 
 
@@ -65,6 +65,11 @@ class Control(C.Structure):
         ("rows", C.c_uint32), ("links_dense", C.c_uint64), ("links_sparse", C.c_uint64),
         ("links_shortcut", C.c_uint64),
     ]
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("device", C.c_int32), ("version", C.c_int32),
+                ("row_comm", C.c_int32), ("pci_bus_id", C.c_char * 32), ("library", C.c_char * 256)]
 
 
 _lib = None
@@ -121,6 +126,7 @@ def load():
     L.svils_gather_communities.argtypes = [vp]
     L.svils_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t]
     L.svils_step_sharded.argtypes = [vp, C.c_uint32]
+    L.svils_comm_query.argtypes = [vp, C.POINTER(CommInfo)]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -345,6 +351,14 @@ class Engine:
     def comm_init(self, comm_id, rank, world):
         assert len(comm_id) == COMM_ID_BYTES
         _chk(load().svils_comm_init(self._h, C.c_char_p(comm_id), rank, world))
+
+    def comm_query(self):
+        """what the bound RCCL says about this handle's communicator (ncclCommCount / UserRank / CuDevice / GetVersion)"""
+        ci = CommInfo()
+        _chk(load().svils_comm_query(self._h, C.byref(ci)))
+        return {"nranks": ci.nranks, "rank": ci.rank, "hip_device": ci.device, "rccl_version": ci.version,
+                "row_communicator": bool(ci.row_comm), "pci_bus_id": ci.pci_bus_id.decode(),
+                "library": ci.library.decode()}
 
     def sweep_sharded(self, nsweeps=1):
         _chk(load().svils_sweep_sharded(self._h, nsweeps))

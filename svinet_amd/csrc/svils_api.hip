@@ -68,6 +68,7 @@ struct svils_handle {
   size_t cls_zero_bytes = 0;
   // native multi-GPU driver (svils_comm_init)
   ncclComm_t comm = nullptr;
+  ncclComm_t comm_rows = nullptr;   // second communicator of the same ranks: the chunked row exchange on comm_stream
   int rank = 0, world = 1;
   // node-block sweeps: the row exchange runs on a stream of its own, in chunks, and the rows of a chunk are expanded
   // (k_expand) on the compute stream while the next chunk travels
@@ -485,6 +486,11 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  // evidence only (svils_comm_query); an RCCL build without one of them still runs the sweeps
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*GetVersion)(int *) = nullptr;
 };
 Rccl g_rccl;
 
@@ -511,6 +517,10 @@ int rccl_load() {
   BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather); BIND(Broadcast);
   BIND(GroupStart); BIND(GroupEnd); BIND(GetErrorString);
 #undef BIND
+  *(void **)(&g_rccl.CommCount) = dlsym(lib, "ncclCommCount");
+  *(void **)(&g_rccl.CommCuDevice) = dlsym(lib, "ncclCommCuDevice");
+  *(void **)(&g_rccl.CommUserRank) = dlsym(lib, "ncclCommUserRank");
+  *(void **)(&g_rccl.GetVersion) = dlsym(lib, "ncclGetVersion");
   g_rccl.lib = lib;
   return 0;
 }
@@ -522,8 +532,33 @@ int rccl_load() {
   } while (0)
 
 void comm_destroy(svils_handle *h) {
+  if (h->comm_rows && g_rccl.lib) (void)g_rccl.CommDestroy(h->comm_rows);
+  h->comm_rows = nullptr;
   if (h->comm && g_rccl.lib) (void)g_rccl.CommDestroy(h->comm);
   h->comm = nullptr;
+}
+
+// The second communicator (same ranks, same devices) that carries the chunked row exchange on comm_stream.  Collective:
+// every rank reaches it at the same point of its first pipelined sweep.  Rank 0 draws a fresh unique id and hands it to
+// the others over the first communicator (128 bytes through the staging word of the handle's stream).
+int ensure_row_comm(svils_handle *h) {
+  if (h->comm_rows || !h->comm) return 0;
+  if (getenv("SVILS_ONE_COMM") && atoi(getenv("SVILS_ONE_COMM")) != 0) {   // A/B knob: rows share the first communicator
+    h->comm_rows = nullptr;
+    return 0;
+  }
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  if (h->rank == 0) NCCLCHK(g_rccl.GetUniqueId(&id));
+  unsigned char *dev = nullptr;
+  HIPCHK(hipMalloc(&dev, sizeof id));
+  HIPCHK(hipMemcpyAsync(dev, &id, sizeof id, hipMemcpyHostToDevice, h->stream));
+  NCCLCHK(g_rccl.Broadcast(dev, dev, sizeof id, ncclUint8, 0, h->comm, h->stream));
+  HIPCHK(hipMemcpyAsync(&id, dev, sizeof id, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(dev);
+  NCCLCHK(g_rccl.CommInitRank(&h->comm_rows, h->world, id, h->rank));
+  return 0;
 }
 }  // namespace
 
@@ -560,6 +595,22 @@ int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
   return 0;
 }
 
+int svils_comm_query(svils_handle *h, svils_comm_info *out) {
+  if (!h || !out) return fail(SVILS_ERR_ARG, "svils_comm_query: null argument");
+  if (!h->comm) return fail(SVILS_ERR_ARG, "svils_comm_query: the handle has no communicator (svils_comm_init)");
+  memset(out, 0, sizeof *out);
+  out->nranks = out->rank = out->device = out->version = -1;
+  if (g_rccl.CommCount) NCCLCHK(g_rccl.CommCount(h->comm, &out->nranks));
+  if (g_rccl.CommUserRank) NCCLCHK(g_rccl.CommUserRank(h->comm, &out->rank));
+  if (g_rccl.CommCuDevice) NCCLCHK(g_rccl.CommCuDevice(h->comm, &out->device));
+  if (g_rccl.GetVersion) { int v = -1; if (g_rccl.GetVersion(&v) == ncclSuccess) out->version = v; }
+  out->row_comm = h->comm_rows ? 1 : 0;
+  if (out->device >= 0) (void)hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, out->device);
+  Dl_info di;
+  if (dladdr((void *)g_rccl.AllReduce, &di) && di.dli_fname) snprintf(out->library, sizeof out->library, "%s", di.dli_fname);
+  return 0;
+}
+
 namespace {
 // the exchanges of one sharded sweep: K-vector all-reduces are latency-bound, the row
 // gather carries N*ld*8 bytes; both all-gathers are in place (send block = own slice of the receive buffer)
@@ -591,8 +642,8 @@ int exchange_rows(svils_handle *h) {
   return 0;
 }
 
-// chunks of the pipelined row exchange: one (the grouped all-gather above) while the whole n-by-k payload is small,
-// up to eight of >= 64 MB each beyond that
+// chunks of the pipelined row exchange: one (the grouped all-gather above) while the whole n-by-k payload is below
+// 256 MB, then one per 128 MB, at most eight
 uint32_t exchange_chunks(const svils_handle *h) {
   if (h->xchunks) return h->xchunks;
   const uint64_t bytes = (uint64_t)h->geo.n_alloc * h->geo.ld * sizeof(double);
@@ -617,6 +668,11 @@ int exchange_rows_and_expand(svils_handle *h) {
   const uint32_t B = g.n_alloc / (uint32_t)h->world;
   if (!h->comm_stream) HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   if (!h->ev_ready) HIPCHK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+  {
+    int rc = ensure_row_comm(h);
+    if (rc) return rc;
+  }
+  ncclComm_t rows_comm = h->comm_rows ? h->comm_rows : h->comm;
   while (h->ev_chunk.size() < C) {
     hipEvent_t e;
     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -634,8 +690,8 @@ int exchange_rows_and_expand(svils_handle *h) {
       const size_t row0 = (size_t)r * B + xb;
       double *gp = d.gamma + row0 * g.ld;
       uint32_t *xp = d.xflags + row0 * d.xf_ld;
-      NCCLCHK(g_rccl.Broadcast(gp, gp, rows * g.ld, ncclDouble, r, h->comm, h->comm_stream));
-      NCCLCHK(g_rccl.Broadcast(xp, xp, rows * d.xf_ld, ncclUint32, r, h->comm, h->comm_stream));
+      NCCLCHK(g_rccl.Broadcast(gp, gp, rows * g.ld, ncclDouble, r, rows_comm, h->comm_stream));
+      NCCLCHK(g_rccl.Broadcast(xp, xp, rows * d.xf_ld, ncclUint32, r, rows_comm, h->comm_stream));
     }
     NCCLCHK(g_rccl.GroupEnd());
     HIPCHK(hipEventRecord(h->ev_chunk[c], h->comm_stream));
@@ -994,10 +1050,11 @@ int svils_destroy(svils_handle *h) {
   if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
   if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
   for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);   // nothing of a communicator may still be enqueued
   comm_destroy(h);
   if (h->stage) (void)hipFree(h->stage);
   if (h->stage_flag) (void)hipFree(h->stage_flag);
-  if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
   for (hipEvent_t e : h->ev_chunk) (void)hipEventDestroy(e);
   for (void *p : h->allocs) (void)hipFree(p);
@@ -1404,6 +1461,9 @@ int graph_sweeps(svils_handle *h, uint32_t n) {
   }
   h->sweeps_issued += n;
   if (n) h->v_flush_needed = h->v_flush_capture;   // what a captured sweep leaves behind
+  // ... and what run_phase's bookkeeping would have noted had the sweeps been launched eagerly: whole sweeps in derived
+  // form leave the stored mean indicators behind gamma (same condition as d.derive_m there)
+  if (n && !h->prm.stoch && !h->d.ksh && !h->d.lpl && h->derive_ok) h->mphi_stale = true;
   // as few replays as possible: powers of two from 2^kGraphMaxLog down (SVILS_GRAPH_POW2=0: 8-sweep graphs + singles)
   static const bool pow2 = !(getenv("SVILS_GRAPH_POW2") && atoi(getenv("SVILS_GRAPH_POW2")) == 0);
   if (pow2) {

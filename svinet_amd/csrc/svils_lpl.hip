@@ -613,11 +613,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
   // `sum`: folded from the phi pass's per-block partial rows (block 0 also publishes it), or the
   // reduced / all-reduced vector when the caller splits the sweep at its exchange points
   bool kv[NC];
-#ifdef FIN_FULL_ROWS   // experiment: write whole padded rows (no partially written 128-byte line)
-#define ST(j) (ok && (uint32_t)(lw + (j) * FW) < ld)
-#else
 #define ST(j) (kv[j] && ok)
-#endif
 #pragma unroll
   for (int j = 0; j < NC; ++j) kv[j] = (uint32_t)(lw + j * FW) < K;
   double s1[NC], s2[NC], scale[NC];
@@ -1268,11 +1264,7 @@ void launch_phi_lpl(const Geometry &g, const DeviceState &d, const Params &p, hi
 }
 // lanes per node in k_finalize_lpl (every lane ceil(K / lanes) communities) -> nodes per wavefront
 int lpl_finalize_group(uint32_t K) { return K <= 32 ? 8 : 16; }
-#ifdef FIN_FULL_ROWS
-#define FIN_NC3_MAXK 16
-#else
 #define FIN_NC3_MAXK 24
-#endif
 #define FIN_DISPATCH(K_, FIN)        \
   do {                               \
     if ((K_) <= 8) FIN(8, 1);        \

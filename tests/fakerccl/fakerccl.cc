@@ -7,11 +7,22 @@
 // environment variable SVILS_RCCL_LIBRARY names the library, and only tests/ ever point it here.
 //
 // Transport: a POSIX shared-memory segment named after the 128-byte unique id, one staging slot per rank.
-// Every collective is executed synchronously at the call (or at ncclGroupEnd for grouped calls, in issue
-// order): stream synchronise, device -> slot, barrier, combine from the slots in rank order, -> device,
-// barrier.  That is stricter than RCCL's stream ordering, never weaker, and deterministic.  Sums are taken
-// in rank order on every rank, so the result is bit-identical everywhere (as RCCL's all-reduce is).
-// A rank that does not show up within FAKERCCL_TIMEOUT_S (default 120) fails the collective on the others.
+// Sums are taken in rank order on every rank, so the result is bit-identical everywhere (as RCCL's all-reduce
+// is).  A rank that does not show up within FAKERCCL_TIMEOUT_S (default 120) fails the collective on the others.
+//
+// Two modes:
+//   synchronous (default): every collective is executed at the call (or at ncclGroupEnd for grouped calls, in
+//     issue order): stream synchronise, device -> slot, barrier, combine from the slots in rank order, -> device,
+//     barrier.  Stricter than RCCL's stream ordering, never weaker: it proves offsets, roots, counts and the
+//     protocol, but it HIDES a missing event edge between the streams of the caller.
+//   asynchronous (FAKERCCL_ASYNC=1): RCCL's contract and nothing more.  The call only ENQUEUES on the op's stream
+//     (copy to pinned staging, a host function that meets the peers and combines, copy back) and returns; the data
+//     is read when the stream gets there and the result exists only for work ordered after the op on that stream.
+//     A producer that was not ordered before the op (missing hipStreamWaitEvent on the communication stream) is read
+//     too early, a consumer on another stream that does not wait for the op reads the old bytes -- wrong answers
+//     instead of hidden bugs.  FAKERCCL_DELAY_US stretches every collective (the stream stays blocked that long after
+//     the peers met), which turns "usually fast enough" races into certain ones.  The operations of ONE communicator
+//     are executed in issue order whatever their streams, as RCCL serialises them.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -21,6 +32,7 @@
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -38,13 +50,19 @@ struct Header {
   std::atomic<uint64_t> calls;   // collectives executed (all ranks count the same ones): test evidence
 };
 
+struct AsyncOp;
 struct Comm {
-  int rank = 0, world = 1;
+  int rank = 0, world = 1, device = 0;
   Header *hdr = nullptr;
   unsigned char *slots = nullptr;
   size_t bytes = 0;
   char name[64] = {0};
   unsigned long long calls = 0, moved = 0;   // collectives this rank executed, payload bytes it contributed
+  // asynchronous mode
+  uint64_t issued = 0;                        // operations enqueued (host order)
+  std::atomic<uint64_t> completed{0};         // operations whose host function has run: ops of one communicator go in issue order
+  std::vector<AsyncOp *> inflight;            // staging of operations that may still be running, reaped at later calls
+  std::vector<std::pair<unsigned char *, size_t>> pool;   // pinned buffers free for reuse
 };
 
 struct Op {
@@ -61,10 +79,10 @@ struct Op {
 
 std::vector<Comm *> g_live;   // communicators not destroyed yet: their statistics are written at process exit
 
-void write_stats(const Comm *c) {   // test evidence: "<rank> <world> <collectives> <bytes>" per communicator
+void write_stats(const Comm *c) {   // test evidence: "<rank> <world> <collectives> <bytes> <communicator>" per communicator
   if (const char *path = getenv("FAKERCCL_STATS")) {
     if (FILE *f = fopen(path, "a")) {
-      fprintf(f, "%d %d %llu %llu\n", c->rank, c->world, c->calls, c->moved);
+      fprintf(f, "%d %d %llu %llu %s\n", c->rank, c->world, c->calls, c->moved, c->name + 10);
       fclose(f);
     }
   }
@@ -174,10 +192,144 @@ ncclResult_t run(const Op &o) {
   return ncclSuccess;
 }
 
+// ---------------------------------------------------------------- asynchronous mode
+bool async_mode() {
+  static const bool on = getenv("FAKERCCL_ASYNC") && atoi(getenv("FAKERCCL_ASYNC")) != 0;
+  return on;
+}
+long delay_us() {
+  static const long us = getenv("FAKERCCL_DELAY_US") ? atol(getenv("FAKERCCL_DELAY_US")) : 0;
+  return us;
+}
+
+struct AsyncOp {
+  Op o;
+  uint64_t seq = 0;
+  unsigned char *in = nullptr, *out = nullptr;   // pinned staging
+  size_t in_cap = 0, out_cap = 0;
+  hipEvent_t done = nullptr;                     // recorded behind the copy back
+};
+
+unsigned char *pinned(Comm *c, size_t need, size_t *cap) {
+  need = need ? need : 8;
+  for (size_t i = 0; i < c->pool.size(); ++i)
+    if (c->pool[i].second >= need) {
+      unsigned char *p = c->pool[i].first;
+      *cap = c->pool[i].second;
+      c->pool.erase(c->pool.begin() + (long)i);
+      return p;
+    }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) return nullptr;
+  *cap = need;
+  return (unsigned char *)p;
+}
+
+void reap(Comm *c, bool wait) {
+  for (size_t i = 0; i < c->inflight.size();) {
+    AsyncOp *a = c->inflight[i];
+    if (wait) (void)hipEventSynchronize(a->done);
+    if (wait || hipEventQuery(a->done) == hipSuccess) {
+      if (a->in) c->pool.emplace_back(a->in, a->in_cap);
+      if (a->out) c->pool.emplace_back(a->out, a->out_cap);
+      (void)hipEventDestroy(a->done);
+      delete a;
+      c->inflight.erase(c->inflight.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+}
+
+// runs on a runtime thread when the op's stream reaches it: no HIP calls in here
+void host_exchange(void *arg) {
+  AsyncOp *a = (AsyncOp *)arg;
+  const Op &o = a->o;
+  Comm *c = o.comm;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (c->completed.load(std::memory_order_acquire) != a->seq) {   // RCCL serialises the ops of one communicator
+    if ((++spins & 1023u) == 0) {
+      sched_yield();
+      if (c->hdr->failed.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s()) {
+        c->hdr->failed.store(1);
+        fprintf(stderr, "fakerccl: rank %d op %llu never got its turn (the ops of one communicator are serialised)\n", c->rank,
+                (unsigned long long)a->seq);
+        break;
+      }
+    }
+  }
+  const size_t es = dtype_size(o.dt);
+  const size_t per = (kSlot / es) * es / 8 * 8;
+  const size_t total = o.count * es;
+  bool ok = !c->hdr->failed.load();
+  for (size_t off = 0; ok && (off < total || (total == 0 && off == 0)); off += per) {
+    const size_t nb = total - off < per ? total - off : per;
+    unsigned char *mine = c->slots + (size_t)c->rank * kSlot;
+    if ((o.kind != 2 || c->rank == o.root) && nb) memcpy(mine, a->in + off, nb);
+    if (!barrier(c)) { ok = false; break; }
+    if (o.kind == 0) {
+      unsigned char *acc = a->out + off;
+      if (nb) memcpy(acc, c->slots, nb);
+      for (int r = 1; r < c->world; ++r) {
+        const unsigned char *x = c->slots + (size_t)r * kSlot;
+        switch (o.dt) {
+          case ncclFloat64: combine((double *)acc, (const double *)x, nb / 8, o.red); break;
+          case ncclUint64: combine((uint64_t *)acc, (const uint64_t *)x, nb / 8, o.red); break;
+          case ncclInt64: combine((int64_t *)acc, (const int64_t *)x, nb / 8, o.red); break;
+          case ncclUint32: combine((uint32_t *)acc, (const uint32_t *)x, nb / 4, o.red); break;
+          default: combine((int32_t *)acc, (const int32_t *)x, nb / 4, o.red); break;
+        }
+      }
+    } else if (o.kind == 1) {
+      for (int r = 0; r < c->world; ++r)
+        if (nb) memcpy(a->out + (size_t)r * total + off, c->slots + (size_t)r * kSlot, nb);
+    } else if (nb) {
+      memcpy(a->out + off, c->slots + (size_t)o.root * kSlot, nb);
+    }
+    if (!barrier(c)) { ok = false; break; }
+    if (total == 0) break;
+  }
+  if (!ok) fprintf(stderr, "fakerccl: rank %d: asynchronous op %llu failed (a peer is missing)\n", c->rank, (unsigned long long)a->seq);
+  if (const long us = delay_us()) usleep((useconds_t)us);   // the collective "takes" this long: the stream stays blocked
+  if (c->rank == 0) c->hdr->calls.fetch_add(1);
+  c->completed.store(a->seq + 1, std::memory_order_release);
+}
+
+ncclResult_t enqueue(const Op &o) {
+  Comm *c = o.comm;
+  const size_t es = dtype_size(o.dt);
+  if (!es) return ncclInvalidArgument;
+  if (o.kind == 0 && !(o.red == ncclSum || o.red == ncclMax || o.red == ncclMin)) return ncclInvalidArgument;
+  if (o.kind == 0 && !(o.dt == ncclFloat64 || o.dt == ncclUint32 || o.dt == ncclUint64 || o.dt == ncclInt32 || o.dt == ncclInt64))
+    return ncclInvalidArgument;
+  if (c->hdr->failed.load()) return ncclSystemError;
+  reap(c, false);
+  const size_t total = o.count * es;
+  AsyncOp *a = new AsyncOp;
+  a->o = o;
+  a->seq = c->issued++;
+  const bool contributes = o.kind != 2 || c->rank == o.root;
+  const size_t out_bytes = o.kind == 1 ? total * (size_t)c->world : total;
+  if (contributes) a->in = pinned(c, total, &a->in_cap);
+  a->out = pinned(c, out_bytes, &a->out_cap);
+  if ((contributes && !a->in) || !a->out) return ncclUnhandledCudaError;
+  HIPOK(hipEventCreateWithFlags(&a->done, hipEventDisableTiming));
+  if (contributes && total) HIPOK(hipMemcpyAsync(a->in, o.send, total, hipMemcpyDeviceToHost, o.stream));
+  HIPOK(hipLaunchHostFunc(o.stream, host_exchange, a));
+  if (out_bytes && !(o.kind == 2 && c->rank == o.root && o.recv == o.send))
+    HIPOK(hipMemcpyAsync(o.recv, a->out, out_bytes, hipMemcpyHostToDevice, o.stream));
+  HIPOK(hipEventRecord(a->done, o.stream));
+  c->inflight.push_back(a);
+  c->calls++;
+  c->moved += total;
+  return ncclSuccess;
+}
+
 ncclResult_t submit(const Op &o) {
   if (!o.comm) return ncclInvalidArgument;
   if (g_depth > 0) { g_ops.push_back(o); return ncclSuccess; }
-  return run(o);
+  return async_mode() ? enqueue(o) : run(o);
 }
 
 uint64_t fnv(const void *p, size_t n) {
@@ -205,6 +357,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
   Comm *c = new Comm;
   c->rank = rank;
   c->world = world;
+  (void)hipGetDevice(&c->device);
   snprintf(c->name, sizeof c->name, "/fakerccl-%016llx", (unsigned long long)fnv(&id, sizeof id));
   c->bytes = kHeader + (size_t)world * kSlot;
   const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
@@ -228,6 +381,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm *c = (Comm *)comm;
   if (!c) return ncclSuccess;
+  reap(c, true);                                     // asynchronous mode: whatever is still enqueued completes first
+  for (auto &b : c->pool) (void)hipHostFree(b.first);
+  c->pool.clear();
   write_stats(c);
   for (size_t i = 0; i < g_live.size(); ++i)
     if (g_live[i] == c) { g_live.erase(g_live.begin() + (long)i); break; }
@@ -263,9 +419,31 @@ ncclResult_t ncclGroupEnd() {
   std::vector<Op> ops;
   ops.swap(g_ops);
   for (const Op &o : ops) {
-    const ncclResult_t r = run(o);
+    const ncclResult_t r = async_mode() ? enqueue(o) : run(o);
     if (r != ncclSuccess) return r;
   }
+  return ncclSuccess;
+}
+
+// what svils_comm_query asks (evidence for launchers): answered from the communicator itself
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+  if (!comm || !count) return ncclInvalidArgument;
+  *count = ((const Comm *)comm)->world;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
+  if (!comm || !rank) return ncclInvalidArgument;
+  *rank = ((const Comm *)comm)->rank;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int *device) {
+  if (!comm || !device) return ncclInvalidArgument;
+  *device = ((const Comm *)comm)->device;
+  return ncclSuccess;
+}
+ncclResult_t ncclGetVersion(int *version) {
+  if (!version) return ncclInvalidArgument;
+  *version = 0;   // not an RCCL release: the tests' transport
   return ncclSuccess;
 }
 

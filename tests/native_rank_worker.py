@@ -87,6 +87,9 @@ def main():
         eng.gather_communities()
         extra = dict(mphi=eng.aux(2))
     eng.synchronize()
+    ci = eng.comm_query()
+    assert ci["rank"] == rank and ci["nranks"] == world and ci["hip_device"] == 0
+    extra.update(row_comm=ci["row_communicator"], comm_nranks=ci["nranks"])
     g, lam, conv = eng.state()
     c = eng.control()
     np.savez(out + ".%d.npz" % rank, gamma=g, lam=lam, conv=conv, member=eng.communities(), iter=c.iter,

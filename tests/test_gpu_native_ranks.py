@@ -26,22 +26,43 @@ FAKE = os.path.join(HERE, "fakerccl", "libfakerccl.so")
 SVINET = os.path.join(ROOT, "svinet_amd", "bin", "svinet")
 
 
-def _env(tmp_path=None):
+def _env(tmp_path=None, sync=False):
+    """The transport runs in its ASYNCHRONOUS mode (RCCL's stream-order contract and nothing more, every collective
+    stretched by 300 us) unless a test asks for the synchronous one: a missing hipStreamWaitEvent between the library's
+    compute and communication streams then gives a wrong answer instead of being hidden (tests/test_gpu_fakerccl_async.py
+    shows that it does)."""
     if not os.path.exists(FAKE):
         import __graft_entry__ as ge
         ge.build_test_transport()
     env = dict(os.environ)
     env["SVILS_RCCL_LIBRARY"] = FAKE
     env["FAKERCCL_TIMEOUT_S"] = "180"
+    env["FAKERCCL_ASYNC"] = "0" if sync else "1"
+    env["FAKERCCL_DELAY_US"] = "0" if sync else "300"
     if tmp_path is not None:
         env["FAKERCCL_STATS"] = str(tmp_path / "fakerccl.stats")
     return env
 
 
-def _run_ranks(tmp_path, path, n, k, count, world, mode, extra_env=None):
+def _read_stats(path, world):
+    """-> (collectives rank 0 executed, summed over its communicators; number of communicators).  Every communicator must
+    have been joined by every rank, and every rank must have executed the same number of collectives on it."""
+    by_comm = {}
+    for line in open(path):
+        r, w, calls, moved, name = line.split()
+        by_comm.setdefault(name, []).append((int(r), int(w), int(calls)))
+    total = 0
+    for name, rows in by_comm.items():
+        assert sorted(x[0] for x in rows) == list(range(world)) and all(x[1] == world for x in rows), (name, rows)
+        assert len({x[2] for x in rows}) == 1, (name, rows)
+        total += rows[0][2]
+    return total, len(by_comm)
+
+
+def _run_ranks(tmp_path, path, n, k, count, world, mode, extra_env=None, sync=False):
     out = str(tmp_path / "state")
     worker = os.path.join(HERE, "native_rank_worker.py")
-    env = _env(tmp_path)
+    env = _env(tmp_path, sync=sync)
     env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, worker, path, str(n), str(k), str(count), out, str(r), str(world), mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
@@ -56,10 +77,7 @@ def _run_ranks(tmp_path, path, n, k, count, world, mode, extra_env=None):
         errs.append(err)
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d:\n%s" % (r, errs[r][-3000:])
-    stats = [tuple(int(x) for x in line.split()) for line in open(env["FAKERCCL_STATS"])]
-    assert sorted(s[0] for s in stats) == list(range(world)) and all(s[1] == world for s in stats)
-    assert len({s[2] for s in stats}) == 1          # every rank executed the same number of collectives
-    return [np.load(out + ".%d.npz" % r) for r in range(world)], stats
+    return [np.load(out + ".%d.npz" % r) for r in range(world)], _read_stats(env["FAKERCCL_STATS"], world)
 
 
 def _oracle(path, n, k, sweeps, **kw):
@@ -85,17 +103,20 @@ def _check_node_block(states, ref, n, world, tags=True):
     return B
 
 
-@pytest.mark.parametrize("graph,world,k,sweeps,chunks", [("lfr", 2, 28, 40, 1), ("lfr", 3, 64, 6, 1), ("lfr", 3, 28, 35, 1),
-                                                          ("astroph", 2, 200, 3, 1),
-                                                          # the pipelined row exchange (chunks on a stream of their own, each
-                                                          # expanded while the next one travels): 3 and 5 chunks of uneven size
-                                                          ("lfr", 3, 28, 35, 3), ("lfr", 2, 100, 8, 5), ("astroph", 3, 200, 3, 4)])
-def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps, chunks):
+@pytest.mark.parametrize("graph,world,k,sweeps,chunks,sync", [("lfr", 2, 28, 40, 1, False), ("lfr", 3, 64, 6, 1, False), ("lfr", 3, 28, 35, 1, False),
+                                                               ("astroph", 2, 200, 3, 1, False),
+                                                               # the pipelined row exchange (chunks on a stream and a communicator of
+                                                               # their own, each expanded while the next one travels): 3 and 5 chunks
+                                                               # of uneven size
+                                                               ("lfr", 3, 28, 35, 3, False), ("lfr", 2, 100, 8, 5, False), ("astroph", 3, 200, 3, 4, False),
+                                                               # and once each on the synchronous transport
+                                                               ("lfr", 2, 28, 40, 1, True), ("lfr", 3, 28, 35, 3, True)])
+def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps, chunks, sync):
     """svils_sweep_sharded in `world` processes: all-reduce of sum[k], the grouped in-place all-gather of the
     gamma rows and packed flags at rank * B * ld, all-reduce of s1,s2,s3 (grouped with sum[k] once annealing is
     off: LFR K=28 leaves annealing at sweep 29, seen at sweep 32)"""
     path, n = graph_files[graph], {"lfr": 1000, "astroph": 17903}[graph]
-    states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, "sweep", {"SVILS_XCHUNKS": str(chunks)})
+    states, (calls, ncomm) = _run_ranks(tmp_path, path, n, k, sweeps, world, "sweep", {"SVILS_XCHUNKS": str(chunks)}, sync=sync)
     ref = _oracle(path, n, k, sweeps)
     _check_node_block(states, ref, n, world)
     late = sum(1 for i in range(sweeps) if i >= 32) if (graph, k) == ("lfr", 28) and not ref.annealing else 0
@@ -103,8 +124,12 @@ def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, swee
         assert int(s["exchanges"]) == 3 * (sweeps - late) + 2 * late
     # collectives on the wire: per sweep all-reduce + rows + all-reduce(s) [sum rides with them once annealing is off],
     # + the tag gather; rows = 2 all-gathers, or chunks x world x 2 broadcasts when pipelined
+    # ... the chunks on a second communicator, whose id travelled as one more broadcast on the first
     rows = 2 if chunks == 1 else chunks * world * 2
-    assert stats[0][2] == (2 + rows) * sweeps + 1
+    assert ncomm == (1 if chunks == 1 else 2)
+    assert calls == (2 + rows) * sweeps + 1 + (0 if chunks == 1 else 1)
+    for s in states:
+        assert bool(s["row_comm"]) == (chunks > 1) and int(s["comm_nranks"]) == world
 
 
 @pytest.mark.parametrize("world,k,steps,mode", [(2, 28, 30, "step:1:0"), (3, 64, 5, "step:1:0")])
@@ -112,10 +137,10 @@ def test_native_step_sharded_full_window_is_a_sweep(graph_files, tmp_path, world
     """svils_step_sharded with one window per block and step size 1: full sweeps, so every rank equals the oracle.
     The window rows travel as world x 3 in-place broadcasts, rank r the root of its own window."""
     path, n = graph_files["lfr"], 1000
-    states, stats = _run_ranks(tmp_path, path, n, k, steps, world, mode)
+    states, (calls, _) = _run_ranks(tmp_path, path, n, k, steps, world, mode)
     ref = _oracle(path, n, k, steps)
     _check_node_block(states, ref, n, world, tags=False)
-    assert stats[0][2] == steps * (2 + 3 * world) + 1
+    assert calls == steps * (2 + 3 * world) + 1
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -153,7 +178,7 @@ def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mo
     slices put together equal the oracle, flags / rows / counters replicated; svils_validation_row and
     svils_comm_allgather_host (collective staging) with rank > 0"""
     path, n = graph_files["lfr"], 1000
-    states, stats = _run_ranks(tmp_path, path, n, k, sweeps, world, mode)
+    states, (calls, _) = _run_ranks(tmp_path, path, n, k, sweeps, world, mode)
     ref = _oracle(path, n, k, sweeps, **({"link_thresh": 0.3} if mode == "kshard-lowt" else {}))
     g = np.concatenate([s["gamma"] for s in states], 1)
     lam = np.concatenate([s["lam"] for s in states], 0)
@@ -174,7 +199,7 @@ def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mo
             assert np.array_equal(s["gathered"][q][:, :q1 - q0], want[:, q0:q1])
         assert int(s["exchanges"]) == per_sweep * sweeps + 2   # + init rows + validation row
     # + 2 collectives of the staging (the agreement all-reduce and the gather itself)
-    assert stats[0][2] == per_sweep * sweeps + 2 + 2
+    assert calls == per_sweep * sweeps + 2 + 2
 
 
 @pytest.mark.parametrize("world,k,nwin,steps", [(2, 28, 3, 45), (3, 100, 4, 16)])
@@ -184,7 +209,7 @@ def test_native_step_ksharded_ranks(graph_files, tmp_path, world, k, nwin, steps
     svils_step on one plain handle with the same windows and step sizes."""
     from svinet_amd.host_api import Setup
     path, n = graph_files["lfr"], 1000
-    states, stats = _run_ranks(tmp_path, path, n, k, steps, world, "kstep:%d:0.6" % nwin)
+    states, (calls, _) = _run_ranks(tmp_path, path, n, k, steps, world, "kstep:%d:0.6" % nwin)
     setup = Setup(path, n, k)
     plain = setup.engine(use_validation_stop=False)
     plain.set_stochastic(batch_nodes=(n + nwin - 1) // nwin, tau0=4.0, kappa=0.6, node_tau0=2.0, node_kappa=0.5)
@@ -198,7 +223,7 @@ def test_native_step_ksharded_ranks(graph_files, tmp_path, world, k, nwin, steps
         assert np.array_equal(s["conv"], pc)
         assert int(s["iter"]) == steps
         np.testing.assert_allclose(s["rows"][:, 1:], plain.rows()[:, 1:], rtol=1e-8, atol=1e-11)
-    assert stats[0][2] == 4 * steps + 2 + 2        # per step den, rowx, q2v, vdot; + init rows, the constructor row, the staged gather
+    assert calls == 4 * steps + 2 + 2        # per step den, rowx, q2v, vdot; + init rows, the constructor row, the staged gather
 
 
 # ----------------------------------------------------------------------------------------- the CLI, forked ranks
@@ -236,8 +261,8 @@ def test_cli_gpus_ranks_files_equal_oracle(graph_files, tmp_path, world, extra):
     assert v.shape == (M + 2, 11)                    # constructor row + one per sweep (quirk Q8: M + 1 sweeps)
     np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
     assert len([x for x in os.listdir(str(tmp_path)) if x.endswith("-linksampling")]) == 1
-    stats = [tuple(int(x) for x in line.split()) for line in open(str(tmp_path / "fakerccl.stats"))]
-    assert sorted(s[0] for s in stats) == list(range(world)) and len({s[2] for s in stats}) == 1 and stats[0][2] > M
+    calls, _ = _read_stats(str(tmp_path / "fakerccl.stats"), world)
+    assert calls > M
 
 
 def test_cli_gpus_minibatch_ranks(graph_files, tmp_path):
@@ -321,6 +346,36 @@ def test_cli_gpus_sigterm_is_collective(graph_files, tmp_path):
     assert v.shape[0] == 1502
 
 
+def _check_bench_line(stdout):
+    import json
+    line = [l for l in stdout.split("\n") if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["roofline"]["launches_timed"] >= 10 and out["exchange"]["ms_per_sweep"] > 0
+    assert out["roofline"]["frac"] <= 1.0
+    # the communicator as the bound library describes it: two ranks, each asked about its own
+    rc = out["rccl"]
+    assert rc["nranks"] == [2] and sorted(r["rank"] for r in rc["ranks"]) == [0, 1]
+    assert len({r["pid"] for r in rc["ranks"]}) == 2 and rc["library"][0].endswith("libfakerccl.so")
+    assert out["n1_same_box"]["value"] > 0 and out["cpu_baseline"]["value"] > 0
+    return out
+
+
+def test_bench_bare_gpus_2_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (what a driver that only knows the N = 1 command types):
+    bench.py spawns its two ranks itself and rank 0 prints the one JSON line -- here in test mode (both ranks on GPU 0,
+    the tests' transport in asynchronous mode)."""
+    env = _env(tmp_path)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--test-one-gpu",
+                        "--extra-list", "config4_astroph_k200"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.split("\n") if l.startswith("{")]) == 1      # ONE line, from rank 0
+    out = _check_bench_line(r.stdout)
+    assert "error" not in out["sharded_extra"]["config4_astroph_k200"]
+
+
 def test_bench_multi_gpu_code_path_two_ranks(tmp_path):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), in its test mode:
     both ranks on GPU 0, the library's collectives on the tests' transport.  The N > 1 path of bench.py -- sharded
@@ -332,10 +387,7 @@ def test_bench_multi_gpu_code_path_two_ranks(tmp_path):
                         "--test-one-gpu", "--extra-list", "config4_astroph_k200,minibatch_steps_astroph_k20,ksharded_config4_astroph_k200"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["value"] > 0 and out["scaling"] == "strong"
-    assert out["roofline"]["launches_timed"] >= 10 and out["exchange"]["ms_per_sweep"] > 0
+    out = _check_bench_line(r.stdout)
     ex = out["sharded_extra"]
     for name in ("config4_astroph_k200", "minibatch_steps_astroph_k20", "ksharded_config4_astroph_k200"):
         assert "error" not in ex[name], ex[name]

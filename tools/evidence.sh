@@ -1,0 +1,77 @@
+#!/bin/bash
+# One parameterised evidence script for the GPU box (replaces the per-round job lists):
+#   gpurun --timeout 3000 -- 'EVIDENCE_COMMIT=<sha> bash tools/evidence.sh <tag> <step> [<step> ...]'
+# Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_*.
+# steps:
+#   smoke        __graft_entry__.smoke()
+#   bench        the driver's command (--gpus 1 --steps 20 --warmup 5) and the default line
+#   bench-lite   the default line without the config5 / hbm_bound records (fast)
+#   bench-extra  LFR K=28 and ca-AstroPh K=200 lines
+#   bench2       bare `python bench.py --gpus 2 --test-one-gpu` (self-spawned ranks on GPU 0, tests' transport, async)
+#   prof         rocprofv3 --kernel-trace --stats of the default command (ca-AstroPh K=20) and of LFR K=28
+#   pmc          rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the three roofline workloads -> traffic.json + table
+#   pmc-small    the same for astroph-k20 only
+#   native       tests/test_gpu_native_ranks.py
+#   pytest       the whole -m gpu suite          (PYTEST_ARGS adds arguments, e.g. PYTEST_ARGS="-k config5")
+#   kscan        tools/k_scan.sh
+#   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations
+#   cli          bench.py's cli_end_to_end record alone
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+prof_one() {  # name, bench args...
+  local name=$1; shift
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o k -- python $R/bench.py "$@" > $O/prof_$name.log 2>&1)
+  local f=$(find $O/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/${name}_kernel_stats.csv && head -6 $f | cut -c1-160
+  rm -rf $O/prof_$name
+}
+for step in "$@"; do
+  echo "=== $step"
+  case $step in
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.txt ;;
+    bench)
+      python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_astroph_k20_steps20.json 2> $O/bench.err; tail -c 300 $O/bench_astroph_k20_steps20.json; echo
+      python bench.py > $O/bench_astroph_k20.json 2>> $O/bench.err; tail -c 300 $O/bench_astroph_k20.json; echo ;;
+    bench-lite) python bench.py --no-hbm-bound --no-config5 > $O/bench_astroph_k20_lite.json 2>> $O/bench.err; tail -c 300 $O/bench_astroph_k20_lite.json; echo ;;
+    bench-extra)
+      python bench.py --workload lfr-k28 --no-hbm-bound --no-config5 --no-cpu-baseline > $O/bench_lfr_k28.json 2>> $O/bench.err
+      python bench.py --workload astroph-k200 --no-hbm-bound --no-config5 --no-cpu-baseline > $O/bench_astroph_k200.json 2>> $O/bench.err
+      tail -c 200 $O/bench_lfr_k28.json; echo ;;
+    bench2)
+      python -c "import __graft_entry__ as g; g.build_test_transport()"
+      SVILS_RCCL_LIBRARY=$R/tests/fakerccl/libfakerccl.so FAKERCCL_ASYNC=1 timeout 900 python bench.py --gpus 2 --steps 10 --warmup 2 --test-one-gpu \
+        --extra-list config4_astroph_k200 > $O/bench_gpus2_one_gpu.json 2> $O/bench2.err; echo "rc=$?"; tail -c 400 $O/bench_gpus2_one_gpu.json; echo; tail -5 $O/bench2.err ;;
+    prof)
+      prof_one astroph_k20 --no-cpu-baseline --no-hbm-bound --no-config5
+      prof_one lfr_k28 --workload lfr-k28 --no-cpu-baseline --no-hbm-bound --no-config5 ;;
+    pmc|pmc-small)
+      WLS="astroph-k20 synthetic:200000:512:24 mmsb:1000000:512:24"; [ $step = pmc-small ] && WLS="astroph-k20"
+      ARGS=""
+      for wl in $WLS; do
+        w=$(echo $wl | tr ':' '_')
+        (cd /tmp && export TMPDIR=/tmp
+         timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$w -o p -- python $R/tools/kernel_times.py $wl 6 > $O/pmcf_$w.log 2>&1
+         timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_$w -o p -- python $R/tools/kernel_times.py $wl 6 > $O/pmcw_$w.log 2>&1)
+        find $O/pmcf_$w $O/pmcw_$w -type f ! -name "*counter_collection.csv" -delete
+        ARGS="$ARGS $wl $O/pmcf_$w $O/pmcw_$w"
+      done
+      python tools/pmc_traffic.py $O/traffic.json $O/hbm_traffic_pmc.txt $ARGS
+      rm -rf $O/pmcf_* $O/pmcw_* ;;
+    native) timeout 2400 python -m pytest tests/test_gpu_native_ranks.py tests/test_gpu_fakerccl_async.py -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_native.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_native.txt; tail -25 $O/pytest_native.txt ;;
+    pytest) timeout 3000 python -m pytest tests -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -25 $O/pytest_gpu.txt ;;
+    kscan) bash tools/k_scan.sh 2>&1 | tee $O/k_scan_astroph.txt ;;
+    shardcost)
+      (cd /tmp; export TMPDIR=/tmp
+       for wl in astroph-k200 mmsb:1000000:512:24; do
+         t=$(echo $wl | tr ':' '_')
+         python $R/tools/shard_cost.py $wl 2,4,8 2>/dev/null | tee -a $O/shard_cost_model_inputs.txt
+         rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$t -o p -- python $R/tools/shard_cost.py $wl 8 > /dev/null 2>&1
+         f=$(find $O/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/shard_rank0of8_kernel_stats_$t.csv
+         rm -rf $O/prof_$t
+       done) ;;
+    cli) python bench.py --cli-only > $O/bench_cli_end_to_end.json 2> $O/bench_cli.err; tail -c 1500 $O/bench_cli_end_to_end.json; echo ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+du -sh $O

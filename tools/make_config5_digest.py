@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Full-size parity pin for BASELINE config 5 (planted MMSB graph, n = 1,000,000, k = 512).
+
+Runs the ORACLE (oracle/svinet_oracle.c, the sequential restatement of src/linksampling.cc:556-790 -- the same
+code every small parity test uses, not the threaded variant) for SWEEPS sweeps from the seeded initial state on the
+graph of svinet_amd/mmsbgen_sparse.py, and writes a small digest under tests/golden/config5/ that the -m gpu test
+tests/test_gpu_config5.py::test_config5_full_size_against_oracle_digest compares the HIP run with:
+
+  lambda [512][2], the column sums of gamma [512], 64 fixed gamma rows [64][512], the converged flags (count + the
+  indices), active_comms histogram, the three link counters of every sweep, the likelihood rows (constructor + one per
+  sweep), SHA-256 of the training-link list and of the held-out pair list (so that the test knows it is looking at the
+  same graph and the same held-out set).
+
+Run in the BUILD container (needs ~25 GB of RAM and ~2.5 min per sweep on one core):
+  python tools/make_config5_digest.py [sweeps=2]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+N, K, DEG = 1_000_000, 512, 24
+ROWS_SEED = 20240517
+
+
+def fixed_rows(n, count=64):
+    """the 64 gamma rows the digest keeps (the test uses the same function)"""
+    return np.sort(np.random.default_rng(ROWS_SEED).choice(n, size=count, replace=False)).astype(np.int64)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    from oracle import oracle as O
+    from svinet_amd import mmsbgen_sparse as G
+    t0 = time.time()
+    pairs = G.generate(N, K, DEG)
+    net = O.Network(n=N, pairs=pairs)
+    ref = O.LinkSampling(net, K, use_validation_stop=False)
+    print("graph + constructor: %.0f s, %d training links" % (time.time() - t0, ref.nlinks), flush=True)
+    counts = []
+    for i in range(sweeps):
+        t1 = time.time()
+        ref.sweep()
+        counts.append([int(x) for x in ref.link_counts()])
+        print("sweep %d: %.0f s, links dense/sparse/shortcut %r" % (i, time.time() - t1, counts[-1]), flush=True)
+    g = ref.gamma
+    conv = ref.converged
+    rows_idx = fixed_rows(N)
+    out = os.path.join(ROOT, "tests", "golden", "config5")
+    os.makedirs(out, exist_ok=True)
+    np.savez_compressed(os.path.join(out, "digest.npz"), lam=ref.lam, gamma_colsum=g.sum(0), gamma_rows=g[rows_idx],
+                        rows_idx=rows_idx, converged_idx=np.flatnonzero(conv).astype(np.uint32),
+                        converged_val=conv[conv > 0], active_hist=np.bincount(ref.active_comms, minlength=K + 1),
+                        link_counts=np.asarray(counts, dtype=np.int64), likelihood_rows=ref.rows,
+                        gamma_rowsum_minmax=np.asarray([g.sum(1).min(), g.sum(1).max()]))
+    meta = {"n": N, "k": K, "mean_degree": DEG, "sweeps": sweeps, "nlinks": int(ref.nlinks),
+            "nvalidation": int(ref.validation_sorted.shape[0]), "links_sha256": sha(ref.links),
+            "validation_sha256": sha(ref.validation_sorted), "total_pairs_uint32": ref.total_pairs, "ones_prob": ref.ones_prob,
+            "generator": "svinet_amd/mmsbgen_sparse.py seed %d" % G.DEFAULT_SEED,
+            "oracle": "oracle/svinet_oracle.c, sequential sweep (orc_ls_sweep)", "made_by": "tools/make_config5_digest.py",
+            "wall_s": round(time.time() - t0)}
+    json.dump(meta, open(os.path.join(out, "digest.json"), "w"), indent=1)
+    print(json.dumps(meta))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,16 +1,21 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, csv output)
-into HBM bytes per kernel launch, and update profiles/traffic.json for the phi kernel.
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, csv output) into HBM bytes
+per kernel launch and per whole sweep, and write the record bench.py reads (profiles/traffic.json).
 
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_X -o p -- python tools/kernel_times.py WORKLOAD 15
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_X -o p -- python tools/kernel_times.py WORKLOAD 15
-  python tools/pmc_traffic.py WORKLOAD gpurun_out/pmc_fetch_X gpurun_out/pmc_write_X [profiles/<file this table is kept in>]
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR/pmcf_W -o p -- python tools/kernel_times.py WORKLOAD 6
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d DIR/pmcw_W -o p -- python tools/kernel_times.py WORKLOAD 6
+  python tools/pmc_traffic.py OUT.json TABLE.txt WORKLOAD DIR/pmcf_W DIR/pmcw_W [WORKLOAD DIR DIR ...]
+(tools/evidence.sh pmc does all of it on the GPU box; copy OUT.json to profiles/traffic.json and TABLE.txt beside it.)
 
-Counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
-(MI355X_MICROARCH.md, HBM section), so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+Counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM
+section), so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Every record carries the hashes of the kernel's source
+files as they were in the tree that was measured (bench.KERNEL_SOURCES): bench.py refuses the record once they differ.
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def load(d, counter):
@@ -25,34 +30,47 @@ def load(d, counter):
     return acc
 
 
+def workload_k(wl):
+    if wl.startswith("astroph-k"):
+        return int(wl[len("astroph-k"):])
+    if wl.startswith("lfr-k"):
+        return int(wl[len("lfr-k"):])
+    return int(wl.split(":")[2])
+
+
 def main():
-    wl, fd, wd = sys.argv[1:4]
-    fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-    print("%-14s %-34s %14s %14s %18s %6s" % ("workload", "kernel", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes/launch", "n"))
-    phi = None
-    for k in fe:
-        n = max(fe[k][1], 1)
-        f, w = fe[k][0] / n, wr.get(k, [0, 1])[0] / max(wr.get(k, [0, 1])[1], 1)
-        b = (2 * f + w) * 1024
-        print("%-14s %-34s %14.0f %14.0f %18.0f %6d" % (wl, k[:34], f, w, b, n))
-        if k.startswith("k_phi"):
-            phi = b
-    if phi is not None:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        path = os.path.join(root, "profiles", "traffic.json")
-        t = json.load(open(path)) if os.path.exists(path) else {}
-        import subprocess
-        try:
-            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
-            dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "svinet_amd/csrc"], text=True).strip())
-            commit += "+uncommitted kernel changes" if dirty else ""
-        except Exception:
-            commit = None
-        t[wl] = {"phi_hbm_bytes_per_launch": phi,
-                 "source": sys.argv[4] if len(sys.argv) > 4 else None,   # the profiles/ file holding this table
-                 "commit": commit,
-                 "counters": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB"}
-        json.dump(t, open(path, "w"), indent=1)
+    from bench import kernel_source_hashes
+    out_json, table = sys.argv[1:3]
+    rest = sys.argv[3:]
+    rec = {}
+    lines = []
+    commit = os.environ.get("EVIDENCE_COMMIT")   # the GPU box has no .git: the caller names the commit it snapshotted
+    for i in range(0, len(rest), 3):
+        wl, fd, wd = rest[i:i + 3]
+        fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+        lines.append("%-24s %-34s %14s %14s %18s %6s" % ("workload", "kernel", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes/launch", "n"))
+        phi, nphi, per_kernel = None, 0, {}
+        for k in fe:
+            n = max(fe[k][1], 1)
+            f, w = fe[k][0] / n, wr.get(k, [0, 1])[0] / max(wr.get(k, [0, 1])[1], 1)
+            b = (2 * f + w) * 1024
+            lines.append("%-24s %-34s %14.0f %14.0f %18.0f %6d" % (wl, k[:34], f, w, b, n))
+            per_kernel[k] = (b, n)
+            if k.startswith("k_phi"):
+                phi, nphi = b, n
+        if phi is None:
+            continue
+        # one whole sweep: every kernel the loop launches (launched at least every other sweep), bytes x launches / sweeps
+        in_loop = {k: v for k, v in per_kernel.items() if k.startswith("k_") and v[1] * 2 >= nphi}
+        sweep = sum(b * n for b, n in in_loop.values()) / nphi
+        lines.append("%-24s %-34s %48.0f %6d" % (wl, ("whole sweep: " + "+".join(sorted(x.split("<")[0] for x in in_loop)))[:34], sweep, nphi))
+        rec[wl] = {"phi_hbm_bytes_per_launch": phi, "sweep_hbm_bytes": sweep,
+                   "sweep_kernels": {k: {"hbm_bytes_per_launch": v[0], "launches": v[1]} for k, v in sorted(in_loop.items())},
+                   "source": None, "commit": commit, "source_hashes": kernel_source_hashes(workload_k(wl)),
+                   "counters": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB"}
+    open(table, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    json.dump(rec, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
