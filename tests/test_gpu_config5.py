@@ -1,10 +1,11 @@
 """-m gpu: BASELINE config 5 (synthetic MMSB, n = 1,000,000, k = 512) at FULL size on one GPU, and an
 HBM-bound parity point against the oracle.
 
-At n = 10^6 the oracle needs ~155 s per sweep, so the full-size run is checked through the
-size-independent properties of the sweep (tests/test_gpu_properties.py); parity proper is pinned one
-size down (n = 2*10^5, k = 512: 0.82 GB per n-by-k array, far outside the 256 MB Infinity Cache, the
-same kernels and layouts), one sweep against the oracle.
+At n = 10^6 the oracle needs ~155 s per sweep: too slow to run beside the test, so the full-size parity check
+compares with a DIGEST of the oracle's state that tools/make_config5_digest.py produced in the build container
+(tests/golden/config5/).  The full-size run is also checked through the size-independent properties of the sweep
+(tests/test_gpu_properties.py), and one size down (n = 2*10^5, k = 512: 0.82 GB per n-by-k array, far outside the
+256 MB Infinity Cache, the same kernels and layouts) against the oracle running live.
 """
 import numpy as np
 import pytest
@@ -48,6 +49,51 @@ def test_config5_full_size_invariants():
     rows = e1.rows()
     assert np.isfinite(rows).all() and list(rows[:, 0]) == [0.0, 1.0] and rows[0, 2] == s.validation_sorted.shape[0]
     assert np.array_equal(rows, e2.rows())
+
+
+def test_config5_full_size_against_oracle_digest():
+    """BASELINE config 5 at FULL size (n = 1,000,000, k = 512) against the ORACLE: tools/make_config5_digest.py ran the
+    sequential oracle for 2 sweeps on this graph in the build container (~2.5 min per sweep, 25 GB -- too slow to repeat
+    on the GPU box) and committed a digest of its state (tests/golden/config5/); the HIP run must reproduce it --
+    lambda, the column sums of gamma and 64 fixed gamma rows to 1e-9 relative, every integer exactly
+    (src/linksampling.cc:605-761)."""
+    import hashlib
+    import json
+    import os
+    from svinet_amd import mmsbgen_sparse as G
+    from svinet_amd.host_api import Setup
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5")
+    meta = json.load(open(os.path.join(d, "digest.json")))
+    dg = np.load(os.path.join(d, "digest.npz"))
+    n, k = meta["n"], meta["k"]
+    assert (n, k) == (1_000_000, 512)
+    s = Setup(n=n, k=k, pairs=G.generate(n, k, meta["mean_degree"]))
+    # the same graph, the same held-out set, the same wrapped total_pairs (quirk Q5) as the oracle saw
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert int(s.nlinks) == meta["nlinks"] and sha(s.links.astype(np.uint32)) == meta["links_sha256"]
+    assert sha(s.validation_sorted.astype(np.uint32)) == meta["validation_sha256"]
+    assert s.total_pairs == meta["total_pairs_uint32"] and s.ones_prob == meta["ones_prob"]
+    eng = s.engine(use_validation_stop=False)
+    row0 = eng.validation_row()
+    eng.sweep(meta["sweeps"])
+    g, lam, conv = eng.state()
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))
+    assert rel(lam, dg["lam"]) < 1e-9
+    assert rel(g.sum(0), dg["gamma_colsum"]) < 1e-9
+    assert rel(g[dg["rows_idx"]], dg["gamma_rows"]) < 1e-9
+    rs = g.sum(1)
+    np.testing.assert_allclose([rs.min(), rs.max()], dg["gamma_rowsum_minmax"], rtol=1e-9)
+    # integers: exactly
+    assert np.array_equal(np.flatnonzero(conv).astype(np.uint32), dg["converged_idx"])
+    assert np.array_equal(conv[conv > 0], dg["converged_val"])
+    assert np.array_equal(np.bincount(eng.aux(3), minlength=k + 1), dg["active_hist"])
+    st = eng.sweep_stats(0, meta["sweeps"])
+    assert np.array_equal(st.astype(np.int64), dg["link_counts"])
+    # likelihood rows: the constructor's and one per sweep (columns: iter, s/k, k, mean0, k0, mean1, k1, ...)
+    want = dg["likelihood_rows"]
+    np.testing.assert_allclose(row0[1:], want[0, 1:], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(eng.rows()[:, 1:], want[1:, 1:], rtol=1e-9, atol=1e-13)
+    assert list(eng.rows()[:, 0]) == list(want[1:, 0])
 
 
 def test_hbm_bound_sweep_against_oracle():
