@@ -344,6 +344,41 @@ def cpu_baseline_allcores(path, pairs, n, k, warmup, steps, budget_s=12.0):
             "cpu_affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota_cores": quota}
 
 
+def cli_end_to_end(path, n, k, value_ms_per_step):
+    """What the user of the DROP-IN gets: wall time of `svinet -file ca-AstroPh -n 17903 -k 20 -link-sampling` run to its
+    stop rule, split into read / constructor / graph upload / sweeps (incl. the per-report files) / final files, from the
+    CLI's own clocks (SVINET_TIMING_FILE).  Three forms: the default (report snapshots collected while the device sweeps
+    on, automatic chunks), -sweep-batch 1 (one report per sweep, the reference's cadence, src/linksampling.cc:777-786)
+    and the synchronous loop of earlier rounds at -sweep-batch 1 (a stream synchronisation + file rewrite per sweep)."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "svinet_amd", "bin", "svinet")
+    out = {"command": "svinet -file ca-AstroPh.csv -n %d -k %d -link-sampling   (runs to the validation stop rule)" % (n, k),
+           "library_ms_per_sweep": value_ms_per_step}
+    for name, extra, env in (("default", [], {}), ("sweep_batch_1", ["-sweep-batch", "1"], {}),
+                             ("sweep_batch_16", ["-sweep-batch", "16"], {}),
+                             ("synchronous_sweep_batch_1", ["-sweep-batch", "1"], {"SVINET_SYNC_REPORTS": "1"})):
+        d = tempfile.mkdtemp(prefix="svinet_cli_")
+        try:
+            tf = os.path.join(d, "timing.json")
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "-file", path, "-n", str(n), "-k", str(k), "-link-sampling"] + extra, cwd=d,
+                               env=dict(os.environ, SVINET_TIMING_FILE=tf, **env), capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                out[name] = {"error": r.stderr[-300:]}
+                continue
+            tm = json.load(open(tf))
+            tm["process_wall_s"] = wall
+            nsw, sw = tm["sweeps"], tm["sweeps_s"]
+            tm["ms_per_sweep"] = sw / nsw * 1e3
+            tm["vs_library_sweep"] = tm["ms_per_sweep"] / value_ms_per_step
+            out[name] = tm
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def _load_workload(name):
     """-> (setup, path, pairs, n, k, data description)"""
     from svinet_amd.host_api import Setup
@@ -525,6 +560,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N>1: skip the side records (config 4, HBM-bound size)")
     ap.add_argument("--extra-list", default="", help="N>1: comma-separated names of the side records to run (default: all)")
     ap.add_argument("--test-one-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-cli", action="store_true", help="N=1: skip the cli_end_to_end record (three runs of the svinet binary to its stop rule, ~5 s)")
+    ap.add_argument("--cli-only", action="store_true", help="print the cli_end_to_end record alone")
     ap.add_argument("--main-timeout", type=int, default=420,
                     help="N>1: seconds the communicator set-up + warm-up + timed sweeps may take before rank 0 prints "
                          "an error line and every rank exits")
@@ -588,6 +625,14 @@ def main():
     setup, path, pairs, n, k, data = _load_workload(args.workload)
     L = int(setup.nlinks)
     V = int(setup.validation_sorted.shape[0])
+
+    if args.cli_only:
+        eng = setup.engine(use_validation_stop=False, device=local_rank)
+        eng.sweep(args.warmup)
+        el = _timed(eng, eng, args.steps, None, torch)
+        print(json.dumps({"cli_end_to_end": cli_end_to_end(path, n, k, el / args.steps * 1e3)}), flush=True)
+        os.unlink(path)
+        return
 
     # N = 1: the plain engine (hipGraph replay).  N > 1: ONE chain, node-block sharded over the N ranks with
     # the RCCL exchanges inside the timed region -- strong scaling of the metric's own workload, whatever
@@ -763,6 +808,11 @@ def main():
                 out["config5"] = hbm_bound_record(local_rank, sweeps=5, workload=CONFIG5_WORKLOAD)
             except Exception as exc:
                 out["config5"] = {"error": repr(exc)[:200]}
+        if not multi and not args.no_cli and path and args.workload.startswith("astroph"):
+            try:
+                out["cli_end_to_end"] = cli_end_to_end(path, n, k, out["ms_per_step"])
+            except Exception as exc:
+                out["cli_end_to_end"] = {"error": repr(exc)[:200]}
         if not args.no_cpu_baseline and not multi:
             out["cpu_baseline"] = cpu_baseline(path, pairs, n, k, args.warmup, args.steps)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]

@@ -180,6 +180,26 @@ int svils_step(svils_handle *h, uint32_t nsteps);
 int svils_step_phase(svils_handle *h, svils_phase phase);
 int svils_step_window(svils_handle *h, uint32_t *begin, uint32_t *end);
 
+/* ---- pipelined reports --------------------------------------------------------------------------
+ * The reference's loop reports after every sweep under -link-sampling (rfreq = 1, src/main.cc:149-153): a likelihood
+ * row, max.txt, communities.txt (src/linksampling.cc:777-786).  Fetching that with svils_get_control / svils_get_rows /
+ * svils_get_communities costs a stream synchronisation per report, i.e. per sweep.  A REPORT is the same data as a
+ * snapshot taken in stream order: svils_report_enqueue() puts, behind the sweeps enqueued so far, one launch that packs
+ * the control block, the likelihood rows [row_first, row_first + row_count) and (with_communities != 0) the community
+ * bitmask of the last tagging sweep into a staging slot; a copy stream takes the slot to pinned host memory while the
+ * compute stream goes on with the next sweeps.  The host collects it later (svils_report_fetch blocks until it has
+ * landed; svils_report_ready does not block).  The caller names the rows because it knows them without asking the
+ * device: every sweep whose _iter becomes a multiple of reportfreq records one (fewer only after the stop rule fired --
+ * the fetched control block says how many really exist).  At most SVILS_REPORT_SLOTS reports may be outstanding, each
+ * of at most SVILS_REPORT_MAX_ROWS rows.  Whole-graph handles only (a sharded run gathers its tags collectively). */
+#define SVILS_REPORT_SLOTS 4
+#define SVILS_REPORT_MAX_ROWS 64
+int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count, int with_communities, int *ticket);
+int svils_report_ready(svils_handle *h, int ticket);     /* 1 = landed, 0 = not yet, < 0 = error */
+/* ctrl: as svils_get_control at the snapshot; rows: [row_count][10], *nrows = how many of them exist
+ * (min(ctrl.rows, row_first + row_count) - row_first); member: [n][k] as svils_get_communities, or NULL.  Frees the slot. */
+int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows, uint8_t *member);
+
 /* rows recorded by the in-loop validation_likelihood(): copies rows
  * [first, first+count) (as numbered since create) into out[count][10]. */
 int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows);

@@ -29,6 +29,7 @@ EXPORTS = (
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
     "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
     "svils_comm_allgather_host", "svils_step_sharded", "svils_step_ksharded", "svils_comm_query",
+    "svils_report_enqueue", "svils_report_ready", "svils_report_fetch",
 )
 
 
@@ -127,6 +128,9 @@ def load():
     L.svils_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t]
     L.svils_step_sharded.argtypes = [vp, C.c_uint32]
     L.svils_comm_query.argtypes = [vp, C.POINTER(CommInfo)]
+    L.svils_report_enqueue.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
+    L.svils_report_ready.argtypes = [vp, C.c_int]
+    L.svils_report_fetch.argtypes = [vp, C.c_int, C.POINTER(Control), vp, C.POINTER(C.c_uint32), vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -346,6 +350,27 @@ class Engine:
         out = np.zeros(3, dtype=np.uint64)
         _chk(load().svils_get_timed_links(self._h, out.ctypes.data))
         return out
+
+    # ---- pipelined reports ----
+    def report_enqueue(self, row_first, row_count, with_communities=True):
+        t = C.c_int()
+        _chk(load().svils_report_enqueue(self._h, row_first, row_count, int(with_communities), C.byref(t)))
+        return t.value
+
+    def report_ready(self, ticket):
+        rc = load().svils_report_ready(self._h, ticket)
+        if rc < 0:
+            _chk(rc)
+        return bool(rc)
+
+    def report_fetch(self, ticket, row_count, with_communities=True):
+        """-> (Control, rows [have][10], member [n][k] or None)"""
+        c, nr = Control(), C.c_uint32()
+        rows = np.zeros((max(row_count, 1), 10), dtype=np.float64)
+        m = np.zeros((self.n, self.k), dtype=np.uint8) if with_communities else None
+        _chk(load().svils_report_fetch(self._h, ticket, C.byref(c), rows.ctypes.data, C.byref(nr),
+                                       m.ctypes.data if with_communities else None))
+        return c, rows[:nr.value], m
 
     # ---- native multi-GPU driver (RCCL inside the library) ----
     def comm_init(self, comm_id, rank, world):

@@ -40,7 +40,7 @@ def _glob(d, exts):
 def build_svils(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     out = os.path.join(LIBDIR, "libsvils.so")
-    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip", "svils_report.hip")]
     deps = srcs + _glob(CSRC, (".h",)) + [os.path.join(ROOT, "include", "svils.h")]
     if force or _stale(out, deps):
         _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out] + srcs)
@@ -50,7 +50,7 @@ def build_svils(force=False):
 def build_stamps():
     """libsvils_stamps.so: the same kernels with wall-clock stamps at phase boundaries (tools/stamps.py)"""
     out = os.path.join(LIBDIR, "libsvils_stamps.so")
-    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip", "svils_report.hip")]
     _run([HIPCC] + HIP_FLAGS + ["-DSVILS_STAMPS", "-shared", "-o", out] + srcs)
     return out
 

@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>   // types only: librccl is dlopen()ed on first use
 
 #include "svils_internal.h"
+#include "svils_report.h"
 
 using namespace svils;
 
@@ -90,6 +91,16 @@ struct svils_handle {
   hipGraphExec_t gexecP[kGraphMaxLog + 1] = {};        // [i]: 2^i sweeps (i = 0 and 3 stay null: gexec1, gexecN)
   bool graphs_ok = true;                               // false after a capture failure: stay eager
   std::vector<void *> allocs;
+  // pipelined reports (svils_report_enqueue): staging slots, a copy stream, per-slot events
+  struct ReportSlot {
+    unsigned char *dev = nullptr, *host = nullptr;
+    hipEvent_t packed = nullptr, landed = nullptr;
+    bool busy = false, with_member = false;
+    uint32_t row_first = 0, row_count = 0;
+  };
+  ReportSlot rslot[SVILS_REPORT_SLOTS];
+  ReportLayout rlay{};
+  hipStream_t copy_stream = nullptr;
   double *row_scratch = nullptr;  // device [10]
   // timing
   uint32_t tmask = 0;
@@ -1057,6 +1068,14 @@ int svils_destroy(svils_handle *h) {
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
   for (hipEvent_t e : h->ev_chunk) (void)hipEventDestroy(e);
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  for (auto &rs : h->rslot) {
+    if (rs.dev) (void)hipFree(rs.dev);
+    if (rs.host) (void)hipHostFree(rs.host);
+    if (rs.packed) (void)hipEventDestroy(rs.packed);
+    if (rs.landed) (void)hipEventDestroy(rs.landed);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1749,6 +1768,97 @@ int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows
     const uint32_t run = std::min(count - done, h->d.rows_cap - slot);
     HIPCHK(hipMemcpy(rows + (size_t)done * 10, h->d.rows + (size_t)slot * 10, (size_t)run * 10 * sizeof(double), hipMemcpyDeviceToHost));
     done += run;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- pipelined reports (include/svils.h)
+namespace {
+void ctrl_out(const DevCtrl &c, svils_control *out) {
+  out->iter = c.iter; out->annealing = c.annealing; out->write_comm = c.write_comm; out->nh = c.nh;
+  out->prev_h = c.prev_h; out->max_h = c.max_h; out->stopped = c.stopped; out->why = c.why;
+  out->sweeps_done = c.sweeps_done; out->rows = c.rows;
+  out->links_dense = c.links_dense; out->links_sparse = c.links_sparse; out->links_shortcut = c.links_shortcut;
+}
+}  // namespace
+
+int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count, int with_communities, int *ticket) {
+  if (!h || !ticket) return fail(SVILS_ERR_ARG, "svils_report_enqueue: null argument");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_report_enqueue: set graph and state first");
+  const Geometry &g = h->geo;
+  if (h->d.ksh || g.node_begin != 0 || g.node_end != g.n)
+    return fail(SVILS_ERR_ARG, "svils_report_enqueue: whole-graph handles only (a sharded run gathers its tags collectively)");
+  if (row_count > SVILS_REPORT_MAX_ROWS) return fail(SVILS_ERR_ARG, "svils_report_enqueue: at most %d rows per report", SVILS_REPORT_MAX_ROWS);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t nwords = (size_t)g.n * g.kw;
+  if (!h->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    h->rlay.off_rows = 128;   // the control block in front (sizeof(DevCtrl) <= 128)
+    static_assert(sizeof(DevCtrl) <= 128, "report layout");
+    h->rlay.off_member = h->rlay.off_rows + (size_t)SVILS_REPORT_MAX_ROWS * 10 * sizeof(double);
+    h->rlay.bytes = h->rlay.off_member + nwords * sizeof(uint64_t);
+  }
+  int t = -1;
+  for (int i = 0; i < SVILS_REPORT_SLOTS; ++i)
+    if (!h->rslot[i].busy) { t = i; break; }
+  if (t < 0) return fail(SVILS_ERR_ARG, "svils_report_enqueue: %d reports outstanding, fetch one first", SVILS_REPORT_SLOTS);
+  svils_handle::ReportSlot &rs = h->rslot[t];
+  if (!rs.dev) {
+    HIPCHK(hipMalloc((void **)&rs.dev, h->rlay.bytes));
+    HIPCHK(hipHostMalloc((void **)&rs.host, h->rlay.bytes, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&rs.packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&rs.landed, hipEventDisableTiming));
+  }
+  launch_report_pack(h->d.ctrl, sizeof(DevCtrl), h->d.rows, h->d.rows_cap, row_first, row_count,
+                     with_communities ? h->d.member : nullptr, with_communities ? nwords : 0, rs.dev, h->rlay, h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(rs.packed, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->copy_stream, rs.packed, 0));
+  HIPCHK(hipMemcpyAsync(rs.host, rs.dev, with_communities ? h->rlay.bytes : h->rlay.off_member, hipMemcpyDeviceToHost, h->copy_stream));
+  HIPCHK(hipEventRecord(rs.landed, h->copy_stream));
+  rs.busy = true;
+  rs.with_member = with_communities != 0;
+  rs.row_first = row_first;
+  rs.row_count = row_count;
+  *ticket = t;
+  return 0;
+}
+
+int svils_report_ready(svils_handle *h, int ticket) {
+  if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_ready: bad ticket");
+  const hipError_t e = hipEventQuery(h->rslot[ticket].landed);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return fail(SVILS_ERR_DEVICE, "svils_report_ready: %s", hipGetErrorString(e));
+}
+
+int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows, uint8_t *member) {
+  if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_fetch: bad ticket");
+  svils_handle::ReportSlot &rs = h->rslot[ticket];
+  if (member && !rs.with_member) return fail(SVILS_ERR_ARG, "svils_report_fetch: this report was enqueued without communities");
+  HIPCHK(hipEventSynchronize(rs.landed));
+  rs.busy = false;
+  DevCtrl c;
+  memcpy(&c, rs.host, sizeof c);
+  if (c.fault) return fault_error(c.fault);
+  if (ctrl) ctrl_out(c, ctrl);
+  const uint32_t have = c.rows > rs.row_first ? std::min(c.rows - rs.row_first, rs.row_count) : 0u;
+  if (nrows) *nrows = have;
+  if (rows && have) memcpy(rows, rs.host + h->rlay.off_rows, (size_t)have * 10 * sizeof(double));
+  if (member) {
+    const Geometry &g = h->geo;
+    const uint64_t *bits = (const uint64_t *)(rs.host + h->rlay.off_member);
+    memset(member, 0, (size_t)g.n * g.K);
+    for (uint32_t p = 0; p < g.n; ++p)
+      for (int v = 0; v < g.V; ++v) {
+        uint64_t b = bits[(size_t)p * g.kw + v];
+        while (b) {
+          const int lw = __builtin_ctzll(b);
+          b &= b - 1;
+          const uint32_t k = kmap_host(g.W, g.V, lw, v);
+          if (k < g.K) member[(size_t)p * g.K + k] = 1;
+        }
+      }
   }
   return 0;
 }

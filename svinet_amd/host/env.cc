@@ -65,7 +65,7 @@ Env::Env(const Args &a)
       datfname(a.datfname), label(a.label), gpus(a.gpus), rank(a.rank), kshard(a.kshard), sharded((a.sharded || a.gpus > 1) && !a.kshard), comm_rfd(a.comm_rfd), comm_wfds(a.comm_wfds),
       batch_mode(a.batch), link_sampling(a.link_sampling), strid(a.strid),
       terminate(0), total_pairs(0), ones_prob(0), zeros_prob(1),
-      device(a.device), sweep_batch(a.sweep_batch ? a.sweep_batch : 1), write_files(a.write_files),
+      device(a.device), sweep_batch(a.sweep_batch), write_files(a.write_files),
       minibatch(a.minibatch), tau0(a.tau0), kappa(a.kappa), nodetau0(a.nodetau0), nodekappa(a.nodekappa),
       sparse_after(a.sparse_after) {
   if (!write_files) {

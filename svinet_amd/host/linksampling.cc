@@ -28,6 +28,11 @@ FILE *open_or_die(const std::string &path, const char *what) {
   }
   return f;
 }
+double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 }  // namespace
 
 // LinkSampling::LinkSampling, src/linksampling.cc:5-155
@@ -35,6 +40,7 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     : env_(env), network_(network), n_(env.n), k_(env.k),
       rng_(env.seed ? (unsigned long)env.seed : 0ul),   // :70-75
       start_time_(time(0)) {
+  const double t_ctor = now_s();
   // `_n * (_n - 1) / 2` in 32-bit unsigned arithmetic (:36-37, quirk Q5)
   total_pairs_ = (double)((uint32_t)(n_ * (n_ - 1u)) / 2u);
   Env::plog("inference n", n_);
@@ -138,6 +144,13 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     }
   }
   start_time_ = time(0);
+  timing_.ctor_s = now_s() - t_ctor;
+}
+
+bool LinkSampling::pipelined_reports() const {
+  if (env_.sharded || env_.kshard || env_.minibatch || env_.gpus > 1) return false;
+  const char *e = getenv("SVINET_SYNC_REPORTS");
+  return !(e && atoi(e) != 0);
 }
 
 LinkSampling::~LinkSampling() {
@@ -535,38 +548,16 @@ void LinkSampling::log_communities() {                     // :839-852, :882-917
     member_.assign((size_t)n_ * k_, 0);
     if (svils_get_communities(h_, member_.data())) die_svils("svils_get_communities");
   }
-  if (!dev_of_.empty()) {
-    std::vector<uint8_t> t((size_t)n_ * k_);
-    for (uint32_t i = 0; i < n_; ++i)
-      std::copy(&member_[(size_t)dev_of_[i] * k_], &member_[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
-    member_.swap(t);
-  }
-  FILE *f = open_or_die(Env::file_str("/communities.txt"), "communities");
-  const std::vector<uint32_t> &s2i = network_.seq2id();
-  std::vector<uint32_t> ids;
-  Cover found;
-  for (uint32_t c = 0; c < k_; ++c) {
-    ids.clear();
-    for (uint32_t p = 0; p < n_; ++p)
-      if (member_[(size_t)p * k_ + c]) ids.push_back(s2i[p]);
-    if (ids.empty()) continue;            // empty communities have no map entry => no line
-    std::sort(ids.begin(), ids.end());
-    for (uint32_t id : ids) fprintf(f, "%d ", id);
-    fprintf(f, "\n");
-    if (env_.nmi) found.push_back(ids);
-  }
-  fclose(f);
-  if (env_.nmi && !ground_truth_.empty()) {
-    // the reference runs `/usr/local/bin/mutual ground_truth.txt communities.txt >> mutual.txt` here (:843-851)
-    FILE *mf = fopen(Env::file_str("/mutual.txt").c_str(), "a");
-    if (mf) {
-      fprintf(mf, "mutual3:\t%g\n", lfk_nmi(ground_truth_, found));
-      fclose(mf);
-    }
-  }
+  write_communities_file();
 }
 
 void LinkSampling::do_on_stop() {                          // src/linksampling.cc:792-802
+  const double t0 = now_s();
+  do_on_stop_impl();
+  timing_.final_files_s += now_s() - t0;
+}
+
+void LinkSampling::do_on_stop_impl() {
   // -gpus N: every rank takes part in the gather of the community bitmasks, rank 0 writes
   if (env_.kshard) {
     fetch_communities_ksharded();
@@ -591,14 +582,7 @@ bool LinkSampling::fetch_and_log_rows() {
   if (c.rows > rows_logged_) {
     std::vector<double> rows((size_t)(c.rows - rows_logged_) * 10);
     if (svils_get_rows(h_, rows_logged_, c.rows - rows_logged_, rows.data())) die_svils("svils_get_rows");
-    if (vf_)
-      for (uint32_t i = 0; i < c.rows - rows_logged_; ++i) {
-        write_validation_row(&rows[(size_t)i * 10], vf_);
-        // test_likelihood over the empty test map prints 0/0 ratios (:1147-1182)
-        fprintf(tf_, "%d\t%d\t-nan\t0\t-nan\t0\t-nan\t0\t-nan\t-nan\t-nan\n", (int)rows[(size_t)i * 10], duration());
-        fflush(tf_);
-      }
-    if (vf_) write_max(&rows[(size_t)(c.rows - rows_logged_ - 1) * 10], c.why, c.max_h);
+    log_rows(rows.data(), c.rows - rows_logged_, c.why, c.max_h);
     rows_logged_ = c.rows;
   }
   return reported;
@@ -612,7 +596,10 @@ int LinkSampling::infer() {
     fprintf(stderr, "error: LinkSampling::infer() without a device (attach_device=false)\n");
     exit(-1);
   }
+  const double t0 = now_s();
   send_graph();
+  if (svils_synchronize(h_)) die_svils("svils_synchronize");
+  timing_.graph_upload_s = now_s() - t0;
   return sweep_loop();
 }
 
@@ -637,12 +624,163 @@ void LinkSampling::send_graph() {
   }
 }
 
-int LinkSampling::sweep_loop() {
+// communities.txt of a report (src/linksampling.cc:839-852,882-917) from tags already on the host
+void LinkSampling::write_communities_file() {
+  if (!dev_of_.empty()) {
+    std::vector<uint8_t> t((size_t)n_ * k_);
+    for (uint32_t i = 0; i < n_; ++i)
+      std::copy(&member_[(size_t)dev_of_[i] * k_], &member_[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
+    member_.swap(t);
+  }
+  const std::vector<uint32_t> &s2i = network_.seq2id();
+  // one pass over the tags: members of every community in node order, then sorted by external id
+  std::vector<std::vector<uint32_t>> ids(k_);
+  for (uint32_t p = 0; p < n_; ++p) {
+    const uint8_t *m = &member_[(size_t)p * k_];
+    for (uint32_t c = 0; c < k_; ++c)
+      if (m[c]) ids[c].push_back(s2i[p]);
+  }
+  std::string out;
+  Cover found;
+  char buf[16];
+  for (uint32_t c = 0; c < k_; ++c) {
+    if (ids[c].empty()) continue;            // empty communities have no map entry => no line
+    std::sort(ids[c].begin(), ids[c].end());
+    for (uint32_t id : ids[c]) {             // "%d " per member
+      char *e = buf + sizeof buf;
+      char *b = e;
+      *--b = ' ';
+      uint32_t v = id;
+      do { *--b = (char)('0' + v % 10); v /= 10; } while (v);
+      out.append(b, (size_t)(e - b));
+    }
+    out.push_back('\n');
+    if (env_.nmi) found.push_back(ids[c]);
+  }
+  FILE *f = open_or_die(Env::file_str("/communities.txt"), "communities");
+  fwrite(out.data(), 1, out.size(), f);
+  fclose(f);
+  if (env_.nmi && !ground_truth_.empty()) {
+    // the reference runs `/usr/local/bin/mutual ground_truth.txt communities.txt >> mutual.txt` here (:843-851)
+    FILE *mf = fopen(Env::file_str("/mutual.txt").c_str(), "a");
+    if (mf) {
+      fprintf(mf, "mutual3:\t%g\n", lfk_nmi(ground_truth_, found));
+      fclose(mf);
+    }
+  }
+}
+
+void LinkSampling::log_rows(const double *rows, uint32_t count, int why, double max_h) {
+  if (!vf_ || !count) return;
+  for (uint32_t i = 0; i < count; ++i) {
+    write_validation_row(&rows[(size_t)i * 10], vf_);
+    // test_likelihood over the empty test map prints 0/0 ratios (:1147-1182)
+    fprintf(tf_, "%d\t%d\t-nan\t0\t-nan\t0\t-nan\t0\t-nan\t-nan\t-nan\n", (int)rows[(size_t)i * 10], duration());
+    fflush(tf_);
+  }
+  write_max(&rows[(size_t)(count - 1) * 10], why, max_h);
+}
+
+// The loop of infer() with the report block of every sweep (:777-786) taken OFF the device's critical path: the host
+// enqueues chunks of sweeps (hipGraph replay inside the library) each followed by a report snapshot
+// (svils_report_enqueue), keeps up to three chunks in flight and writes the files of report t while the device is
+// already past it.  What reaches the files is what the synchronous loop writes: every likelihood row in order,
+// max.txt, communities.txt -- except that a communities.txt which the NEXT landed report would overwrite at once is
+// not written (the file is rewritten from scratch by every report; only its latest content is observable), and the
+// final files always come from do_on_stop().  -sweep-batch B fixes the chunk at B sweeps; the default (0) starts at
+// one sweep per report and doubles the chunk up to 16 while the host is the slower side.
+int LinkSampling::sweep_loop_pipelined() {
   const uint64_t nlinks = links_.size() / 2;
   svils_control c;
   if (svils_get_control(h_, &c)) die_svils("svils_get_control");
+  if (env_.max_iterations == 1 && !c.write_comm) {              // :581-582
+    c.write_comm = 1;
+    if (svils_set_control(h_, &c)) die_svils("svils_set_control");
+  }
+  struct Flight { int ticket; uint32_t row_count; bool with_comm; };
+  std::vector<Flight> flight;             // oldest first
+  uint32_t issued_iter = c.iter;          // _iter after the sweeps enqueued so far (if nothing stops them)
+  uint32_t rows_issued = rows_logged_;
+  uint32_t chunk = env_.sweep_batch ? env_.sweep_batch : 1;
+  const uint32_t rf = std::max<uint32_t>(1, env_.reportfreq);
+  const bool always_report = env_.accuracy || val_sorted_.empty();
+  std::vector<double> rows((size_t)SVILS_REPORT_MAX_ROWS * 10);
+  bool quit_max = false;
+  timing_.pipelined = true;
+  timing_.sweeps_t0 = now_s();
+  for (;;) {
+    // ---- keep the device busy: up to SVILS_REPORT_SLOTS - 1 chunks ahead of the host
+    while (!quit_max && flight.size() + 1 < (size_t)SVILS_REPORT_SLOTS) {
+      uint32_t batch = std::min<uint32_t>(chunk, (uint32_t)SVILS_REPORT_MAX_ROWS * rf);
+      if (env_.max_iterations) {
+        if (issued_iter > env_.max_iterations) { quit_max = true; break; }      // :573-579, seen at issue time
+        batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - issued_iter);
+      }
+      printf("\riteration %d: processing %d links", issued_iter, (int)nlinks);
+      fflush(stdout);
+      if (svils_sweep(h_, batch)) die_svils("svils_sweep");
+      const uint32_t new_rows = (issued_iter + batch) / rf - issued_iter / rf;   // multiples of rf in (iter, iter + batch]
+      issued_iter += batch;
+      Flight f{-1, new_rows, new_rows > 0 || always_report};
+      if (svils_report_enqueue(h_, rows_issued, new_rows, f.with_comm ? 1 : 0, &f.ticket)) die_svils("svils_report_enqueue");
+      rows_issued += new_rows;
+      flight.push_back(f);
+      timing_.chunks++;
+      if (!env_.sweep_batch && !flight.empty() && chunk < 16 && svils_report_ready(h_, flight.front().ticket) == 1 && flight.size() > 1)
+        chunk *= 2;     // the device finished a chunk before the host came back for it: the host is the slower side
+    }
+    if (flight.empty()) break;              // everything issued and reported: -max-iterations reached
+    // ---- the oldest report: blocks until it has landed
+    const Flight f = flight.front();
+    flight.erase(flight.begin());
+    uint32_t have = 0;
+    // is a newer report already on the host?  then this one's communities.txt would be overwritten at once
+    // (-nmi scores every report's communities -- one mutual.txt line per report, :843-851 -- so nothing is skipped then)
+    const bool superseded = !env_.nmi && !flight.empty() && flight.front().with_comm && svils_report_ready(h_, flight.front().ticket) == 1;
+    const bool want_comm = f.with_comm && env_.write_files && !superseded;
+    if (want_comm) member_.assign((size_t)n_ * k_, 0);
+    if (svils_report_fetch(h_, f.ticket, &c, rows.data(), &have, want_comm ? member_.data() : nullptr)) die_svils("svils_report_fetch");
+    const double t0 = now_s();
+    log_rows(rows.data(), have, c.why, c.max_h);
+    rows_logged_ += have;
+    if (!c.stopped && want_comm) { write_communities_file(); timing_.communities_written++; }
+    timing_.reports++;
+    timing_.report_host_s += now_s() - t0;
+    if (c.stopped) {                                              // :1044-1048; the sweeps behind the stop were no-ops
+      for (const Flight &g : flight) {
+        svils_control cc;
+        uint32_t hv = 0;
+        if (svils_report_fetch(h_, g.ticket, &cc, rows.data(), &hv, nullptr)) die_svils("svils_report_fetch");
+      }
+      timing_.sweeps_t1 = now_s();
+      timing_.sweeps = c.sweeps_done;
+      do_on_stop();
+      return 1;
+    }
+    if (env_.terminate) {                                         // :763-766 (SIGTERM: save the model and go on)
+      do_on_stop();                                               // synchronises; the reports in flight stay valid
+      env_.terminate = 0;
+    }
+  }
+  timing_.sweeps_t1 = now_s();
+  timing_.sweeps = c.sweeps_done;
+  printf("+ Quitting: reached max iterations.\n");
+  Env::plog("maxiterations reached", true);
+  env_.terminate = 1;
+  do_on_stop();
+  return 0;
+}
+
+int LinkSampling::sweep_loop() {
+  if (pipelined_reports()) return sweep_loop_pipelined();
+  const uint64_t nlinks = links_.size() / 2;
+  svils_control c;
+  if (svils_get_control(h_, &c)) die_svils("svils_get_control");
+  timing_.sweeps_t0 = now_s();
   for (;;) {
     if (env_.max_iterations && c.iter > env_.max_iterations) {     // :573-579
+      timing_.sweeps_t1 = now_s();
+      timing_.sweeps = c.sweeps_done;
       printf("+ Quitting: reached max iterations.\n");
       Env::plog("maxiterations reached", true);
       env_.terminate = 1;
@@ -653,7 +791,7 @@ int LinkSampling::sweep_loop() {
       c.write_comm = 1;
       if (svils_set_control(h_, &c)) die_svils("svils_set_control");
     }
-    uint32_t batch = env_.sweep_batch;
+    uint32_t batch = env_.sweep_batch ? env_.sweep_batch : 1;
     if (env_.max_iterations) batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - c.iter);
     printf("\riteration %d: processing %d links", c.iter, (int)nlinks);
     fflush(stdout);
@@ -677,14 +815,20 @@ int LinkSampling::sweep_loop() {
       else if (env_.sharded && svils_gather_communities(h_)) die_svils("svils_gather_communities");
       if (env_.write_files) log_communities();
     }
+    timing_.reports += reported ? 1 : 0;
     if (c.stopped) {                                              // :1044-1048
+      timing_.sweeps_t1 = now_s();
+      timing_.sweeps = c.sweeps_done;
       do_on_stop();
       return 1;
     }
     // :763-766 (SIGTERM: save the model and go on).  -gpus N: the signal reaches the ranks at different sweeps, and
     // do_on_stop() is collective there, so the ranks agree first: one byte per rank, gathered at every poll
+    // (a blocking H2D + all-gather + D2H + sync: asked for at every 16th poll, not at every sweep -- a signal waits
+    // for at most 16 polls, the sweeps pay nothing in between; the poll counter runs in step on all ranks)
     bool term = env_.terminate != 0;
-    if (env_.gpus > 1) {
+    if (env_.gpus > 1 && (++term_polls_ & 15u) != 0) term = false;
+    else if (env_.gpus > 1) {
       const unsigned char mine = term ? 1 : 0;
       std::vector<unsigned char> all((size_t)env_.gpus, 0);
       if (svils_comm_allgather_host(h_, &mine, all.data(), 1)) die_svils("svils_comm_allgather_host");

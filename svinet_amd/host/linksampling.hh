@@ -66,7 +66,13 @@ class LinkSampling {
   void attach();
   void write_validation_row(const double *row, FILE *f) const;
   void write_max(const double *row, int why, double max_h) const;
+  void do_on_stop_impl();
   void log_communities();
+  void write_communities_file();               // communities.txt (+ mutual.txt) from member_
+  void log_rows(const double *rows, uint32_t count, int why, double max_h);   // validation.txt, test.txt, max.txt
+  int sweep_loop_pipelined();                  // reports taken off the device's critical path (svils_report_*)
+  // one whole-graph engine driving full sweeps: the pipelined loop; SVINET_SYNC_REPORTS=1 keeps the per-batch synchronous one
+  bool pipelined_reports() const;
   void send_graph();                           // training links to the device (once)
   int sweep_loop();                            // the body of infer()
   void fetch_state_ksharded(std::vector<double> &g, std::vector<double> &l);   // -kshard: merged gamma / lambda (collective)
@@ -98,6 +104,20 @@ class LinkSampling {
   bool have_row0_ = false;
   time_t start_time_;
   FILE *vf_ = nullptr, *tf_ = nullptr;
+  uint32_t term_polls_ = 0;
+
+ public:
+  // where the wall time of a run went (SVINET_TIMING_FILE=path makes the CLI write it as JSON; bench.py's
+  // cli_end_to_end record)
+  struct Timing {
+    double ctor_s = 0, graph_upload_s = 0, sweeps_t0 = 0, sweeps_t1 = 0, report_host_s = 0, final_files_s = 0;
+    uint32_t sweeps = 0, chunks = 0, reports = 0, communities_written = 0;
+    bool pipelined = false;
+  };
+  const Timing &timing() const { return timing_; }
+
+ private:
+  Timing timing_;
 };
 
 }  // namespace svinet

@@ -11,6 +11,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -75,7 +76,7 @@ static void usage() {
           "\t\t\tper sweep four all-reduces of O(links) doubles instead of an all-gather of the rows) -- the\n"
           "\t\t\tlayout for large K (-link-thresh < 0.5 adds two exchanges of one double per link: the arg-max tagging rule);\n"
           "\t\t\twith -minibatch <m> every GPU steps through the same windows of m nodes on its own columns\n\n"
-          "\t-sweep-batch <b>\tsweeps enqueued between host polls/file writes (default 1 = reference cadence)\n\n"
+          "\t-sweep-batch <b>\tsweeps per report chunk (default 0 = automatic: one sweep per report at first, doubling to 16\n\t\t\t\twhile the host is the slower side; reports are written while the device sweeps on)\n\n"
           "\t-sparse-after <i>\tthe active-set branch of the phi pass is used once the iteration count exceeds i\n"
           "\t\t\t(default 1000, the reference's constant)\n\n"
           "\t-minibatch <m>\tmini-batch mode of -link-sampling: one step = the links of m randomly chosen nodes,\n"
@@ -258,10 +259,13 @@ run:
   Env env(a);
   env_global = &env;
   Network network(env);
+  timespec t_read0, t_read1;
+  clock_gettime(CLOCK_MONOTONIC, &t_read0);
   if (network.read(a.datfname) < 0) {
     fprintf(stderr, "error reading %s; quitting\n", a.datfname.c_str());
     return -1;
   }
+  clock_gettime(CLOCK_MONOTONIC, &t_read1);
   env.n = network.n() - network.singles();   // src/main.cc:291
   if (network.ones() == 0 || env.n < 2) {
     fprintf(stderr, "error: no links read from %s; quitting\n", a.datfname.c_str());
@@ -274,6 +278,18 @@ run:
     exit(0);
   }
   LinkSampling ls(env, network);
-  ls.infer();
+  const int how = ls.infer();
+  if (const char *tf = getenv("SVINET_TIMING_FILE")) {   // where the wall time went (bench.py's cli_end_to_end record)
+    if (FILE *f = fopen(tf, "w")) {
+      const LinkSampling::Timing &t = ls.timing();
+      fprintf(f, "{\"read_s\": %.6f, \"ctor_s\": %.6f, \"graph_upload_s\": %.6f, \"sweeps_s\": %.6f, \"sweeps\": %u, \"chunks\": %u, "
+                 "\"reports\": %u, \"communities_written\": %u, \"report_host_s\": %.6f, \"final_files_s\": %.6f, \"pipelined\": %s, "
+                 "\"ended_by\": \"%s\"}\n",
+              (double)(t_read1.tv_sec - t_read0.tv_sec) + 1e-9 * (double)(t_read1.tv_nsec - t_read0.tv_nsec), t.ctor_s, t.graph_upload_s,
+              t.sweeps_t1 - t.sweeps_t0, t.sweeps, t.chunks, t.reports, t.communities_written, t.report_host_s, t.final_files_s,
+              t.pipelined ? "true" : "false", how == 1 ? "stop rule" : "max iterations");
+      fclose(f);
+    }
+  }
   exit(0);
 }

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 SVINET = os.path.join(ROOT, "svinet_amd", "bin", "svinet")
 
 
-def _run(args, cwd):
-    return subprocess.run([SVINET] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+def _run(args, cwd, env=None):
+    return subprocess.run([SVINET] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                          env=dict(os.environ, **(env or {})))
 
 
 def _cmp_numeric(path_a, path_b, skip, atol):
@@ -25,11 +26,21 @@ def _cmp_numeric(path_a, path_b, skip, atol):
     np.testing.assert_allclose(a[:, skip:], b[:, skip:], rtol=1e-5, atol=atol)
 
 
-@pytest.mark.parametrize("batch", [1, 7])
-def test_cli_max_iterations(graph_files, tmp_path, batch):
+@pytest.mark.parametrize("batch,sync", [(0, False), (1, False), (7, False), (1, True), (7, True)])
+def test_cli_max_iterations(graph_files, tmp_path, batch, sync):
+    """batch 0 = the default (automatic chunks); sync = SVINET_SYNC_REPORTS=1, the loop that synchronises at every
+    batch instead of collecting report snapshots while the device sweeps on -- the files are the same"""
+    tfile = tmp_path / "timing.json"
     r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop",
-              "-max-iterations", "20", "-sweep-batch", str(batch)], str(tmp_path))
+              "-max-iterations", "20"] + (["-sweep-batch", str(batch)] if batch else []), str(tmp_path),
+             env={"SVINET_SYNC_REPORTS": "1" if sync else "0", "SVINET_TIMING_FILE": str(tfile)})
     assert r.returncode == 0, r.stderr
+    import json
+    tm = json.loads(tfile.read_text())
+    assert tm["pipelined"] == (not sync) and tm["ended_by"] == "max iterations"
+    if not sync:
+        assert tm["sweeps"] == 21 and tm["reports"] == tm["chunks"] and tm["sweeps_s"] > 0
+        assert tm["chunks"] == (21 if batch == 1 else 3 if batch == 7 else tm["chunks"]) and 1 <= tm["communities_written"] <= tm["reports"]
     assert "+ Quitting: reached max iterations." in r.stdout
     d = tmp_path / "n1000-k28-mmsb-linksampling"
     ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False, max_iterations=20)

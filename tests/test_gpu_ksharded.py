@@ -39,6 +39,39 @@ def test_ksharded_virtual_ranks_equal_oracle(graph_files, graph, world, k, sweep
         assert np.array_equal(s.engine.aux(3), ref.active_comms)
 
 
+def test_ksharded_astroph_k200_four_shards_whole_trajectory(graph_files):
+    """BASELINE config 4 (ca-AstroPh, K = 200) on FOUR virtual K-shards of 50 columns over the reference's whole natural
+    run: annealing switch (sweep 24), shortcut regime, and the replicated stop rule firing on every shard at the
+    oracle's sweep (27)."""
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, init_virtual, sweep_virtual
+    path, n, k, world = graph_files["astroph"], 17903, 200, 4
+    setup = Setup(path, n, k)
+    shards = [KShard(setup, r, world, 0, use_validation_stop=True) for r in range(world)]
+    init_virtual(shards)
+    ref = O.LinkSampling(O.Network(path, n), k)
+    n_ref = 0
+    while True:
+        rc = ref.sweep()
+        n_ref += 1
+        if rc == 2:
+            break
+        assert n_ref < 200
+    sweep_virtual(shards, n_ref + 3)                   # the sweeps after the stop are no-ops on every shard
+    states = [s.engine.state() for s in shards]
+    g = np.concatenate([st[0] for st in states], 1)
+    lam = np.concatenate([st[1] for st in states], 0)
+    assert np.max(np.abs(g - ref.gamma) / np.abs(ref.gamma)) < 1e-9
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-9
+    want = ref.communities()
+    for s, st in zip(shards, states):
+        c = s.engine.control()
+        assert c.stopped == 1 and c.sweeps_done == n_ref and c.iter == ref.iter and bool(c.annealing) == ref.annealing
+        assert np.array_equal(st[2], ref.converged)
+        np.testing.assert_allclose(s.engine.rows()[:, 1:], np.asarray(ref.rows)[1:, 1:], rtol=1e-8, atol=1e-11)
+        assert np.array_equal(s.engine.communities(), want[:, s.k0:s.k1])
+
+
 @pytest.mark.parametrize("world,k,sweeps", [(2, 28, 40), (3, 100, 5)])
 def test_ksharded_processes_one_gpu(graph_files, tmp_path, world, k, sweeps):
     """svinet_amd/ksharded.py end to end in separate processes (one per rank, as on a multi-GPU node), all on

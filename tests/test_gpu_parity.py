@@ -130,6 +130,71 @@ def test_astroph(graph_files, k, sweeps):
     assert np.array_equal(eng.communities(), ref.communities())
 
 
+def test_astroph_k200_trajectory_through_anneal_switch_and_stop(graph_files):
+    """BASELINE config 4's shape (ca-AstroPh, K = 200: the row-per-wavefront kernels k_phi / k_finalize / k_s3 / k_tail
+    of svils_device.hip) over the reference's WHOLE natural run, not a few sweeps: the annealing switch (sweep 24 on
+    this input), ~28 000 shortcut links per sweep from sweep ~20 on, and the device-side stop rule firing on the same
+    sweep as the oracle's (27).  Then the same input with -no-stop for 45 sweeps (past the point where the run would
+    have stopped): state, per-sweep link-branch counts, likelihood rows and communities.
+    src/linksampling.cc:600-761,966-1050."""
+    net = O.Network(graph_files["astroph"], 17903)
+    ref = O.LinkSampling(net, 200)
+    eng = _engine_from_oracle(ref, net)
+    n_ref, switched_ref = 0, None
+    while True:
+        was = ref.annealing
+        rc = ref.sweep()
+        n_ref += 1
+        if was and not ref.annealing:
+            switched_ref = n_ref
+        if rc == 2:
+            break
+        assert n_ref < 200
+    assert switched_ref is not None and switched_ref < n_ref          # the run crosses the annealing switch before it stops
+    eng.sweep(n_ref + 5)                                              # sweeps after the stop are no-ops
+    c = eng.control()
+    assert c.stopped == 1 and c.sweeps_done == n_ref and c.iter == ref.iter and not c.annealing
+    _check_state(eng, ref, "astroph k=200 at its stop (sweep %d)" % n_ref)
+    np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+    assert np.array_equal(eng.communities(), ref.communities())
+    # -no-stop, 45 sweeps: per-sweep branch counts and the annealing flag sweep by sweep
+    ref2 = O.LinkSampling(net, 200, use_validation_stop=False)
+    eng2 = _engine_from_oracle(ref2, net, use_validation_stop=False)
+    counts, anneal = [], []
+    for _ in range(45):
+        ref2.sweep()
+        counts.append(ref2.link_counts())
+        anneal.append(ref2.annealing)
+    eng2.sweep(45)
+    st = eng2.sweep_stats(0, 45)
+    assert [tuple(int(x) for x in r[:3]) for r in st] == counts
+    assert max(cnt[2] for cnt in counts) > 20000                      # the shortcut regime was really entered
+    assert anneal[0] and not anneal[-1] and bool(eng2.control().annealing) == anneal[-1]
+    _check_state(eng2, ref2, "astroph k=200 after 45 sweeps")
+    np.testing.assert_allclose(eng2.rows()[:, 1:], ref2.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+    assert np.array_equal(eng2.communities(), ref2.communities())
+
+
+def test_stored_mean_indicators_stay_current_across_graph_replays(graph_files):
+    """K > 56 whole sweeps keep the mean indicators in DERIVED form (svils_internal.h: derive_m) and bring the stored
+    array up to date on demand.  The bookkeeping must also see sweeps that were REPLAYED from hipGraphs (svils_sweep of
+    >= 4 sweeps): read mphi, replay more sweeps, read it again -- and run a phase-split sweep, whose s3 pass reads the
+    stored rows, right after a replay.  src/linksampling.cc:526-545,731-746."""
+    from svinet_amd import _svils
+    net = O.Network(graph_files["lfr"], 1000)
+    ref = O.LinkSampling(net, 100, use_validation_stop=False)
+    eng = _engine_from_oracle(ref, net, use_validation_stop=False)
+    for rnd in range(3):
+        _run_both(eng, ref, 8)                  # round 0 captures the graphs, rounds 1 and 2 only replay them
+        np.testing.assert_allclose(eng.aux(2), ref.mphi, rtol=1e-9, atol=1e-300, err_msg="round %d" % rnd)
+    _run_both(eng, ref, 8)                      # a replay ...
+    for ph in (_svils.PHASE_A, _svils.PHASE_B, _svils.PHASE_EXPAND, _svils.PHASE_C, _svils.PHASE_D):
+        eng.sweep_phase(ph)                     # ... then a sweep split at its exchange points (stored mphi in s3)
+    ref.sweep()
+    _check_state(eng, ref, "phase-split sweep after a graph replay")
+    np.testing.assert_allclose(eng.aux(2), ref.mphi, rtol=1e-9, atol=1e-300)
+
+
 def test_sparse_path(graph_files):
     """_iter > 1000 switches on the active-set path (src/linksampling.cc:634-681).
     Jump there by setting _iter on both sides after a converged-ish prefix."""
