@@ -96,6 +96,19 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks);
  * [nv][3] = (p, q, y).  nv == 0 disables the likelihood/stop rule. */
 int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv);
 
+/* Test pairs of -load-test in std::map<Edge,bool> order (LinkSampling::load_test, src/linksampling.cc:1417-1450;
+ * test_likelihood, :1147-1182): [nt][3] = (p, q, y), y = network.y(p, q).  Every report that does not end the run
+ * (the stopping sweep leaves validation_likelihood through do_on_stop + exit, before test_likelihood is reached,
+ * :777-781) also records a TEST row with the columns of the validation row, under the same row number; fetch them
+ * with svils_get_test_rows or a report.  The caller has already taken the pairs out of the training links
+ * (edge_ok, src/linksampling.hh:296-305).  Sweeps of a handle with a test set run as four launches (the three-launch
+ * form of K <= 32 defers the stop rule to the next launch, too late to decide whether the test row exists).
+ * nt == 0 removes the set.  Not for K-sharded handles. */
+int svils_set_test(svils_handle *h, const uint32_t *pairs_y, uint64_t nt);
+/* out[count][10]: the test rows of reports [first, first + count) (numbered like the validation rows); a report that
+ * recorded none (the stopping sweep) reads as NaN.  Synchronises. */
+int svils_get_test_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows);
+
 /* gamma [n][k], lambda [k][2] after init_gamma2/init_lambda (or -load);
  * converged [n] or NULL (= all 0, as at the top of infer(), :559).
  * Computes Elogpi / Elogbeta (set_dir_exp, src/linksampling.hh:170-187). */
@@ -199,6 +212,10 @@ int svils_report_ready(svils_handle *h, int ticket);     /* 1 = landed, 0 = not 
 /* ctrl: as svils_get_control at the snapshot; rows: [row_count][10], *nrows = how many of them exist
  * (min(ctrl.rows, row_first + row_count) - row_first); member: [n][k] as svils_get_communities, or NULL.  Frees the slot. */
 int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows, uint8_t *member);
+/* the TEST rows of the same report (svils_set_test): test_rows [row_count][10]; call it BEFORE svils_report_fetch (which
+ * frees the slot); blocks until the report has landed.  *ntest = rows that exist: one per validation row, minus the one
+ * of the stopping sweep. */
+int svils_report_test_rows(svils_handle *h, int ticket, double *test_rows, uint32_t *ntest);
 
 /* rows recorded by the in-loop validation_likelihood(): copies rows
  * [first, first+count) (as numbered since create) into out[count][10]. */

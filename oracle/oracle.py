@@ -29,7 +29,9 @@ class _Config(C.Structure):
                 ("reportfreq", C.c_uint32), ("max_iterations", C.c_uint32),
                 ("use_validation_stop", C.c_int), ("skip_init", C.c_int), ("accuracy", C.c_int),
                 ("eta_override0", C.c_double), ("eta_override1", C.c_double), ("train_on_heldout", C.c_int),
-                ("sparse_after_iter", C.c_int32)]
+                ("sparse_after_iter", C.c_int32),
+                ("test_pairs", C.c_void_p), ("ntest", C.c_uint32),
+                ("init_comm_ptr", C.c_void_p), ("init_comm_nodes", C.c_void_p), ("ninit_comm", C.c_uint32)]
 
 
 _lib = None
@@ -99,13 +101,13 @@ def lib():
     sig("orc_ls_free", None, vp)
     sig("orc_ls_sweep", C.c_int, vp)
     sig("orc_ls_set_skip_validation", None, vp, C.c_int)
-    for nm in ("n", "k", "nlinks", "nvalidation", "iter", "nrows"):
+    for nm in ("n", "k", "nlinks", "nvalidation", "iter", "nrows", "ntest", "ntest_rows"):
         sig("orc_ls_" + nm, u32, vp)
     sig("orc_ls_links", P(u32), vp)
     sig("orc_ls_training_links", P(dbl), vp)
-    for nm in ("gamma", "lambda", "elogpi", "elogbeta", "mphi", "fmap", "rows"):
+    for nm in ("gamma", "lambda", "elogpi", "elogbeta", "mphi", "fmap", "rows", "test_rows"):
         sig("orc_ls_" + nm, P(dbl), vp)
-    for nm in ("converged", "active_comms", "validation_accept", "validation_sorted"):
+    for nm in ("converged", "active_comms", "validation_accept", "validation_sorted", "test_sorted"):
         sig("orc_ls_" + nm, P(u32), vp)
     sig("orc_ls_set_iter", None, vp, u32)
     sig("orc_ls_annealing", C.c_int, vp)
@@ -195,7 +197,10 @@ class LinkSampling:
 
     def __init__(self, net, k, seed=0, heldout_ratio=0.01, link_thresh=0.5, lt_min_deg=0,
                  eta_type="uniform", reportfreq=1, max_iterations=0, use_validation_stop=True,
-                 skip_init=False, accuracy=False, eta_override=None, train_on_heldout=False, sparse_after_iter=1000):
+                 skip_init=False, accuracy=False, eta_override=None, train_on_heldout=False, sparse_after_iter=1000,
+                 test_pairs=None, init_communities=None):
+        """test_pairs: [T][2] SEQUENCE ids as -load-test maps them (src/linksampling.cc:1417-1450);
+        init_communities: list of lists of sequence ids, one per line of the -init-communities file"""
         L = lib()
         cfg = _Config()
         L.orc_config_default(C.byref(cfg), k)
@@ -213,6 +218,13 @@ class LinkSampling:
             cfg.eta_override0, cfg.eta_override1 = eta_override
         cfg.train_on_heldout = int(train_on_heldout)
         cfg.sparse_after_iter = int(sparse_after_iter)
+        if test_pairs is not None:
+            self._tp = np.ascontiguousarray(test_pairs, dtype=np.uint32).reshape(-1, 2)
+            cfg.test_pairs, cfg.ntest = self._tp.ctypes.data, self._tp.shape[0]
+        if init_communities is not None:
+            self._icp = np.concatenate([[0], np.cumsum([len(c) for c in init_communities])]).astype(np.uint32)
+            self._icn = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in init_communities] or [np.zeros(0, np.uint32)]))
+            cfg.init_comm_ptr, cfg.init_comm_nodes, cfg.ninit_comm = self._icp.ctypes.data, self._icn.ctypes.data, len(init_communities)
         self.net = net
         self._h = L.orc_ls_create(net._h, C.byref(cfg))
         self.n = L.orc_ls_n(self._h)
@@ -301,6 +313,16 @@ class LinkSampling:
     def rows(self):
         r = lib().orc_ls_nrows(self._h)
         return _arr(lib().orc_ls_rows(self._h), (r, 10), np.float64).copy()
+
+    @property
+    def test_sorted(self):
+        t = lib().orc_ls_ntest(self._h)
+        return _arr(lib().orc_ls_test_sorted(self._h), (t, 3), np.uint32).copy()
+
+    @property
+    def test_rows(self):
+        r = lib().orc_ls_ntest_rows(self._h)
+        return _arr(lib().orc_ls_test_rows(self._h), (r, 10), np.float64).copy()
 
     @property
     def iter(self):

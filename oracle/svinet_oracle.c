@@ -285,6 +285,12 @@ struct orc_ls {
 
   double *rows;
   uint32_t nrows, rows_cap;
+
+  /* -load-test: the test map (distinct pairs, ordered, std::map order) and its likelihood rows */
+  uint32_t ntest;
+  uint32_t *test_sorted; /* [ntest][3] a,b,y */
+  double *trows;
+  uint32_t ntrows, trows_cap;
 };
 
 void orc_config_default(orc_config *c, uint32_t k) {
@@ -323,7 +329,7 @@ static void vset_add(orc_ls *m, uint32_t a, uint32_t b) {
   m->vused[h] = 1; m->vkeys[h] = key;
 }
 
-/* LinkSampling::edge_ok, src/linksampling.hh:296-326 (test map always empty here) */
+/* LinkSampling::edge_ok, src/linksampling.hh:296-326 (validation and test map share the set) */
 static int edge_ok(const orc_ls *m, uint32_t a, uint32_t b) {
   if (a == b) return 0;
   return !vset_has(m, a, b);
@@ -361,7 +367,7 @@ static void init_validation(orc_ls *m) {
   int p = s1 / 2;
   int c0 = 0, c1 = 0;
   uint32_t cap = 16;
-  while (cap < 4u * (uint32_t)(2 * p + 1)) cap <<= 1;
+  while (cap < 4u * ((uint32_t)(2 * p + 1) + m->cfg.ntest)) cap <<= 1;   /* the test map shares the set (edge_ok looks in both) */
   m->vcap = cap;
   m->vkeys = (uint64_t *)calloc(cap, sizeof(uint64_t));
   m->vused = (uint8_t *)calloc(cap, 1);
@@ -539,6 +545,94 @@ static int validation_likelihood(orc_ls *m) {
   return 0;
 }
 
+/* LinkSampling::load_test, src/linksampling.cc:1417-1450: every pair of the file is ordered (Network::order_edge) and
+ * entered into _test_map (a std::map: duplicates collapse, iteration in (first, second) order).  Called AFTER the
+ * validation sample was drawn (src/linksampling.cc:97-108), so the sampler never saw these pairs. */
+static void load_test(orc_ls *m) {
+  uint32_t nt = m->cfg.ntest;
+  uint32_t *t = (uint32_t *)malloc((size_t)(nt + 1) * 3 * sizeof(uint32_t));
+  for (uint32_t i = 0; i < nt; ++i) {
+    uint32_t a = m->cfg.test_pairs[2 * i], b = m->cfg.test_pairs[2 * i + 1];
+    if (a > b) { uint32_t x = a; a = b; b = x; }
+    t[3 * i] = a; t[3 * i + 1] = b; t[3 * i + 2] = 0;
+  }
+  qsort(t, nt, 3 * sizeof(uint32_t), cmp_triple);
+  uint32_t u = 0;
+  for (uint32_t i = 0; i < nt; ++i) {
+    if (u && t[3 * (u - 1)] == t[3 * i] && t[3 * (u - 1) + 1] == t[3 * i + 1]) continue;
+    t[3 * u] = t[3 * i]; t[3 * u + 1] = t[3 * i + 1];
+    t[3 * u + 2] = (uint32_t)orc_net_y(m->g, t[3 * i], t[3 * i + 1]);   /* test_likelihood asks the network, :1160 */
+    if (!vset_has(m, t[3 * u], t[3 * u + 1])) vset_add(m, t[3 * u], t[3 * u + 1]);
+    u++;
+  }
+  m->test_sorted = t;
+  m->ntest = u;
+}
+
+/* LinkSampling::init_gamma_external, src/linksampling.cc:405-453: gamma = alpha; for every adjacency ENTRY of p (both
+ * directions of every link, held-out ones included) a vector phi = alpha everywhere, + n / |c(p)| on each of the
+ * communities the file lists p in (once per listing), normalised, is added to gamma[p] -- deg(p) additions of the
+ * same vector, kept as repeated additions.  No random draw. */
+static void init_gamma_external(orc_ls *m) {
+  uint32_t K = m->k, n = m->n;
+  /* node -> its communities in the order of the file's lines (Network::_init_communities_seq) */
+  uint32_t *cnt = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+  uint32_t total = m->cfg.init_comm_ptr[m->cfg.ninit_comm];
+  for (uint32_t i = 0; i < total; ++i) cnt[m->cfg.init_comm_nodes[i] + 1]++;
+  for (uint32_t p = 0; p < n; ++p) cnt[p + 1] += cnt[p];
+  uint32_t *fill = (uint32_t *)malloc((size_t)(n + 1) * sizeof(uint32_t));
+  memcpy(fill, cnt, (size_t)(n + 1) * sizeof(uint32_t));
+  uint32_t *comm = (uint32_t *)malloc((size_t)(total + 1) * sizeof(uint32_t));
+  for (uint32_t c = 0; c < m->cfg.ninit_comm; ++c)
+    for (uint32_t i = m->cfg.init_comm_ptr[c]; i < m->cfg.init_comm_ptr[c + 1]; ++i)
+      comm[fill[m->cfg.init_comm_nodes[i]]++] = c;
+  for (size_t i = 0; i < (size_t)n * K; ++i) m->gamma[i] = m->alpha;
+  double *phi = m->phi;
+  for (uint32_t p = 0; p < n; ++p) {
+    const uvec *e = &m->g->adj[p];
+    uint32_t nc = cnt[p + 1] - cnt[p];
+    for (uint32_t r = 0; r < e->n; ++r) {
+      for (uint32_t k = 0; k < K; ++k) phi[k] = m->alpha;
+      for (uint32_t j = 0; j < nc; ++j) {
+        uint32_t c = comm[cnt[p] + j];
+        if (c < K) phi[c] += (double)n / nc;      /* (the reference indexes phi[r[j]] unchecked; a line beyond K is out of bounds there) */
+      }
+      double s = .0;
+      for (uint32_t k = 0; k < K; ++k) s += phi[k];
+      for (uint32_t k = 0; k < K; ++k) phi[k] = phi[k] / s;     /* Array::normalize, src/matrix.hh */
+      for (uint32_t k = 0; k < K; ++k) m->gamma[(size_t)p * K + k] += phi[k];
+    }
+  }
+  free(cnt); free(fill); free(comm);
+}
+
+/* test_likelihood, src/linksampling.cc:1147-1182: the columns of the validation row over the test map, no stop rule */
+static void test_likelihood(orc_ls *m) {
+  if (m->cfg.accuracy || !m->ntest) return;
+  uint32_t K = m->k;
+  double *pi_p = (double *)malloc(sizeof(double) * K), *pi_q = (double *)malloc(sizeof(double) * K);
+  uint32_t k = 0, kzeros = 0, kones = 0;
+  double s = .0, szeros = 0, sones = 0;
+  for (uint32_t i = 0; i < m->ntest; ++i) {
+    uint32_t p = m->test_sorted[3 * i], q = m->test_sorted[3 * i + 1];
+    int y = (int)m->test_sorted[3 * i + 2];
+    double u = edge_likelihood(m, p, q, y, pi_p, pi_q);
+    s += u; k += 1;
+    if (y) { sones += u; kones++; } else { szeros += u; kzeros++; }
+  }
+  free(pi_p); free(pi_q);
+  double nshol = (m->zeros_prob * (szeros / kzeros)) + (m->ones_prob * (sones / kones));
+  double row[10] = {(double)m->iter, s / k, (double)k, szeros / kzeros, (double)kzeros,
+                    sones / kones, (double)kones, m->zeros_prob * (szeros / kzeros),
+                    m->ones_prob * (sones / kones), nshol};
+  if (m->ntrows == m->trows_cap) {
+    m->trows_cap = m->trows_cap ? m->trows_cap * 2 : 64;
+    m->trows = (double *)realloc(m->trows, (size_t)m->trows_cap * 10 * sizeof(double));
+  }
+  memcpy(m->trows + (size_t)m->ntrows * 10, row, 10 * sizeof(double));
+  m->ntrows++;
+}
+
 orc_ls *orc_ls_create(const orc_net *g, const orc_config *cfg) {
   orc_ls *m = (orc_ls *)calloc(1, sizeof(orc_ls));
   m->g = g;
@@ -596,8 +690,10 @@ orc_ls *orc_ls_create(const orc_net *g, const orc_config *cfg) {
   m->r = orc_rng_new(cfg->seed ? (unsigned long)cfg->seed : 0ul);
 
   init_validation(m);
-  if (!cfg->skip_init) init_gamma2(m);
-  else for (size_t i = 0; i < nk; ++i) m->gamma[i] = 1.0;
+  if (cfg->test_pairs && cfg->ntest) load_test(m);            /* src/linksampling.cc:105-108 */
+  if (cfg->skip_init) for (size_t i = 0; i < nk; ++i) m->gamma[i] = 1.0;
+  else if (cfg->init_comm_ptr) init_gamma_external(m);        /* :112-115 (init_lambda follows: nolambda is false) */
+  else init_gamma2(m);
   for (size_t i = 0; i < nk; ++i) m->gammanext[i] = m->alpha;
   for (uint32_t k = 0; k < K; ++k) {
     m->lambda[2 * k] = m->lambdanext[2 * k] = m->eta0;
@@ -625,7 +721,7 @@ void orc_ls_free(orc_ls *m) {
   free(m->elogpi); free(m->elogbeta); free(m->mphi); free(m->fmap); free(m->member);
   free(m->s1); free(m->s2); free(m->s3); free(m->sum); free(m->phi);
   free(m->converged); free(m->active_comms); free(m->active_k); free(m->active_k_len);
-  free(m->training_links); free(m->links); free(m->rows);
+  free(m->training_links); free(m->links); free(m->rows); free(m->test_sorted); free(m->trows);
   orc_rng_free(m->r);
   free(m);
 }
@@ -782,6 +878,7 @@ int orc_ls_sweep(orc_ls *m) {
   if (m->iter % m->cfg.reportfreq == 0 && !m->skip_validation)
     stopped = validation_likelihood(m);
   if (stopped) return 2;
+  if (m->iter % m->cfg.reportfreq == 0 && !m->skip_validation) test_likelihood(m);   /* :781, not reached on the stopping sweep */
   m->iter++;
   return 0;
 }
@@ -813,6 +910,10 @@ double orc_ls_eta0(const orc_ls *m) { return m->eta0; }
 double orc_ls_eta1(const orc_ls *m) { return m->eta1; }
 double orc_ls_ones_prob(const orc_ls *m) { return m->ones_prob; }
 double orc_ls_total_pairs(const orc_ls *m) { return m->total_pairs; }
+uint32_t orc_ls_ntest(const orc_ls *m) { return m->ntest; }
+const uint32_t *orc_ls_test_sorted(const orc_ls *m) { return m->test_sorted; }
+uint32_t orc_ls_ntest_rows(const orc_ls *m) { return m->ntrows; }
+const double *orc_ls_test_rows(const orc_ls *m) { return m->trows; }
 uint32_t orc_ls_nrows(const orc_ls *m) { return m->nrows; }
 const double *orc_ls_rows(const orc_ls *m) { return m->rows; }
 void orc_ls_link_counts(const orc_ls *m, uint32_t *dense, uint32_t *sparse, uint32_t *shortcut) {

@@ -81,6 +81,18 @@ typedef struct {
   /* the active-set ("sparse") branch is taken when _iter > sparse_after_iter (src/linksampling.cc:634
    * has the constant 1000; the revision that made the shipped runs had no such condition: -1) */
   int32_t sparse_after_iter;
+  /* -load-test <file> (LinkSampling::load_test, src/linksampling.cc:1417-1450): the pairs of the file as SEQUENCE ids
+   * (the caller maps external ids, as the reference does through id2seq), in file order, not yet ordered; NULL = no test
+   * set.  They leave the training links (edge_ok, src/linksampling.hh:296-305) and get a likelihood row per report
+   * (test_likelihood, src/linksampling.cc:1147-1182) */
+  const uint32_t *test_pairs;            /* [ntest][2] */
+  uint32_t ntest;
+  /* -init-communities <file> (Network::load_init_communities, src/network.cc:374-440; LinkSampling::init_gamma_external,
+   * src/linksampling.cc:405-453): community c = line c of the file holds the nodes init_comm_nodes[init_comm_ptr[c] ..
+   * init_comm_ptr[c+1]) as sequence ids in file order; NULL = the seeded init_gamma2 */
+  const uint32_t *init_comm_ptr;         /* [ninit_comm + 1] */
+  const uint32_t *init_comm_nodes;
+  uint32_t ninit_comm;
 } orc_config;
 
 void orc_config_default(orc_config *c, uint32_t k);
@@ -127,6 +139,10 @@ double orc_ls_eta0(const orc_ls *m);
 double orc_ls_eta1(const orc_ls *m);
 double orc_ls_ones_prob(const orc_ls *m);
 double orc_ls_total_pairs(const orc_ls *m);
+uint32_t orc_ls_ntest(const orc_ls *m);                /* distinct test pairs (the std::map's size) */
+const uint32_t *orc_ls_test_sorted(const orc_ls *m);   /* [ntest][3] a,b,y in std::map order */
+uint32_t orc_ls_ntest_rows(const orc_ls *m);           /* test.txt rows so far (one per report that did not exit) */
+const double *orc_ls_test_rows(const orc_ls *m);       /* [ntest_rows][10], the columns of orc_ls_rows */
 uint32_t orc_ls_nrows(const orc_ls *m);                /* validation rows so far */
 const double *orc_ls_rows(const orc_ls *m);            /* [nrows][10]: iter, s/k, k, mean0, k0, mean1, k1, z*mean0, o*mean1, a */
 void orc_ls_link_counts(const orc_ls *m, uint32_t *dense, uint32_t *sparse, uint32_t *shortcut);

@@ -29,7 +29,8 @@ EXPORTS = (
     "svils_comm_unique_id", "svils_comm_init", "svils_sweep_sharded", "svils_gather_communities",
     "svils_ksweep_phase", "svils_ksh_buffer_ptr", "svils_ksh_init_state", "svils_sweep_ksharded", "svils_ksh_log_domain",
     "svils_comm_allgather_host", "svils_step_sharded", "svils_step_ksharded", "svils_comm_query",
-    "svils_report_enqueue", "svils_report_ready", "svils_report_fetch",
+    "svils_report_enqueue", "svils_report_ready", "svils_report_fetch", "svils_report_test_rows",
+    "svils_set_test", "svils_get_test_rows",
 )
 
 
@@ -131,6 +132,9 @@ def load():
     L.svils_report_enqueue.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
     L.svils_report_ready.argtypes = [vp, C.c_int]
     L.svils_report_fetch.argtypes = [vp, C.c_int, C.POINTER(Control), vp, C.POINTER(C.c_uint32), vp]
+    L.svils_report_test_rows.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_uint32)]
+    L.svils_set_test.argtypes = [vp, vp, C.c_uint64]
+    L.svils_get_test_rows.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -234,6 +238,19 @@ class Engine:
     def set_validation(self, pairs_y):
         pairs_y = np.ascontiguousarray(pairs_y, dtype=np.uint32).reshape(-1, 3)
         _chk(load().svils_set_validation(self._h, pairs_y.ctypes.data, pairs_y.shape[0]))
+
+    def set_test(self, pairs_y):
+        """-load-test pairs [T][3] = (p, q, y) in map order: a test row per report (include/svils.h)"""
+        pairs_y = np.ascontiguousarray(pairs_y, dtype=np.uint32).reshape(-1, 3)
+        _chk(load().svils_set_test(self._h, pairs_y.ctypes.data, pairs_y.shape[0]))
+
+    def test_rows(self, first=0, count=None):
+        if count is None:
+            count = self.control().rows - first
+        out = np.zeros((count, 10), dtype=np.float64)
+        if count:
+            _chk(load().svils_get_test_rows(self._h, first, count, out.ctypes.data))
+        return out
 
     def set_state(self, gamma, lam, converged=None):
         gamma = np.ascontiguousarray(gamma, dtype=np.float64)
@@ -362,6 +379,13 @@ class Engine:
         if rc < 0:
             _chk(rc)
         return bool(rc)
+
+    def report_test_rows(self, ticket, row_count):
+        """the test rows of a report (before report_fetch, which frees the slot)"""
+        nr = C.c_uint32()
+        rows = np.zeros((max(row_count, 1), 10), dtype=np.float64)
+        _chk(load().svils_report_test_rows(self._h, ticket, rows.ctypes.data, C.byref(nr)))
+        return rows[:nr.value]
 
     def report_fetch(self, ticket, row_count, with_communities=True):
         """-> (Control, rows [have][10], member [n][k] or None)"""

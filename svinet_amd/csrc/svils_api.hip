@@ -90,6 +90,7 @@ struct svils_handle {
   static constexpr uint32_t kGraphMaxLog = 6;
   hipGraphExec_t gexecP[kGraphMaxLog + 1] = {};        // [i]: 2^i sweeps (i = 0 and 3 stay null: gexec1, gexecN)
   bool graphs_ok = true;                               // false after a capture failure: stay eager
+  uint32_t graph_after = 128;                          // sweeps a handle runs eagerly before it captures graphs (svils_sweep)
   std::vector<void *> allocs;
   // pipelined reports (svils_report_enqueue): staging slots, a copy stream, per-slot events
   struct ReportSlot {
@@ -98,6 +99,10 @@ struct svils_handle {
     bool busy = false, with_member = false;
     uint32_t row_first = 0, row_count = 0;
   };
+  // -load-test (svils_set_test): a second pair set through the validation kernel, rows in a ring of their own
+  uint32_t *t_pairs = nullptr;
+  double *t_uval = nullptr, *t_rows = nullptr;
+  uint32_t nt = 0;
   ReportSlot rslot[SVILS_REPORT_SLOTS];
   ReportLayout rlay{};
   hipStream_t copy_stream = nullptr;
@@ -219,7 +224,8 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   // classification fits the <= 64 co-resident role blocks of the s3 launch with at most two tiles per worker.
   // Larger graphs keep four launches, where the two classification passes ride spin-free on the s3 and tail
   // launches with as many blocks as they need (n=1e6, K=20: s3 launch 1740 -> see profiles/r02h).
-  d.fused3 = (d.fold && !prm.stoch && d.gacc0 && d.cls_ntiles <= 512u) ? 1 : 0;
+  // (a handle with a test set keeps four launches: the deferred stop rule would come too late for the test row)
+  d.fused3 = (d.fold && !prm.stoch && d.gacc0 && d.cls_ntiles <= 512u && !h->nt) ? 1 : 0;
   if (d.fused3) {
     d.gacc = d.gacc0;
     d.nvb = lpl_validation_blocks(g, d.nv, g.K);
@@ -252,6 +258,12 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
       if (!d.fused3) {
         Timed t(h, SVILS_KERNEL_TAIL);
         launch_tail(g, d, prm, s);
+        if (h->nt) {   // test_likelihood (src/linksampling.cc:781): the validation kernel over the test pairs, then the row
+          DeviceState dt = d;
+          dt.vpairs = h->t_pairs; dt.uval = h->t_uval; dt.nv = h->nt;
+          launch_validation(g, dt, prm, s);
+          launch_test_row(dt, prm, h->t_rows, d.rows_cap, s);
+        }
       } else {
         h->v_flush_needed = true;   // the sweep's likelihood row is owed by the next phi launch or by flush_validation()
       }
@@ -480,6 +492,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
     svils_destroy(h);
     return fail(SVILS_ERR_DEVICE, "control block upload failed");
   }
+  if (const char *e = getenv("SVILS_GRAPH_AFTER")) h->graph_after = (uint32_t)std::max(0, atoi(e));
   *out = h;
   return 0;
 }
@@ -1520,7 +1533,13 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
     return fail(SVILS_ERR_ARG, "svils_sweep: at most %llu sweeps per call (likelihood-row ring of %u entries)",
                 (unsigned long long)max_batch, h->d.rows_cap);
   int rc = 0;
-  if (!h->graphs_ok || nsweeps < 4) rc = eager_sweeps(h, nsweeps);   // short calls are not worth a capture
+  // Capturing and instantiating the sweep graphs costs milliseconds (three to five graphs of up to 64 sweeps x 3-4
+  // nodes): more than a whole short run -- ca-AstroPh K = 20 with the default flags stops after 31 sweeps, ~2 ms of
+  // device time.  Graph replay only removes host launch cost, so it starts paying once a run is long: calls stay
+  // eager until the handle has seen graph_after sweeps (128; SVILS_GRAPH_AFTER, read when the handle is created,
+  // overrides; 0 = capture at the first call of >= 4 sweeps), unless a single call is itself long.  Results are identical either way (one code path per kernel).
+  const bool warm = h->gexec1 != nullptr || h->sweeps_issued + nsweeps >= h->graph_after || nsweeps >= 64;
+  if (!h->graphs_ok || nsweeps < 4 || !warm) rc = eager_sweeps(h, nsweeps);   // short calls are not worth a capture
   else if (h->tmask == 0) rc = graph_sweeps(h, nsweeps);
   // Per-kernel hipEvent timing needs eager launches: events captured as graph nodes cannot be read
   // with hipEventElapsedTime on this runtime.  With a sampling period P > 1 only every P-th sweep is
@@ -1795,7 +1814,8 @@ int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count
     HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     h->rlay.off_rows = 128;   // the control block in front (sizeof(DevCtrl) <= 128)
     static_assert(sizeof(DevCtrl) <= 128, "report layout");
-    h->rlay.off_member = h->rlay.off_rows + (size_t)SVILS_REPORT_MAX_ROWS * 10 * sizeof(double);
+    h->rlay.off_trows = h->rlay.off_rows + (size_t)SVILS_REPORT_MAX_ROWS * 10 * sizeof(double);
+    h->rlay.off_member = h->rlay.off_trows + (size_t)SVILS_REPORT_MAX_ROWS * 10 * sizeof(double);
     h->rlay.bytes = h->rlay.off_member + nwords * sizeof(uint64_t);
   }
   int t = -1;
@@ -1809,7 +1829,7 @@ int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count
     HIPCHK(hipEventCreateWithFlags(&rs.packed, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&rs.landed, hipEventDisableTiming));
   }
-  launch_report_pack(h->d.ctrl, sizeof(DevCtrl), h->d.rows, h->d.rows_cap, row_first, row_count,
+  launch_report_pack(h->d.ctrl, sizeof(DevCtrl), h->d.rows, h->nt ? h->t_rows : nullptr, h->d.rows_cap, row_first, row_count,
                      with_communities ? h->d.member : nullptr, with_communities ? nwords : 0, rs.dev, h->rlay, h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(rs.packed, h->stream));
@@ -1830,6 +1850,68 @@ int svils_report_ready(svils_handle *h, int ticket) {
   if (e == hipSuccess) return 1;
   if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
   return fail(SVILS_ERR_DEVICE, "svils_report_ready: %s", hipGetErrorString(e));
+}
+
+int svils_report_test_rows(svils_handle *h, int ticket, double *test_rows, uint32_t *ntest) {
+  if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_test_rows: bad ticket");
+  if (!h->nt) return fail(SVILS_ERR_ARG, "svils_report_test_rows: the handle has no test set (svils_set_test)");
+  svils_handle::ReportSlot &rs = h->rslot[ticket];
+  HIPCHK(hipEventSynchronize(rs.landed));
+  DevCtrl c;
+  memcpy(&c, rs.host, sizeof c);
+  if (c.fault) return fault_error(c.fault);
+  uint32_t have = c.rows > rs.row_first ? std::min(c.rows - rs.row_first, rs.row_count) : 0u;
+  // the stopping sweep recorded its validation row and left before test_likelihood: that row, the last one, has no partner
+  if (c.stopped && have && rs.row_first + have == c.rows) --have;
+  if (ntest) *ntest = have;
+  if (test_rows && have) memcpy(test_rows, rs.host + h->rlay.off_trows, (size_t)have * 10 * sizeof(double));
+  return 0;
+}
+
+int svils_set_test(svils_handle *h, const uint32_t *pairs_y, uint64_t nt) {
+  if (!h || (!pairs_y && nt)) return fail(SVILS_ERR_ARG, "svils_set_test: null argument");
+  if (h->d.ksh) return fail(SVILS_ERR_UNSUPPORTED, "svils_set_test: not for K-sharded handles");
+  if (nt > 0xffffffffull) return fail(SVILS_ERR_ARG, "svils_set_test: too many pairs");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (uint64_t i = 0; i < nt; ++i)
+    if (pairs_y[3 * i] >= h->geo.n || pairs_y[3 * i + 1] >= h->geo.n || pairs_y[3 * i] == pairs_y[3 * i + 1])
+      return fail(SVILS_ERR_ARG, "svils_set_test: pair %llu names node %u / %u (n = %u)", (unsigned long long)i, pairs_y[3 * i], pairs_y[3 * i + 1], h->geo.n);
+  drop_graphs_of(h);            // the captured sweeps do not know about the test launches (or still carry them)
+  h->nt = 0;
+  if (!nt) return 0;
+  int rc;
+  if ((rc = dalloc(h, &h->t_pairs, 3 * (size_t)nt))) return rc;
+  if ((rc = dalloc(h, &h->t_uval, (size_t)nt))) return rc;
+  if (!h->t_rows) {
+    if ((rc = dalloc(h, &h->t_rows, (size_t)h->d.rows_cap * 10, false))) return rc;
+    // a report without a test row reads as NaN
+    HIPCHK(hipMemsetAsync(h->t_rows, 0xff, (size_t)h->d.rows_cap * 10 * sizeof(double), h->stream));
+  }
+  HIPCHK(hipMemcpyAsync(h->t_pairs, pairs_y, 3 * (size_t)nt * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->nt = (uint32_t)nt;
+  return 0;
+}
+
+int svils_get_test_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows) {
+  if (!h || (!rows && count)) return fail(SVILS_ERR_ARG, "svils_get_test_rows: null argument");
+  if (!h->nt) return fail(SVILS_ERR_ARG, "svils_get_test_rows: the handle has no test set (svils_set_test)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DevCtrl c;
+  HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
+  if (c.fault) return fault_error(c.fault);
+  if ((uint64_t)first + count > c.rows) return fail(SVILS_ERR_ARG, "test rows [%u,%u) not recorded yet (have %u)", first, first + count, c.rows);
+  if (c.rows - first > h->d.rows_cap) return fail(SVILS_ERR_ARG, "test row %u already overwritten in the ring", first);
+  uint32_t done = 0;
+  while (done < count) {
+    const uint32_t slot = (first + done) % h->d.rows_cap;
+    const uint32_t run = std::min(count - done, h->d.rows_cap - slot);
+    HIPCHK(hipMemcpy(rows + (size_t)done * 10, h->t_rows + (size_t)slot * 10, (size_t)run * 10 * sizeof(double), hipMemcpyDeviceToHost));
+    done += run;
+  }
+  return 0;
 }
 
 int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows, uint8_t *member) {

@@ -61,6 +61,7 @@ Env::Env(const Args &a)
       model_load(a.load), gamma_location(a.location),
       load_heldout(a.val_load), load_heldout_fname(a.val_file_location),
       load_test(a.test_load), load_test_fname(a.test_file_location),
+      use_init_communities(a.init_comm), init_communities_fname(a.init_comm_fname),
       nmi(a.nmi), ground_truth_fname(a.ground_truth_fname),
       datfname(a.datfname), label(a.label), gpus(a.gpus), rank(a.rank), kshard(a.kshard), sharded((a.sharded || a.gpus > 1) && !a.kshard), comm_rfd(a.comm_rfd), comm_wfds(a.comm_wfds),
       batch_mode(a.batch), link_sampling(a.link_sampling), strid(a.strid),
@@ -136,7 +137,7 @@ Env::Env(const Args &a)
   plog("lt_min_deg", lt_min_deg);
   plog("epsilon", epsilon);
   plog("sets_mini_batch", (uint32_t)(n / 100));
-  plog("use_init_communities", false);
+  plog("use_init_communities", use_init_communities);
   plog("load_test_sets", false);
   plog("val_load", load_heldout);
   plog("val_file_location", load_heldout_fname);

@@ -24,6 +24,8 @@ class Env {
     std::string val_file_location;
     bool test_load = false;
     std::string test_file_location;
+    bool init_comm = false;             // -init-communities <file>
+    std::string init_comm_fname;
     double hol_ratio = 0.01;
     std::string eta_type = "uniform";
     uint32_t rfreq = 1;
@@ -81,6 +83,8 @@ class Env {
   std::string load_heldout_fname;
   bool load_test;
   std::string load_test_fname;
+  bool use_init_communities;
+  std::string init_communities_fname;
   bool nmi;
   std::string ground_truth_fname;
   std::string datfname, label;

@@ -68,7 +68,7 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
   FILE *vef = nullptr;
   if (env_.write_files) {
     vef = open_or_die(Env::file_str("/validation-edges.txt"), "validation edges");
-    fclose(open_or_die(Env::file_str("/test-edges.txt"), "test edges"));
+    if (!env_.load_test) fclose(open_or_die(Env::file_str("/test-edges.txt"), "test edges"));   // load_test() writes it
   }
   if (!env_.load_heldout) {
     Env::plog("load validation from file:", false);
@@ -83,9 +83,9 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     fprintf(vef, "%s\n", edgelist_s(val_accept_).c_str());
     fclose(vef);
   }
-  if (env_.load_test) {
-    fprintf(stderr, "error: -load-test is not supported by this build\n");
-    exit(-1);
+  if (env_.load_test) {                          // src/linksampling.cc:105-108: after the validation sample, so the
+    Env::plog("load test from file:", true);     // sampler never saw these pairs
+    load_test();
   }
 
   if (env_.nmi) {   // Network::load_ground_truth / write_gt_communities (src/network.cc:252-307,508-525)
@@ -110,6 +110,9 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
   lambda_.assign(2 * (size_t)k_, 0.0);
   if (env_.model_load) {
     if (load_model() < 0) exit(-1);
+  } else if (env_.use_init_communities) {        // src/linksampling.cc:112-115 (nolambda is never set on this path)
+    init_gamma_external();
+    init_lambda();
   } else {
     init_gamma2();
     init_lambda();
@@ -129,6 +132,13 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     val_sorted_.push_back(kv.first.first);
     val_sorted_.push_back(kv.first.second);
     val_sorted_.push_back(network_.y(kv.first.first, kv.first.second) ? 1u : 0u);
+  }
+
+  // ... and of test_likelihood's loop over _test_map (:1154-1172); y is asked of the network there
+  for (const auto &kv : test_map_) {
+    test_sorted_.push_back(kv.first.first);
+    test_sorted_.push_back(kv.first.second);
+    test_sorted_.push_back(network_.y(kv.first.first, kv.first.second) ? 1u : 0u);
   }
 
   if (attach_device) {
@@ -234,6 +244,13 @@ void LinkSampling::attach() {
       for (size_t i = 0; i < v.size(); i += 3) { v[i] = dev_of_[v[i]]; v[i + 1] = dev_of_[v[i + 1]]; }
     if (svils_set_validation(h_, v.data(), v.size() / 3)) die_svils("svils_set_validation");
   }
+  if (!env_.accuracy && !test_sorted_.empty()) {      // test_likelihood returns at once with -accuracy (:1150-1151)
+    if (env_.kshard) { fprintf(stderr, "error: -load-test is not available with -kshard\n"); exit(-1); }
+    std::vector<uint32_t> v(test_sorted_);
+    if (!dev_of_.empty())
+      for (size_t i = 0; i < v.size(); i += 3) { v[i] = dev_of_[v[i]]; v[i + 1] = dev_of_[v[i + 1]]; }
+    if (svils_set_test(h_, v.data(), v.size() / 3)) die_svils("svils_set_test");
+  }
   if (env_.kshard) {
     const uint32_t w = k1_ - k0_;
     std::vector<double> g((size_t)n_ * w);
@@ -254,6 +271,7 @@ void LinkSampling::attach() {
 // ---------------------------------------------------------------- validation set
 bool LinkSampling::edge_ok(const Edge &e) const {       // src/linksampling.hh:296-326
   if (e.first == e.second) return false;
+  if (test_map_.find(e) != test_map_.end()) return false;
   return validation_map_.find(e) == validation_map_.end();
 }
 
@@ -317,6 +335,40 @@ void LinkSampling::load_validation() {                    // src/linksampling.cc
   Env::plog("link sampling: loaded validation heldout pairs:", cnt);
 }
 
+// LinkSampling::load_test, src/linksampling.cc:1417-1450: "id<TAB>id" lines of external ids; every pair is ordered and
+// entered into _test_map (a std::map: a repeated pair collapses) and appended to _test_pairs (test-edges.txt lists
+// every line, with the network's y)
+void LinkSampling::load_test() {
+  FILE *f = fopen(env_.load_test_fname.c_str(), "r");
+  if (!f) {
+    fprintf(stderr, "error: cannot read test test file %s\n", env_.load_test_fname.c_str());
+    exit(-1);
+  }
+  int a, b;
+  uint32_t cnt = 0;
+  std::vector<uint32_t> listed;
+  while (fscanf(f, "%d %d", &a, &b) == 2) {
+    uint32_t p, q;
+    if (!network_.id2seq((uint32_t)a, &p) || !network_.id2seq((uint32_t)b, &q)) {
+      fprintf(stderr, "error: id %d or id %d not found in original network\n", a, b);
+      exit(-1);
+    }
+    const Edge e = p < q ? Edge(p, q) : Edge(q, p);
+    test_map_[e] = true;
+    listed.push_back(e.first);
+    listed.push_back(e.second);
+    listed.push_back(network_.y(p, q) ? 1u : 0u);
+    ++cnt;
+  }
+  fclose(f);
+  Env::plog("link sampling: loaded test heldout pairs:", cnt);
+  if (env_.write_files) {
+    FILE *tef = open_or_die(Env::file_str("/test-edges.txt"), "test edges");
+    fprintf(tef, "%s\n", edgelist_s(listed).c_str());
+    fclose(tef);
+  }
+}
+
 std::string LinkSampling::edgelist_s(const std::vector<uint32_t> &t) const {  // :190-206
   std::ostringstream sa;
   const std::vector<uint32_t> &s2i = network_.seq2id();
@@ -332,6 +384,75 @@ std::string LinkSampling::edgelist_s(const std::vector<uint32_t> &t) const {  //
 // thread, chunk by chunk; normalising a chunk and adding it into gamma is done by worker threads
 // while the next chunk is being drawn.  Every node's row is owned by one worker and receives its
 // links' vectors in link order, so the result is bit-identical to the sequential loop.
+// Network::load_init_communities (src/network.cc:374-440) + LinkSampling::init_gamma_external (src/linksampling.cc:405-453).
+// The file holds one community per line (external ids, whitespace separated); line c is community c.  gamma starts at
+// alpha; for every adjacency entry of p (every link of p, held-out ones included) the vector phi = alpha everywhere,
+// + n / |c(p)| on each community that lists p, normalised to sum 1, is added to gamma[p] -- deg(p) additions of one
+// vector, done as repeated additions as the reference does them.  No random draw.  init_memberships.txt is written
+// as the reference writes it.
+void LinkSampling::init_gamma_external() {
+  FILE *f = fopen(env_.init_communities_fname.c_str(), "r");
+  if (!f) {
+    fprintf(stderr, "error: cannot read init communities file %s\n", env_.init_communities_fname.c_str());
+    exit(-1);
+  }
+  printf("+ Loading init communities from %s\n", env_.init_communities_fname.c_str());
+  std::vector<std::vector<uint32_t>> of_node(n_);   // _init_communities_seq: node -> communities in line order
+  char *line = nullptr;
+  size_t cap = 0;
+  uint32_t cid = 0;
+  ssize_t got;
+  while ((got = getline(&line, &cap, f)) > 0) {
+    // (the reference skips a line only when sscanf fails on it, i.e. at end of input: an empty line IS a community)
+    const char *p = line;
+    for (;;) {
+      char *e = nullptr;
+      const long u = strtol(p, &e, 10);
+      if (e == p) break;
+      p = e;
+      uint32_t seq;
+      if (!network_.id2seq((uint32_t)u, &seq)) {
+        fprintf(stderr, "error: id %ld of the init communities file is not in the network\n", u);
+        exit(-1);
+      }
+      of_node[seq].push_back(cid);
+    }
+    cid++;
+  }
+  free(line);
+  fclose(f);
+  printf("+ Loaded %d init communities\n", cid);
+  if (env_.write_files) {
+    FILE *g = open_or_die(Env::file_str("/init_memberships.txt"), "init memberships");
+    const std::vector<uint32_t> &s2i = network_.seq2id();
+    for (uint32_t i = 0; i < n_; ++i) {
+      fprintf(g, "%d\t", s2i[i]);
+      for (uint32_t c : of_node[i]) fprintf(g, "%d\t", c);
+      fprintf(g, "\n");
+    }
+    fclose(g);
+  }
+  std::fill(gamma_.begin(), gamma_.end(), env_.alpha);
+  std::vector<double> phi(k_);
+  for (uint32_t p = 0; p < n_; ++p) {
+    const std::vector<uint32_t> &r = of_node[p];
+    for (uint32_t c : r)
+      if (c >= k_) {   // the reference logs it and then writes phi[c] out of bounds
+        fprintf(stderr, "error: the init communities file has more than k = %u lines (node %u is on line %u)\n", k_, network_.seq2id()[p], c);
+        exit(-1);
+      }
+    std::fill(phi.begin(), phi.end(), env_.alpha);
+    for (uint32_t c : r) phi[c] += (double)n_ / (double)r.size();
+    double s = 0.0;
+    for (uint32_t k = 0; k < k_; ++k) s += phi[k];
+    for (uint32_t k = 0; k < k_; ++k) phi[k] = phi[k] / s;
+    double *g = &gamma_[(size_t)p * k_];
+    const size_t deg = network_.get_edges(p).size();
+    for (size_t e = 0; e < deg; ++e)
+      for (uint32_t k = 0; k < k_; ++k) g[k] += phi[k];
+  }
+}
+
 void LinkSampling::init_gamma2() {
   std::vector<uint32_t> lp, lq;
   lp.reserve(network_.ones());
@@ -581,8 +702,15 @@ bool LinkSampling::fetch_and_log_rows() {
   const bool reported = c.rows > rows_logged_ || env_.accuracy || val_sorted_.empty();
   if (c.rows > rows_logged_) {
     std::vector<double> rows((size_t)(c.rows - rows_logged_) * 10);
-    if (svils_get_rows(h_, rows_logged_, c.rows - rows_logged_, rows.data())) die_svils("svils_get_rows");
-    log_rows(rows.data(), c.rows - rows_logged_, c.why, c.max_h);
+    const uint32_t cnt = c.rows - rows_logged_;
+    if (svils_get_rows(h_, rows_logged_, cnt, rows.data())) die_svils("svils_get_rows");
+    const bool with_test = !test_sorted_.empty() && !env_.accuracy;
+    std::vector<double> trows;
+    if (with_test) {
+      trows.resize((size_t)cnt * 10);
+      if (svils_get_test_rows(h_, rows_logged_, cnt, trows.data())) die_svils("svils_get_test_rows");
+    }
+    log_rows(rows.data(), cnt, c.why, c.max_h, with_test ? trows.data() : nullptr, c.stopped ? cnt - 1 : cnt);
     rows_logged_ = c.rows;
   }
   return reported;
@@ -670,13 +798,18 @@ void LinkSampling::write_communities_file() {
   }
 }
 
-void LinkSampling::log_rows(const double *rows, uint32_t count, int why, double max_h) {
+// validation.txt / test.txt / max.txt of `count` reports.  test: [ntest][10] rows of the test set (svils_set_test), or
+// null: test_likelihood over the empty test map prints 0/0 ratios (:1147-1182).  ntest < count only when the last
+// report is the one that ends the run: the reference leaves through do_on_stop + exit before test_likelihood (:777-781).
+void LinkSampling::log_rows(const double *rows, uint32_t count, int why, double max_h, const double *test, uint32_t ntest) {
   if (!vf_ || !count) return;
   for (uint32_t i = 0; i < count; ++i) {
     write_validation_row(&rows[(size_t)i * 10], vf_);
-    // test_likelihood over the empty test map prints 0/0 ratios (:1147-1182)
-    fprintf(tf_, "%d\t%d\t-nan\t0\t-nan\t0\t-nan\t0\t-nan\t-nan\t-nan\n", (int)rows[(size_t)i * 10], duration());
-    fflush(tf_);
+    if (i < ntest) {
+      if (test) write_validation_row(&test[(size_t)i * 10], tf_);
+      else fprintf(tf_, "%d\t%d\t-nan\t0\t-nan\t0\t-nan\t0\t-nan\t-nan\t-nan\n", (int)rows[(size_t)i * 10], duration());
+      fflush(tf_);
+    }
   }
   write_max(&rows[(size_t)(count - 1) * 10], why, max_h);
 }
@@ -702,11 +835,24 @@ int LinkSampling::sweep_loop_pipelined() {
   uint32_t issued_iter = c.iter;          // _iter after the sweeps enqueued so far (if nothing stops them)
   uint32_t rows_issued = rows_logged_;
   uint32_t chunk = env_.sweep_batch ? env_.sweep_batch : 1;
+  // -nmi scores the communities of EVERY report (one mutual.txt line per report, :843-851): one report per rfreq sweeps
+  const bool fixed_chunk = env_.sweep_batch != 0 || env_.nmi;
   const uint32_t rf = std::max<uint32_t>(1, env_.reportfreq);
+  if (env_.nmi && !env_.sweep_batch) chunk = rf;
   const bool always_report = env_.accuracy || val_sorted_.empty();
-  std::vector<double> rows((size_t)SVILS_REPORT_MAX_ROWS * 10);
+  std::vector<double> rows((size_t)SVILS_REPORT_MAX_ROWS * 10), trows((size_t)SVILS_REPORT_MAX_ROWS * 10);
   bool quit_max = false;
   timing_.pipelined = true;
+  {   // the report slots (device staging + pinned host memory, ~1 ms of allocations) exist before the first sweep
+    int t[SVILS_REPORT_SLOTS];
+    for (int i = 0; i < SVILS_REPORT_SLOTS; ++i)
+      if (svils_report_enqueue(h_, 0, 0, 1, &t[i])) die_svils("svils_report_enqueue");
+    for (int i = 0; i < SVILS_REPORT_SLOTS; ++i) {
+      svils_control cc;
+      uint32_t hv = 0;
+      if (svils_report_fetch(h_, t[i], &cc, rows.data(), &hv, nullptr)) die_svils("svils_report_fetch");
+    }
+  }
   timing_.sweeps_t0 = now_s();
   for (;;) {
     // ---- keep the device busy: up to SVILS_REPORT_SLOTS - 1 chunks ahead of the host
@@ -726,7 +872,7 @@ int LinkSampling::sweep_loop_pipelined() {
       rows_issued += new_rows;
       flight.push_back(f);
       timing_.chunks++;
-      if (!env_.sweep_batch && !flight.empty() && chunk < 16 && svils_report_ready(h_, flight.front().ticket) == 1 && flight.size() > 1)
+      if (!fixed_chunk && !flight.empty() && chunk < 16 && svils_report_ready(h_, flight.front().ticket) == 1 && flight.size() > 1)
         chunk *= 2;     // the device finished a chunk before the host came back for it: the host is the slower side
     }
     if (flight.empty()) break;              // everything issued and reported: -max-iterations reached
@@ -739,9 +885,14 @@ int LinkSampling::sweep_loop_pipelined() {
     const bool superseded = !env_.nmi && !flight.empty() && flight.front().with_comm && svils_report_ready(h_, flight.front().ticket) == 1;
     const bool want_comm = f.with_comm && env_.write_files && !superseded;
     if (want_comm) member_.assign((size_t)n_ * k_, 0);
+    uint32_t have_t = 0;
+    const bool with_test = !test_sorted_.empty() && !env_.accuracy;
+    if (with_test && svils_report_test_rows(h_, f.ticket, trows.data(), &have_t)) die_svils("svils_report_test_rows");
     if (svils_report_fetch(h_, f.ticket, &c, rows.data(), &have, want_comm ? member_.data() : nullptr)) die_svils("svils_report_fetch");
     const double t0 = now_s();
-    log_rows(rows.data(), have, c.why, c.max_h);
+    // (without a test set every report that does not end the run still gets its row of 0/0 ratios)
+    if (!with_test) have_t = (c.stopped && have && rows_logged_ + have == c.rows) ? have - 1 : have;
+    log_rows(rows.data(), have, c.why, c.max_h, with_test ? trows.data() : nullptr, have_t);
     rows_logged_ += have;
     if (!c.stopped && want_comm) { write_communities_file(); timing_.communities_written++; }
     timing_.reports++;

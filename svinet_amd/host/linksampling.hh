@@ -45,6 +45,7 @@ class LinkSampling {
   const std::vector<double> &lambda() const { return lambda_; }
   const std::vector<uint32_t> &validation_accept() const { return val_accept_; }   // [V][3]
   const std::vector<uint32_t> &validation_sorted() const { return val_sorted_; }   // [V][3]
+  const std::vector<uint32_t> &test_sorted() const { return test_sorted_; }        // [T][3]
   // assign_training_links (src/linksampling.cc:493-523); idempotent
   const std::vector<uint32_t> &training_links();                                   // [L][2]
   double total_pairs() const { return total_pairs_; }
@@ -55,6 +56,8 @@ class LinkSampling {
  private:
   void init_validation();
   void load_validation();
+  void load_test();                            // -load-test
+  void init_gamma_external();                  // -init-communities
   void set_validation_sample(int s);
   void get_random_edge(bool link, Edge &e);
   bool edge_ok(const Edge &e) const;
@@ -69,7 +72,7 @@ class LinkSampling {
   void do_on_stop_impl();
   void log_communities();
   void write_communities_file();               // communities.txt (+ mutual.txt) from member_
-  void log_rows(const double *rows, uint32_t count, int why, double max_h);   // validation.txt, test.txt, max.txt
+  void log_rows(const double *rows, uint32_t count, int why, double max_h, const double *test, uint32_t ntest);   // validation.txt, test.txt, max.txt
   int sweep_loop_pipelined();                  // reports taken off the device's critical path (svils_report_*)
   // one whole-graph engine driving full sweeps: the pipelined loop; SVINET_SYNC_REPORTS=1 keeps the per-batch synchronous one
   bool pipelined_reports() const;
@@ -88,6 +91,8 @@ class LinkSampling {
   GslMt19937 rng_;
   std::map<Edge, bool> validation_map_;        // std::map: the likelihood loop runs in key order
   std::vector<uint32_t> val_accept_, val_sorted_;
+  std::map<Edge, bool> test_map_;              // -load-test
+  std::vector<uint32_t> test_sorted_;          // [T][3] p, q, y in map order
   std::vector<double> gamma_, lambda_;
   std::vector<uint32_t> links_;
   bool links_done_ = false;

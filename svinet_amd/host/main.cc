@@ -148,10 +148,9 @@ int main(int argc, char **argv) {
     else if (is("-kappa")) { need(i); a.kappa = atof(argv[++i]); }
     else if (is("-nodetau0")) { need(i); a.nodetau0 = atof(argv[++i]); }
     else if (is("-nodekappa")) { need(i); a.nodekappa = atof(argv[++i]); }
-    else if (is("-stopthresh") || is("-inf") || is("-scale") || is("-itype") || is("-groups-file") ||
-             is("-init-communities")) {
+    else if (is("-init-communities")) { need(i); a.init_comm = true; a.init_comm_fname = argv[++i]; }   // src/main.cc:237-239
+    else if (is("-stopthresh") || is("-inf") || is("-scale") || is("-itype") || is("-groups-file")) {
       need(i); ++i;   // value flags of other engines: consumed, no effect on this path
-      if (is("-init-communities")) { unsupported = true; unsupported_flag = f; }
     }
     else if (is("-gen") || is("-ppc") || is("-lcstats") || is("-gml") || is("-findk") || is("-stratified") ||
              is("-rnode") || is("-rpair") || is("-orig") || is("-infset") || is("-single") ||

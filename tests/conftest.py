@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # svils_sweep captures its hipGraphs only once a handle has run 128 sweeps (capture costs more than a short run).
+    # Most tests run tens of sweeps: let them replay graphs from the first call of >= 4 sweeps on, so that the replay
+    # path keeps the coverage it had; tests/test_gpu_parity.py::test_graph_capture_threshold runs the default.
+    os.environ.setdefault("SVILS_GRAPH_AFTER", "0")
     # a clean checkout has no built artefacts (they are git-ignored): build them once, in-tree
     need = [os.path.join(ROOT, "svinet_amd", "lib", "libsvils.so"),
             os.path.join(ROOT, "svinet_amd", "lib", "libsvinet_host.so"),

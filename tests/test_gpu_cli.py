@@ -268,3 +268,71 @@ def test_cli_sharded_minibatch_world_of_one(graph_files, tmp_path):
     assert (da / "communities.txt").read_text() == (db / "communities.txt").read_text()
     va, vb = np.loadtxt(da / "validation.txt"), np.loadtxt(db / "validation.txt")
     np.testing.assert_allclose(np.delete(va, 1, axis=1), np.delete(vb, 1, axis=1), rtol=0, atol=2e-9)
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_cli_load_test(graph_files, tmp_path, sync):
+    """-load-test <file> (external ids, "id<TAB>id"): test-edges.txt lists every line with the network's y, the pairs leave
+    the training links, test.txt gets the likelihood of the test set per report -- none for the report that ends the
+    run (src/linksampling.cc:777-781,1147-1182,1417-1450).  Against the oracle's counterpart, in both report loops."""
+    net = O.Network(graph_files["lfr"], 1000)
+    s2i, e = net.seq2id(), net.edges()
+    tp = np.concatenate([e[7::97], [[3, 900], [17, 512], [3, 900], [999, 4]]]).astype(np.uint32)
+    tf = tmp_path / "test_pairs.txt"
+    tf.write_text("".join("%d\t%d\n" % (s2i[a], s2i[b]) for a, b in tp))
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-load-test", str(tf)], str(tmp_path),
+             env={"SVINET_SYNC_REPORTS": "1" if sync else "0"})
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(net, 28, test_pairs=tp)
+    while ref.sweep() != 2:
+        assert ref.iter < 500
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    v, t = np.loadtxt(d / "validation.txt"), np.loadtxt(d / "test.txt")
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+    assert t.shape == (v.shape[0] - 2, 11)               # no constructor row, none for the stopping report
+    np.testing.assert_allclose(np.delete(t, 1, axis=1), ref.test_rows, rtol=0, atol=6e-10)
+    te = [l.split("\t") for l in (d / "test-edges.txt").read_text().split("\n") if l]
+    assert len(te) == tp.shape[0]
+    for (a, b), row in zip(tp, te):
+        lo, hi = min(a, b), max(a, b)
+        assert (int(row[0]), int(row[1]), int(row[2])) == (int(s2i[lo]), int(s2i[hi]), net.y(int(lo), int(hi)))
+
+
+def test_cli_init_communities(graph_files, tmp_path):
+    """-init-communities <file> (one community per line, external ids; Network::load_init_communities,
+    src/network.cc:374-440; LinkSampling::init_gamma_external, src/linksampling.cc:405-453): no random gamma, the model
+    starts from the listed memberships.  Files against the oracle's counterpart; init_memberships.txt as the reference
+    writes it."""
+    net = O.Network(graph_files["lfr"], 1000)
+    s2i = net.seq2id()
+    rng = np.random.default_rng(5)
+    comms = [sorted(rng.choice(1000, size=int(rng.integers(20, 60)), replace=False).tolist()) for _ in range(28)]
+    comms[5] = comms[5] + comms[5][:3]                   # a node listed twice on one line counts twice
+    cf = tmp_path / "init.txt"
+    cf.write_text("".join(" ".join(str(int(s2i[p])) for p in c) + "\n" for c in comms))
+    r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-init-communities", str(cf),
+              "-no-stop", "-max-iterations", "25"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(net, 28, use_validation_stop=False, max_iterations=25, init_communities=comms)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    v = np.loadtxt(d / "validation.txt")
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+    assert "use_init_communities: True" in (d / "param.txt").read_text()
+    mem = [l.rstrip("\n").split("\t") for l in (d / "init_memberships.txt").read_text().split("\n") if l]
+    assert len(mem) == 1000 and int(mem[0][0]) == int(s2i[0])
+    of = {int(m[0]): [int(x) for x in m[1:] if x != ""] for m in mem}
+    for c, nodes in enumerate(comms):
+        for p in nodes:
+            assert c in of[int(s2i[p])]

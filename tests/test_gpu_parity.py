@@ -186,13 +186,95 @@ def test_stored_mean_indicators_stay_current_across_graph_replays(graph_files):
     eng = _engine_from_oracle(ref, net, use_validation_stop=False)
     for rnd in range(3):
         _run_both(eng, ref, 8)                  # round 0 captures the graphs, rounds 1 and 2 only replay them
-        np.testing.assert_allclose(eng.aux(2), ref.mphi, rtol=1e-9, atol=1e-300, err_msg="round %d" % rnd)
+        # (a stale array is off by O(1); the derived form m = (gamma * iscale - alpha) / (n - 1) itself cancels to ~1e-8
+        #  relative on indicators of 1e-7 and below)
+        np.testing.assert_allclose(eng.aux(2), ref.mphi, rtol=1e-6, atol=1e-15, err_msg="round %d" % rnd)
     _run_both(eng, ref, 8)                      # a replay ...
     for ph in (_svils.PHASE_A, _svils.PHASE_B, _svils.PHASE_EXPAND, _svils.PHASE_C, _svils.PHASE_D):
         eng.sweep_phase(ph)                     # ... then a sweep split at its exchange points (stored mphi in s3)
     ref.sweep()
     _check_state(eng, ref, "phase-split sweep after a graph replay")
-    np.testing.assert_allclose(eng.aux(2), ref.mphi, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(eng.aux(2), ref.mphi, rtol=1e-6, atol=1e-15)
+
+
+@pytest.mark.parametrize("k", [28, 100])
+def test_load_test_set_rows_against_oracle(graph_files, k):
+    """-load-test (LinkSampling::load_test, src/linksampling.cc:1417-1450; test_likelihood, :1147-1182): the test pairs
+    leave the training links and get a likelihood row per report -- except on the sweep that ends the run, where the
+    reference exits before test_likelihood (:777-781).  K = 28 is the lane-per-link layout (four launches with a
+    test set), K = 100 the row-per-wavefront one.  Also through a report snapshot."""
+    net = O.Network(graph_files["lfr"], 1000)
+    e = net.edges()
+    tp = np.concatenate([e[7::97], [[3, 900], [17, 512], [3, 900], [999, 4]]]).astype(np.uint32)   # links, non-links, a repeat, unordered
+    ref = O.LinkSampling(net, k, test_pairs=tp)
+    base = O.LinkSampling(net, k)
+    assert ref.nlinks < base.nlinks and ref.test_sorted.shape[0] == tp.shape[0] - 1
+    eng = _engine_from_oracle(ref, net)
+    eng.set_test(ref.test_sorted)
+    n_ref = 0
+    while True:
+        rc = ref.sweep()
+        n_ref += 1
+        if rc == 2:
+            break
+        assert n_ref < 500
+    first = max(0, n_ref - 9)
+    eng.sweep(first)
+    t = eng.report_enqueue(first, 20, False)              # names more rows than the run will make
+    eng.sweep(n_ref - first + 5)                          # the stop rule fires inside
+    c = eng.control()
+    assert c.stopped == 1 and c.sweeps_done == n_ref and c.iter == ref.iter
+    _check_state(eng, ref, "lfr k=%d with a test set, at the stop" % k)
+    want = ref.test_rows
+    assert want.shape[0] == n_ref - 1 and eng.control().rows == n_ref      # no test row for the stopping sweep
+    got = eng.test_rows(0, n_ref - 1)
+    np.testing.assert_allclose(got[:, 1:], want[:, 1:], rtol=1e-7, atol=1e-12)
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert np.isnan(eng.test_rows(n_ref - 1, 1)).all()
+    np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+    # the report that was enqueued before the stop: taken at sweep `first`, it knows nothing of later rows
+    tr = eng.report_test_rows(t, 20)
+    cc, rows, _ = eng.report_fetch(t, 20, False)
+    assert cc.sweeps_done == first and rows.shape[0] == 0 and tr.shape[0] == 0
+    t2 = eng.report_enqueue(first, 20, False)             # after the stop: 9 validation rows, 8 test rows
+    tr2 = eng.report_test_rows(t2, 20)
+    cc2, rows2, _ = eng.report_fetch(t2, 20, False)
+    assert cc2.stopped == 1 and rows2.shape[0] == n_ref - first and tr2.shape[0] == n_ref - first - 1
+    assert np.array_equal(tr2, got[first:])
+
+
+def test_graph_capture_threshold(graph_files):
+    """the product default: a handle replays hipGraphs only once it has run 128 sweeps (SVILS_GRAPH_AFTER unset) -- calls
+    of 40 sweeps are eager, eager, eager, then captured and replayed; the state after every call equals the oracle's and
+    an engine that captured at once (one code path per kernel: bitwise)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from svinet_amd.host_api import Setup\n"
+        "s = Setup(%r, 1000, 28)\n"
+        "e = s.engine(use_validation_stop=False)\n"
+        "for i in range(5):\n"
+        "    e.sweep(40)\n"
+        "g, lam, conv = e.state()\n"
+        "np.savez(%r, g=g, lam=lam, conv=conv, rows=e.rows())\n"
+    )
+    outs = []
+    for after in (None, "0"):
+        out = os.path.join(os.path.dirname(graph_files["lfr"]), "thr_%s.npz" % after)
+        env = {k: v for k, v in os.environ.items() if k != "SVILS_GRAPH_AFTER"}
+        if after is not None:
+            env["SVILS_GRAPH_AFTER"] = after
+        r = subprocess.run([sys.executable, "-c", code % (ROOT_DIR, graph_files["lfr"], out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    for key in ("g", "lam", "conv", "rows"):
+        assert np.array_equal(a[key], b[key]), key
+    ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False)
+    for _ in range(200):
+        ref.sweep()
+    assert _rel(a["g"], ref.gamma) < RTOL and _rel(a["lam"], ref.lam) < RTOL and np.array_equal(a["conv"], ref.converged)
 
 
 def test_sparse_path(graph_files):

@@ -11,8 +11,10 @@ tests/test_gpu_config5.py::test_config5_full_size_against_oracle_digest compares
   sweep), SHA-256 of the training-link list and of the held-out pair list (so that the test knows it is looking at the
   same graph and the same held-out set).
 
-Run in the BUILD container (needs ~25 GB of RAM and ~2.5 min per sweep on one core):
-  python tools/make_config5_digest.py [sweeps=2]
+Run in the BUILD container (needs ~25-30 GB of RAM and ~5 min per sweep on one core):
+  python tools/make_config5_digest.py [sweeps=2]              -> digest.{json,npz}: from the seeded initial state
+  python tools/make_config5_digest.py --planted [sweeps=3]    -> digest_planted.{json,npz}: from planted_state() with
+        _iter = 1001 -- converged flags, shortcut links and the active-set branch at full size
 """
 import hashlib
 import json
@@ -38,14 +40,40 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def planted_state(pairs, truth, n, k):
+    """A state NEAR the planted solution (the regime a long run ends in, which 2 sweeps from the seeded state never
+    reach at this size): gamma = alpha + degree x planted membership, lambda from the link budget.  From here the first
+    sweep's prune() flags the single-community nodes, the second takes O(1) shortcuts for their links and -- with _iter
+    set past 1000 -- the active-set branch for most of the others (src/linksampling.cc:622-681), the third exercises
+    the s3 pass on those flags (quirk Q2).  A pure function of the generator's output; the test recomputes it."""
+    comm, w, _ = truth
+    deg = np.bincount(pairs.ravel(), minlength=n).astype(np.float64)
+    g = np.full((n, k), 1.0 / k)
+    rows = np.repeat(np.arange(n), comm.shape[1])
+    np.add.at(g, (rows, comm.ravel()), (deg[:, None] * w).ravel())
+    lam = np.empty((k, 2))
+    lam[:, 0] = 1.0 + 2.0 * pairs.shape[0] / k
+    lam[:, 1] = 1.0 + 20.0 * pairs.shape[0] / k
+    return g, lam
+
+
 def main():
-    sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    planted = "--planted" in sys.argv
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    sweeps = int(nums[0]) if nums else (3 if planted else 2)
     from oracle import oracle as O
     from svinet_amd import mmsbgen_sparse as G
     t0 = time.time()
-    pairs = G.generate(N, K, DEG)
+    pairs, truth = G.generate(N, K, DEG, return_truth=True)
     net = O.Network(n=N, pairs=pairs)
     ref = O.LinkSampling(net, K, use_validation_stop=False)
+    g0 = None
+    if planted:
+        g0, lam0 = planted_state(pairs, truth, N, K)
+        ref.set_gamma(g0)
+        ref.set_lambda(lam0)
+        ref.refresh()
+        ref.iter = 1001
     print("graph + constructor: %.0f s, %d training links" % (time.time() - t0, ref.nlinks), flush=True)
     counts = []
     for i in range(sweeps):
@@ -58,7 +86,8 @@ def main():
     rows_idx = fixed_rows(N)
     out = os.path.join(ROOT, "tests", "golden", "config5")
     os.makedirs(out, exist_ok=True)
-    np.savez_compressed(os.path.join(out, "digest.npz"), lam=ref.lam, gamma_colsum=g.sum(0), gamma_rows=g[rows_idx],
+    stem = "digest_planted" if planted else "digest"
+    np.savez_compressed(os.path.join(out, stem + ".npz"), lam=ref.lam, gamma_colsum=g.sum(0), gamma_rows=g[rows_idx],
                         rows_idx=rows_idx, converged_idx=np.flatnonzero(conv).astype(np.uint32),
                         converged_val=conv[conv > 0], active_hist=np.bincount(ref.active_comms, minlength=K + 1),
                         link_counts=np.asarray(counts, dtype=np.int64), likelihood_rows=ref.rows,
@@ -69,7 +98,9 @@ def main():
             "generator": "svinet_amd/mmsbgen_sparse.py seed %d" % G.DEFAULT_SEED,
             "oracle": "oracle/svinet_oracle.c, sequential sweep (orc_ls_sweep)", "made_by": "tools/make_config5_digest.py",
             "wall_s": round(time.time() - t0)}
-    json.dump(meta, open(os.path.join(out, "digest.json"), "w"), indent=1)
+    if planted:
+        meta.update({"start": "planted_state() of this script, _iter = 1001", "gamma0_sha256": sha(g0), "iter0": 1001})
+    json.dump(meta, open(os.path.join(out, stem + ".json"), "w"), indent=1)
     print(json.dumps(meta))
 
 
