@@ -12,10 +12,12 @@
 #   pmc          rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the three roofline workloads -> traffic.json + table
 #   pmc-small    the same for astroph-k20 only
 #   native       tests/test_gpu_native_ranks.py
-#   pytest       the whole -m gpu suite          (PYTEST_ARGS adds arguments, e.g. PYTEST_ARGS="-k config5")
+#   pytest       the whole -m gpu suite          (PYTEST_ARGS adds arguments, e.g. PYTEST_ARGS="-k config5"; PYTEST_PATHS
+#                replaces `tests` by a list of files)
 #   kscan        tools/k_scan.sh
 #   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations
 #   cli          bench.py's cli_end_to_end record alone
+#   ab-wt        A/B of the write-through store variants (tools/build_variant.sh wtN -DSVILS_WT=N first)
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -59,7 +61,7 @@ for step in "$@"; do
       python tools/pmc_traffic.py $O/traffic.json $O/hbm_traffic_pmc.txt $ARGS
       rm -rf $O/pmcf_* $O/pmcw_* ;;
     native) timeout 2400 python -m pytest tests/test_gpu_native_ranks.py tests/test_gpu_fakerccl_async.py -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_native.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_native.txt; tail -25 $O/pytest_native.txt ;;
-    pytest) timeout 3000 python -m pytest tests -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -25 $O/pytest_gpu.txt ;;
+    pytest) timeout 3000 python -m pytest ${PYTEST_PATHS:-tests} -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -25 $O/pytest_gpu.txt ;;
     kscan) bash tools/k_scan.sh 2>&1 | tee $O/k_scan_astroph.txt ;;
     shardcost)
       (cd /tmp; export TMPDIR=/tmp
@@ -71,6 +73,7 @@ for step in "$@"; do
          rm -rf $O/prof_$t
        done) ;;
     cli) python bench.py --cli-only > $O/bench_cli_end_to_end.json 2> $O/bench_cli.err; tail -c 1500 $O/bench_cli_end_to_end.json; echo ;;
+    ab-wt) bash tools/ab_libs.sh $O/ab_write_through_stores.txt libsvils.so libsvils_wt1.so libsvils_wt2.so libsvils_wt3.so ;;
     *) echo "unknown step $step" ;;
   esac
 done
