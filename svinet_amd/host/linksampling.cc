@@ -872,8 +872,9 @@ int LinkSampling::sweep_loop_pipelined() {
       rows_issued += new_rows;
       flight.push_back(f);
       timing_.chunks++;
-      if (!fixed_chunk && !flight.empty() && chunk < 16 && svils_report_ready(h_, flight.front().ticket) == 1 && flight.size() > 1)
-        chunk *= 2;     // the device finished a chunk before the host came back for it: the host is the slower side
+      // the device finished a chunk before the host came back for it: the host is the slower side -- longer chunks
+      // (a report costs the host ~0.1-1 ms of file writing, a sweep the device tens of microseconds)
+      if (!fixed_chunk && chunk < 16 && svils_report_ready(h_, flight.front().ticket) == 1) chunk *= 2;
     }
     if (flight.empty()) break;              // everything issued and reported: -max-iterations reached
     // ---- the oldest report: blocks until it has landed

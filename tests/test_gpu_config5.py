@@ -96,6 +96,55 @@ def test_config5_full_size_against_oracle_digest():
     assert list(eng.rows()[:, 0]) == list(want[1:, 0])
 
 
+def test_config5_full_size_planted_state_against_oracle_digest():
+    """The same full-size graph in the regime a long run ends in, which two sweeps from the seeded state never reach:
+    started from tools/make_config5_digest.py::planted_state (gamma = alpha + degree x planted membership) at _iter = 999,
+    the oracle ran four sweeps -- dense with prune() flagging the single-community nodes, dense with O(1) shortcuts and the
+    s3 pass on those flags (quirk Q2), then two sweeps past _iter = 1000 on the active-set branch
+    (src/linksampling.cc:622-681,731-746) -- and its digest is committed; the HIP run must match: link-branch counts of
+    every sweep and every flag exactly, lambda / gamma to 1e-9."""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+    from svinet_amd import mmsbgen_sparse as G
+    from svinet_amd.host_api import Setup
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = os.path.join(here, "golden", "config5")
+    meta = json.load(open(os.path.join(d, "digest_planted.json")))
+    dg = np.load(os.path.join(d, "digest_planted.npz"))
+    spec = importlib.util.spec_from_file_location("make_config5_digest", os.path.join(os.path.dirname(here), "tools", "make_config5_digest.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    n, k = meta["n"], meta["k"]
+    pairs, truth = G.generate(n, k, meta["mean_degree"], return_truth=True)
+    g0, lam0 = tool.planted_state(pairs, truth, n, k)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(g0) == meta["gamma0_sha256"]
+    s = Setup(n=n, k=k, pairs=pairs)
+    assert sha(s.links.astype(np.uint32)) == meta["links_sha256"] and sha(s.validation_sorted.astype(np.uint32)) == meta["validation_sha256"]
+    eng = s.engine(use_validation_stop=False)
+    eng.set_state(g0, lam0)
+    del g0
+    eng.set_control(iter=meta["iter0"])
+    nsw = meta["sweeps"]
+    eng.sweep(nsw)
+    st = eng.sweep_stats(0, nsw).astype(np.int64)
+    assert np.array_equal(st, dg["link_counts"]), (st, dg["link_counts"])
+    assert st[:, 2].max() > 1_000_000 and st[:, 1].max() > 1_000_000      # the shortcut and the active-set regime were entered
+    g, lam, conv = eng.state()
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))
+    assert rel(lam, dg["lam"]) < 1e-9
+    assert rel(g.sum(0), dg["gamma_colsum"]) < 1e-9
+    assert rel(g[dg["rows_idx"]], dg["gamma_rows"]) < 1e-9
+    assert np.array_equal(np.flatnonzero(conv).astype(np.uint32), dg["converged_idx"]) and dg["converged_idx"].size > 100_000
+    assert np.array_equal(conv[conv > 0], dg["converged_val"])
+    assert np.array_equal(np.bincount(eng.aux(3), minlength=k + 1), dg["active_hist"])
+    want = dg["likelihood_rows"]                        # row 0 is the seeded constructor's (before the planted state went in)
+    np.testing.assert_allclose(eng.rows()[:, 1:], want[1:, 1:], rtol=1e-9, atol=1e-13)
+    assert list(eng.rows()[:, 0]) == list(want[1:, 0])
+
+
 def test_hbm_bound_sweep_against_oracle():
     """three sweeps at n = 2e5, k = 512 on the planted MMSB graph: gamma / lambda within 1e-5 relative
     (the north-star bar; observed ~1e-13), flags, counters and the likelihood row equal"""

@@ -13,8 +13,8 @@ tests/test_gpu_config5.py::test_config5_full_size_against_oracle_digest compares
 
 Run in the BUILD container (needs ~25-30 GB of RAM and ~5 min per sweep on one core):
   python tools/make_config5_digest.py [sweeps=2]              -> digest.{json,npz}: from the seeded initial state
-  python tools/make_config5_digest.py --planted [sweeps=3]    -> digest_planted.{json,npz}: from planted_state() with
-        _iter = 1001 -- converged flags, shortcut links and the active-set branch at full size
+  python tools/make_config5_digest.py --planted [sweeps=4]    -> digest_planted.{json,npz}: from planted_state() with
+        _iter = 999 -- converged flags, shortcut links and the active-set branch at full size
 """
 import hashlib
 import json
@@ -42,10 +42,11 @@ def sha(a):
 
 def planted_state(pairs, truth, n, k):
     """A state NEAR the planted solution (the regime a long run ends in, which 2 sweeps from the seeded state never
-    reach at this size): gamma = alpha + degree x planted membership, lambda from the link budget.  From here the first
-    sweep's prune() flags the single-community nodes, the second takes O(1) shortcuts for their links and -- with _iter
-    set past 1000 -- the active-set branch for most of the others (src/linksampling.cc:622-681), the third exercises
-    the s3 pass on those flags (quirk Q2).  A pure function of the generator's output; the test recomputes it."""
+    reach at this size): gamma = alpha + degree x planted membership, lambda from the link budget.  With _iter set to 999
+    the first sweep is dense and its prune() flags the single-community nodes and fills the active sets, the second
+    (_iter = 1000, still dense) takes the O(1) shortcuts for their links and its s3 pass runs on those flags (quirk Q2),
+    the third and fourth (_iter > 1000) take the active-set branch for most of the other links
+    (src/linksampling.cc:622-681).  A pure function of the generator's output; the test recomputes it."""
     comm, w, _ = truth
     deg = np.bincount(pairs.ravel(), minlength=n).astype(np.float64)
     g = np.full((n, k), 1.0 / k)
@@ -60,7 +61,7 @@ def planted_state(pairs, truth, n, k):
 def main():
     planted = "--planted" in sys.argv
     nums = [a for a in sys.argv[1:] if a.isdigit()]
-    sweeps = int(nums[0]) if nums else (3 if planted else 2)
+    sweeps = int(nums[0]) if nums else (4 if planted else 2)
     from oracle import oracle as O
     from svinet_amd import mmsbgen_sparse as G
     t0 = time.time()
@@ -73,7 +74,7 @@ def main():
         ref.set_gamma(g0)
         ref.set_lambda(lam0)
         ref.refresh()
-        ref.iter = 1001
+        ref.iter = 999      # two dense sweeps (the first one's prune() sets the flags, the second takes the shortcuts), then _iter > 1000
     print("graph + constructor: %.0f s, %d training links" % (time.time() - t0, ref.nlinks), flush=True)
     counts = []
     for i in range(sweeps):
@@ -99,7 +100,7 @@ def main():
             "oracle": "oracle/svinet_oracle.c, sequential sweep (orc_ls_sweep)", "made_by": "tools/make_config5_digest.py",
             "wall_s": round(time.time() - t0)}
     if planted:
-        meta.update({"start": "planted_state() of this script, _iter = 1001", "gamma0_sha256": sha(g0), "iter0": 1001})
+        meta.update({"start": "planted_state() of this script, _iter = 999", "gamma0_sha256": sha(g0), "iter0": 999})
     json.dump(meta, open(os.path.join(out, stem + ".json"), "w"), indent=1)
     print(json.dumps(meta))
 
