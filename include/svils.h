@@ -74,7 +74,7 @@ typedef struct {
    * src/linksampling.cc:634 (svils_config_default).  The revision that produced the runs shipped
    * under example/ behaved like 0, which is how the tests reproduce them. */
   int32_t sparse_after_iter;
-  /* K-sharded handles (multi-GPU layout of DESIGN.md section 8): k_total != 0 means this handle holds the
+  /* K-sharded handles (multi-GPU layout of DESIGN.md section 6): k_total != 0 means this handle holds the
    * columns [k_begin, k_begin + k) of k_total communities for ALL n nodes; alpha stays 1/k_total,
    * gamma / lambda are passed and returned as that column slice.  0: the handle holds every column. */
   uint32_t k_begin, k_total;
@@ -343,7 +343,7 @@ int svils_step_sharded(svils_handle *h, uint32_t nsteps);
 int svils_gather_communities(svils_handle *h);
 
 /* ---- K-sharded sweeps: one process per GPU, every rank holds a column slice of all rows --------
- * The columns of a row are coupled in four places (DESIGN.md section 8); each is a buffer of partials
+ * The columns of a row are coupled in four places (DESIGN.md section 6); each is a buffer of partials
  * that must be SUMmed over the ranks between two phases (tests/test_ksharded_protocol.py is the protocol):
  *   svils_set_state (slices) -> phase KINIT_ROWS -> SUM KSH_ROWX -> phase KINIT_EXPAND        (once)
  *   per sweep: phase KDEN -> SUM KSH_DEN -> phase KPHI -> SUM KSH_ROWX -> phase KFIN -> SUM KSH_Q2

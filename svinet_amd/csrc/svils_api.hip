@@ -1628,7 +1628,7 @@ void step_window(const svils_handle *h, uint64_t t, uint32_t *b, uint32_t *e) {
   const uint32_t B = h->scfg.shard_block ? h->scfg.shard_block : h->geo.n;
   const uint32_t bn = (h->scfg.batch_nodes == 0 || h->scfg.batch_nodes > B) ? B : h->scfg.batch_nodes;
   const uint32_t nblocks = (B + bn - 1) / bn;
-  const uint32_t blk = (uint32_t)((t + h->scfg.seed) % nblocks);   // fixed cyclic order
+  const uint32_t blk = (uint32_t)((t + h->scfg.seed) % nblocks);   // fixed cyclic order (profiles/HISTORY.md section 6a)
   *b = blk * bn;
   *e = std::min(B, *b + bn);
 }

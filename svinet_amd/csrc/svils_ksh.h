@@ -1,4 +1,4 @@
-// svils_ksh.h -- K-sharded sweeps (included once, at the end of svils_device.hip, whose helpers it uses): every rank keeps the columns [K0, K0 + K) of all n rows (DESIGN.md section 8).
+// svils_ksh.h -- K-sharded sweeps (included once, at the end of svils_device.hip, whose helpers it uses): every rank keeps the columns [K0, K0 + K) of all n rows (DESIGN.md section 6).
 //
 // The sweep of src/linksampling.cc:556-790 couples the columns of a row in four places only: the softmax
 // denominator of a link, the row sum inside Elogpi = psi(gamma) - psi(sum_k gamma), the active-community

@@ -2,7 +2,7 @@
 
 The node-block layout (sharded.py) replicates the n-by-k state and all-gathers the gamma rows every sweep
 (n*k*8 bytes).  Here the state is split by columns instead; the columns of a row are coupled in four places
-only, each a buffer of partials SUMmed over the ranks between two phases (DESIGN.md section 8,
+only, each a buffer of partials SUMmed over the ranks between two phases (DESIGN.md section 6,
 svinet_amd/csrc/svils_ksh.h, tests/test_ksharded_protocol.py):
 
     DEN -> SUM den[L] -> PHI -> SUM rowx[3n] -> FIN -> SUM q2v[K] -> LAMBDA -> SUM vdot[V] -> STOP

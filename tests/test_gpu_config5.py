@@ -98,7 +98,8 @@ def test_config5_full_size_against_oracle_digest():
 
 def test_config5_full_size_planted_state_against_oracle_digest():
     """The same full-size graph in the regime a long run ends in, which two sweeps from the seeded state never reach:
-    started from tools/make_config5_digest.py::planted_state (gamma = alpha + degree x planted membership) at _iter = 999,
+    started from tools/make_config5_digest.py::planted_state (gamma = alpha + degree x planted membership) at _iter = 999 with
+    annealing off,
     the oracle ran four sweeps -- dense with prune() flagging the single-community nodes, dense with O(1) shortcuts and the
     s3 pass on those flags (quirk Q2), then two sweeps past _iter = 1000 on the active-set branch
     (src/linksampling.cc:622-681,731-746) -- and its digest is committed; the HIP run must match: link-branch counts of
@@ -126,7 +127,7 @@ def test_config5_full_size_planted_state_against_oracle_digest():
     eng = s.engine(use_validation_stop=False)
     eng.set_state(g0, lam0)
     del g0
-    eng.set_control(iter=meta["iter0"])
+    eng.set_control(iter=meta["iter0"], annealing=0)
     nsw = meta["sweeps"]
     eng.sweep(nsw)
     st = eng.sweep_stats(0, nsw).astype(np.int64)

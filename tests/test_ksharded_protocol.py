@@ -1,4 +1,4 @@
-"""CPU: the K-sharded multi-GPU layout sketched in DESIGN.md section 8, as a numpy PROTOCOL against the oracle.
+"""CPU: the K-sharded multi-GPU layout sketched in DESIGN.md section 6, as a numpy PROTOCOL against the oracle.
 
 Not product code and not a substitute for it: this pins the design claim that a rank holding only the
 columns [k0, k1) of every row can run the sweep of src/linksampling.cc:556-790 exactly, exchanging per

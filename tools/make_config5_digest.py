@@ -42,7 +42,8 @@ def sha(a):
 
 def planted_state(pairs, truth, n, k):
     """A state NEAR the planted solution (the regime a long run ends in, which 2 sweeps from the seeded state never
-    reach at this size): gamma = alpha + degree x planted membership, lambda from the link budget.  With _iter set to 999
+    reach at this size): gamma = alpha + degree x planted membership, lambda from the link budget, annealing off (as it is
+    late in a run).  With _iter set to 999
     the first sweep is dense and its prune() flags the single-community nodes and fills the active sets, the second
     (_iter = 1000, still dense) takes the O(1) shortcuts for their links and its s3 pass runs on those flags (quirk Q2),
     the third and fourth (_iter > 1000) take the active-set branch for most of the other links
@@ -74,6 +75,7 @@ def main():
         ref.set_gamma(g0)
         ref.set_lambda(lam0)
         ref.refresh()
+        ref.annealing = False   # (while annealing, gammanext *= ones / sum[k] makes EVERY node active in every column of below-half-average mass)
         ref.iter = 999      # two dense sweeps (the first one's prune() sets the flags, the second takes the shortcuts), then _iter > 1000
     print("graph + constructor: %.0f s, %d training links" % (time.time() - t0, ref.nlinks), flush=True)
     counts = []
@@ -100,7 +102,7 @@ def main():
             "oracle": "oracle/svinet_oracle.c, sequential sweep (orc_ls_sweep)", "made_by": "tools/make_config5_digest.py",
             "wall_s": round(time.time() - t0)}
     if planted:
-        meta.update({"start": "planted_state() of this script, _iter = 999", "gamma0_sha256": sha(g0), "iter0": 999})
+        meta.update({"start": "planted_state() of this script, _iter = 999, annealing off", "gamma0_sha256": sha(g0), "iter0": 999})
     json.dump(meta, open(os.path.join(out, stem + ".json"), "w"), indent=1)
     print(json.dumps(meta))
 
