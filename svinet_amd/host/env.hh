@@ -41,7 +41,7 @@ class Env {
     bool strid = false;
     // extensions of this build (not in the reference)
     int device = 0;
-    uint32_t sweep_batch = 0;   // sweeps enqueued per report chunk / between host polls; 0 = automatic (1, doubling to 16 while the host is the slower side)
+    uint32_t sweep_batch = 0;   // sweeps enqueued per report chunk / between host polls; 0 = automatic (1, 2, 4, 8, then 16)
     std::string outdir_root;    // directory in which the output dir is created ("" = cwd)
     bool write_files = true;    // false: library use (bench / tests), nothing touches the disk
     // mini-batch mode of -link-sampling (include/svils.h, svils_step): 0 = full sweeps (the reference's loop)

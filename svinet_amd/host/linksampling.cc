@@ -763,9 +763,17 @@ void LinkSampling::write_communities_file() {
   const std::vector<uint32_t> &s2i = network_.seq2id();
   // one pass over the tags: members of every community in node order, then sorted by external id
   std::vector<std::vector<uint32_t>> ids(k_);
-  for (uint32_t p = 0; p < n_; ++p) {
+  for (uint32_t p = 0; p < n_; ++p) {   // a node tags one or two communities: skip its zero bytes eight at a time
     const uint8_t *m = &member_[(size_t)p * k_];
-    for (uint32_t c = 0; c < k_; ++c)
+    uint32_t c = 0;
+    for (; c + 8 <= k_; c += 8) {
+      uint64_t w;
+      memcpy(&w, m + c, 8);
+      if (!w) continue;
+      for (uint32_t j = c; j < c + 8; ++j)
+        if (m[j]) ids[j].push_back(s2i[p]);
+    }
+    for (; c < k_; ++c)
       if (m[c]) ids[c].push_back(s2i[p]);
   }
   std::string out;
@@ -820,8 +828,8 @@ void LinkSampling::log_rows(const double *rows, uint32_t count, int why, double 
 // already past it.  What reaches the files is what the synchronous loop writes: every likelihood row in order,
 // max.txt, communities.txt -- except that a communities.txt which the NEXT landed report would overwrite at once is
 // not written (the file is rewritten from scratch by every report; only its latest content is observable), and the
-// final files always come from do_on_stop().  -sweep-batch B fixes the chunk at B sweeps; the default (0) starts at
-// one sweep per report and doubles the chunk up to 16 while the host is the slower side.
+// final files always come from do_on_stop().  -sweep-batch B fixes the chunk at B sweeps; the default (0) is 1, 2, 4, 8,
+// then 16 sweeps per report.
 int LinkSampling::sweep_loop_pipelined() {
   const uint64_t nlinks = links_.size() / 2;
   svils_control c;
@@ -872,9 +880,9 @@ int LinkSampling::sweep_loop_pipelined() {
       rows_issued += new_rows;
       flight.push_back(f);
       timing_.chunks++;
-      // the device finished a chunk before the host came back for it: the host is the slower side -- longer chunks
-      // (a report costs the host ~0.1-1 ms of file writing, a sweep the device tens of microseconds)
-      if (!fixed_chunk && chunk < 16 && svils_report_ready(h_, flight.front().ticket) == 1) chunk *= 2;
+      // automatic chunks: 1, 2, 4, 8, 16, 16, ... sweeps per report -- the first reports come at once, later ones every 16
+      // sweeps (a report costs the host ~0.5 ms of file writing, a sweep the device tens of microseconds)
+      if (!fixed_chunk && chunk < 16) chunk *= 2;
     }
     if (flight.empty()) break;              // everything issued and reported: -max-iterations reached
     // ---- the oldest report: blocks until it has landed

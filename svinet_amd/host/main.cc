@@ -76,7 +76,7 @@ static void usage() {
           "\t\t\tper sweep four all-reduces of O(links) doubles instead of an all-gather of the rows) -- the\n"
           "\t\t\tlayout for large K (-link-thresh < 0.5 adds two exchanges of one double per link: the arg-max tagging rule);\n"
           "\t\t\twith -minibatch <m> every GPU steps through the same windows of m nodes on its own columns\n\n"
-          "\t-sweep-batch <b>\tsweeps per report chunk (default 0 = automatic: one sweep per report at first, doubling to 16\n\t\t\t\twhile the host is the slower side; reports are written while the device sweeps on)\n\n"
+          "\t-sweep-batch <b>\tsweeps per report chunk (default 0 = automatic: 1, 2, 4, 8, then 16 sweeps per report;\n\t\t\t\treports are written while the device sweeps on)\n\n"
           "\t-sparse-after <i>\tthe active-set branch of the phi pass is used once the iteration count exceeds i\n"
           "\t\t\t(default 1000, the reference's constant)\n\n"
           "\t-minibatch <m>\tmini-batch mode of -link-sampling: one step = the links of m randomly chosen nodes,\n"

@@ -265,6 +265,32 @@ def test_cli_gpus_ranks_files_equal_oracle(graph_files, tmp_path, world, extra):
     assert calls > M
 
 
+def test_cli_gpus_load_test_ranks(graph_files, tmp_path):
+    """`svinet -gpus 2 -load-test FILE`: the test set on node-block shards (every rank holds the replicated state and
+    records the same test rows; rank 0 writes test.txt) -- files against the oracle's counterpart"""
+    net = O.Network(graph_files["lfr"], 1000)
+    s2i, e = net.seq2id(), net.edges()
+    tp = np.concatenate([e[11::89], [[5, 800], [40, 77]]]).astype(np.uint32)
+    tf = tmp_path / "test_pairs.txt"
+    tf.write_text("".join("%d\t%d\n" % (s2i[a], s2i[b]) for a, b in tp))
+    M = 30
+    r = _cli(tmp_path, ["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop", "-max-iterations", str(M),
+                        "-load-test", str(tf), "-sweep-batch", "5"], 2)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = tmp_path / "n1000-k28-mmsb-linksampling"
+    ref = O.LinkSampling(net, 28, use_validation_stop=False, max_iterations=M, test_pairs=tp)
+    while ref.sweep() == 0:
+        pass
+    rd = tmp_path / "ref"
+    ref.write_model(str(rd))
+    _cmp_numeric(d / "gamma.txt", rd / "gamma.txt", 2, 1.1e-5)
+    _cmp_numeric(d / "lambda.txt", rd / "lambda.txt", 1, 1.1e-5)
+    assert (d / "communities.txt").read_text() == (rd / "communities.txt").read_text()
+    t = np.loadtxt(d / "test.txt")
+    assert t.shape == (M + 1, 11)
+    np.testing.assert_allclose(np.delete(t, 1, axis=1), ref.test_rows, rtol=0, atol=6e-10)
+
+
 def test_cli_gpus_minibatch_ranks(graph_files, tmp_path):
     """`svinet -gpus 2 -minibatch m`: svils_step_sharded behind the forked command line (relabelling on every rank,
     shard_block, the window broadcasts).  Two ranks stepping through windows of m nodes of their own blocks visit the

@@ -49,6 +49,13 @@ def planted_state(pairs, truth, n, k):
     the third and fourth (_iter > 1000) take the active-set branch for most of the other links
     (src/linksampling.cc:622-681).  A pure function of the generator's output; the test recomputes it."""
     comm, w, _ = truth
+    # the generator's memberships are four comparable components per node (Dirichlet(0.05) over 512 columns, truncated to
+    # its top 4), which never collapse to one: every third node is made PURE in its strongest community here, so that
+    # prune() has nodes to flag converged (active == 1) and the O(1) shortcut branch has links to take
+    w = w.copy()
+    pure = (np.arange(n) % 3) == 0
+    w[pure, 0] = 1.0
+    w[pure, 1:] = 0.0
     deg = np.bincount(pairs.ravel(), minlength=n).astype(np.float64)
     g = np.full((n, k), 1.0 / k)
     rows = np.repeat(np.arange(n), comm.shape[1])
