@@ -42,16 +42,16 @@ def sha(a):
 
 def planted_state(pairs, truth, n, k):
     """A state NEAR the planted solution (the regime a long run ends in, which 2 sweeps from the seeded state never
-    reach at this size): gamma = alpha + degree x planted membership, lambda from the link budget, annealing off (as it is
-    late in a run).  With _iter set to 999
-    the first sweep is dense and its prune() flags the single-community nodes and fills the active sets, the second
-    (_iter = 1000, still dense) takes the O(1) shortcuts for their links and its s3 pass runs on those flags (quirk Q2),
-    the third and fourth (_iter > 1000) take the active-set branch for most of the other links
-    (src/linksampling.cc:622-681).  A pure function of the generator's output; the test recomputes it."""
+    reach at this size): gamma = alpha + degree x planted membership with every third node PURE in its strongest
+    community and carrying that community's converged flag, lambda from the link budget, annealing off (as it is late in
+    a run).  With _iter set to 999 the first two sweeps are dense with O(1) shortcuts for the links that have exactly one
+    flagged endpoint (44 % of them) and the s3 pass runs on those flags (quirk Q2); the third and fourth (_iter > 1000)
+    also take the active-set branch wherever both endpoints have fewer than K/10 active communities
+    (src/linksampling.cc:622-681).  A pure function of the generator's output; the test recomputes it.
+    -> gamma [n][k], lambda [k][2], converged [n]"""
     comm, w, _ = truth
     # the generator's memberships are four comparable components per node (Dirichlet(0.05) over 512 columns, truncated to
-    # its top 4), which never collapse to one: every third node is made PURE in its strongest community here, so that
-    # prune() has nodes to flag converged (active == 1) and the O(1) shortcut branch has links to take
+    # its top 4), which never collapse to one: every third node is made PURE in its strongest community here
     w = w.copy()
     pure = (np.arange(n) % 3) == 0
     w[pure, 0] = 1.0
@@ -63,7 +63,12 @@ def planted_state(pairs, truth, n, k):
     lam = np.empty((k, 2))
     lam[:, 0] = 1.0 + 2.0 * pairs.shape[0] / k
     lam[:, 1] = 1.0 + 20.0 * pairs.shape[0] / k
-    return g, lam
+    # ... and those nodes carry the converged flag of that community from the start (the sticky _converged[] of
+    # src/linksampling.cc:455-475, handed over like -load would have to): left to itself the model spreads a pure node
+    # over its neighbours' communities again within one sweep, and no flag would ever be set on this graph
+    conv = np.zeros(n, dtype=np.uint32)
+    conv[pure] = comm[pure, 0].astype(np.uint32) + 1
+    return g, lam, conv
 
 
 def main():
@@ -78,9 +83,10 @@ def main():
     ref = O.LinkSampling(net, K, use_validation_stop=False)
     g0 = None
     if planted:
-        g0, lam0 = planted_state(pairs, truth, N, K)
+        g0, lam0, conv0 = planted_state(pairs, truth, N, K)
         ref.set_gamma(g0)
         ref.set_lambda(lam0)
+        ref.set_converged(conv0)
         ref.refresh()
         ref.annealing = False   # (while annealing, gammanext *= ones / sum[k] makes EVERY node active in every column of below-half-average mass)
         ref.iter = 999      # two dense sweeps (the first one's prune() sets the flags, the second takes the shortcuts), then _iter > 1000
@@ -109,7 +115,7 @@ def main():
             "oracle": "oracle/svinet_oracle.c, sequential sweep (orc_ls_sweep)", "made_by": "tools/make_config5_digest.py",
             "wall_s": round(time.time() - t0)}
     if planted:
-        meta.update({"start": "planted_state() of this script, _iter = 999, annealing off", "gamma0_sha256": sha(g0), "iter0": 999})
+        meta.update({"start": "planted_state() of this script (gamma, lambda, converged flags), _iter = 999, annealing off", "gamma0_sha256": sha(g0), "iter0": 999})
     json.dump(meta, open(os.path.join(out, stem + ".json"), "w"), indent=1)
     print(json.dumps(meta))
 
