@@ -28,20 +28,6 @@
 
 namespace svils {
 
-// Row stores of the small-K passes.  A launch that leaves B bytes dirty in the XCD L2s pays ~0.6 us per MB at its end
-// (the kernel-end release writes them back before the next launch may read them from another XCD).  SVILS_WT (A/B
-// macro: bit 0 = the finalise pass's gamma / Elogpi / mphi rows, bit 1 = the phi pass's pieces) issues them as
-// agent-scope relaxed atomic stores instead (global_store ... sc1: write-through, the line does not stay dirty), so
-// that the bytes drain while the launch is still computing.
-#ifndef SVILS_WT
-#define SVILS_WT 0
-#endif
-template <int BIT>
-__device__ __forceinline__ void row_store(double *p, double v) {
-  if constexpr ((SVILS_WT >> BIT) & 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
 // LDS row stride in doubles: an odd number of 16-byte chunks, so the 8-lane groups
 // of ds_write_b128 hit distinct slots
 template <int KC>
@@ -450,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ?
       if ((vmask >> a) & 1ull) {                                                            \
         const uint32_t cur = __builtin_amdgcn_readlane(p, a);                               \
         double *dst = (DST);                                                                \
-        row_store<1>(&dst[lane], acc);                                                      \
+        dst[lane] = acc;                                                                    \
         csum += acc;                                                                        \
         if (any_tag) {                                                                      \
           const unsigned long long runmask = (((B) >= 63) ? ~0ull : ((2ull << (B)) - 1ull)) & ~((1ull << a) - 1ull); \
@@ -824,7 +810,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
           if (kv[j]) gn[j] = (1.0 - rho) * gold[j] + rho * gn[j];
           if (kv[j] && ok) { s1[j] -= sold[j]; s2[j] -= sold[j] * sold[j]; }
         }
-        if ((STOCH || !d.derive_m) && ST(j)) row_store<0>(&d.mphi[rowoff + j * FW], m[j]);
+        if ((STOCH || !d.derive_m) && ST(j)) d.mphi[rowoff + j * FW] = m[j];
       }
     } else {
       // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
@@ -834,7 +820,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     double rsl = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      if (ST(j)) row_store<0>(&d.gamma[rowoff + j * FW], gn[j]);   // padding columns stay 0
+      if (ST(j)) d.gamma[rowoff + j * FW] = gn[j];   // padding columns stay 0
       rsl += gn[j];
     }
     const double rs = group_sum<FW>(rsl);
@@ -853,7 +839,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     unsigned long long bits = 0ull;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      if (ST(j)) row_store<0>(&d.elogpi[rowoff + j * FW], kv[j] ? ps[j] - psi_rs : 0.0);
+      if (ST(j)) d.elogpi[rowoff + j * FW] = kv[j] ? ps[j] - psi_rs : 0.0;
       // prune / check_and_set_converged, src/linksampling.cc:455-475
       bits |= ((__ballot(kv[j] && (gn[j] - prm.alpha >= 1.0)) >> (g * FW)) & group_mask<FW>()) << (j * FW);
     }

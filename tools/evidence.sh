@@ -18,7 +18,7 @@
 #   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations
 #   cli          bench.py's cli_end_to_end record alone
 #   cliff        per-kernel times and sweep time on ca-AstroPh at K = 20 / 22 / 24 (the register cliff of the small-K kernels)
-#   ab-wt        A/B of the write-through store variants (tools/build_variant.sh wtN -DSVILS_WT=N first)
+#   ab-mid12     A/B of tools/build_variant.sh mid12 -DLPL_MID_KC=12 (K = 21..24 phi in the 4-wave block shape)
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -75,7 +75,7 @@ for step in "$@"; do
        done) ;;
     cli) python bench.py --cli-only > $O/bench_cli_end_to_end.json 2> $O/bench_cli.err; tail -c 1500 $O/bench_cli_end_to_end.json; echo ;;
     cliff) for k in 20 22 24; do python tools/kernel_times.py astroph-k$k 100 2>/dev/null | tail -1; python bench.py --workload astroph-k$k --steps 100 --warmup 5 --reps 20 --no-hbm-bound --no-config5 --no-cpu-baseline --no-cli 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('astroph-k$k graph-replayed sweep %.2f us' % (d['ms_per_step']*1e3))"; done | tee $O/k20_k24_cliff_kernel_times.txt ;;
-    ab-wt) bash tools/ab_libs.sh $O/ab_write_through_stores.txt libsvils.so libsvils_wt1.so libsvils_wt2.so libsvils_wt3.so ;;
+    ab-mid12) WLS="astroph-k22 astroph-k24 astroph-k20 lfr-k28" bash tools/ab_libs.sh $O/ab_mid_kc12.txt libsvils.so libsvils_mid12.so ;;
     *) echo "unknown step $step" ;;
   esac
 done
