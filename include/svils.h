@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 4   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info */
+#define SVILS_ABI_VERSION 5   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags */
 
 typedef enum {
   SVILS_OK = 0,
@@ -212,6 +212,15 @@ int svils_report_ready(svils_handle *h, int ticket);     /* 1 = landed, 0 = not 
 /* ctrl: as svils_get_control at the snapshot; rows: [row_count][10], *nrows = how many of them exist
  * (min(ctrl.rows, row_first + row_count) - row_first); member: [n][k] as svils_get_communities, or NULL.  Frees the slot. */
 int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows, uint8_t *member);
+/* The communities of a report as (node, community) PAIRS -- what communities.txt is made of (src/linksampling.cc:882-917
+ * walks the map community -> members) -- instead of the n x k byte matrix (n = 1e6, k = 512: 512 MB and a pass over it per
+ * report, against ~1e6 pairs).  tags[2i] = node, tags[2i+1] = community, by ascending node (a node's communities in no
+ * particular order).  svils_report_tag_count blocks until the report has landed and says how many pairs it holds (the slot
+ * is kept); svils_report_fetch_tags is svils_report_fetch with the pairs in place of `member`: `cap` = room in pairs,
+ * *ntags = pairs that exist; if they do not fit nothing is freed and SVILS_ERR_ARG comes back. */
+int svils_report_tag_count(svils_handle *h, int ticket, uint64_t *ntags);
+int svils_report_fetch_tags(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows,
+                            uint32_t *tags, uint64_t cap, uint64_t *ntags);
 /* the TEST rows of the same report (svils_set_test): test_rows [row_count][10]; call it BEFORE svils_report_fetch (which
  * frees the slot); blocks until the report has landed.  *ntest = rows that exist: one per validation row, minus the one
  * of the stopping sweep. */
@@ -228,6 +237,8 @@ int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *co
 /* communities of the last tagging sweep (src/linksampling.cc:704-717,882-917):
  * member[n][k] bytes, 1 = node p belongs on line k of communities.txt. */
 int svils_get_communities(svils_handle *h, uint8_t *member);
+/* the same as (node, community) pairs (see svils_report_fetch_tags); tags == NULL (cap 0): only the count */
+int svils_get_community_tags(svils_handle *h, uint32_t *tags, uint64_t cap, uint64_t *ntags);
 
 /* Derived device arrays for parity tests and integrators:
  * which = 0 Elogpi [n][k], 1 Elogbeta [k][2], 2 mphi [n][k],

@@ -31,6 +31,7 @@ EXPORTS = (
     "svils_comm_allgather_host", "svils_step_sharded", "svils_step_ksharded", "svils_comm_query",
     "svils_report_enqueue", "svils_report_ready", "svils_report_fetch", "svils_report_test_rows",
     "svils_set_test", "svils_get_test_rows",
+    "svils_report_tag_count", "svils_report_fetch_tags", "svils_get_community_tags",
 )
 
 
@@ -135,6 +136,10 @@ def load():
     L.svils_report_test_rows.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_uint32)]
     L.svils_set_test.argtypes = [vp, vp, C.c_uint64]
     L.svils_get_test_rows.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.svils_report_tag_count.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.svils_report_fetch_tags.argtypes = [vp, C.c_int, C.POINTER(Control), vp, C.POINTER(C.c_uint32), vp, C.c_uint64,
+                                          C.POINTER(C.c_uint64)]
+    L.svils_get_community_tags.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
@@ -328,6 +333,14 @@ class Engine:
         _chk(load().svils_get_communities(self._h, m.ctypes.data))
         return m
 
+    def community_tags(self):
+        """the same communities as (node, community) pairs [ntags][2] (svils_get_community_tags)"""
+        nt = C.c_uint64()
+        _chk(load().svils_get_community_tags(self._h, None, 0, C.byref(nt)))
+        t = np.zeros((max(nt.value, 1), 2), dtype=np.uint32)
+        _chk(load().svils_get_community_tags(self._h, t.ctypes.data, nt.value, C.byref(nt)))
+        return t[:nt.value]
+
     def aux(self, which):
         shapes = {0: ((self.n, self.k), np.float64), 1: ((self.k, 2), np.float64),
                   2: ((self.n, self.k), np.float64), 3: ((self.n,), np.uint32),
@@ -395,6 +408,19 @@ class Engine:
         _chk(load().svils_report_fetch(self._h, ticket, C.byref(c), rows.ctypes.data, C.byref(nr),
                                        m.ctypes.data if with_communities else None))
         return c, rows[:nr.value], m
+
+    def report_fetch_tags(self, ticket, row_count, cap=None):
+        """-> (Control, rows [have][10], tags [ntags][2]); cap: room offered (default: what svils_report_tag_count says)"""
+        nt = C.c_uint64()
+        if cap is None:
+            _chk(load().svils_report_tag_count(self._h, ticket, C.byref(nt)))
+            cap = nt.value
+        c, nr = Control(), C.c_uint32()
+        rows = np.zeros((max(row_count, 1), 10), dtype=np.float64)
+        t = np.zeros((max(cap, 1), 2), dtype=np.uint32)
+        _chk(load().svils_report_fetch_tags(self._h, ticket, C.byref(c), rows.ctypes.data, C.byref(nr), t.ctypes.data, cap,
+                                            C.byref(nt)))
+        return c, rows[:nr.value], t[:nt.value]
 
     # ---- native multi-GPU driver (RCCL inside the library) ----
     def comm_init(self, comm_id, rank, world):

@@ -1945,6 +1945,60 @@ int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double 
   return 0;
 }
 
+namespace {
+// (node, community) pairs of a lane-layout community bitmask [n][kw]; counts them all, writes at most `cap`
+uint64_t tags_of_bits(const Geometry &g, const uint64_t *bits, uint32_t *tags, uint64_t cap) {
+  uint64_t cnt = 0;
+  for (uint32_t p = 0; p < g.n; ++p)
+    for (int v = 0; v < g.V; ++v) {
+      uint64_t b = bits[(size_t)p * g.kw + v];
+      while (b) {
+        const int lw = __builtin_ctzll(b);
+        b &= b - 1;
+        const uint32_t k = kmap_host(g.W, g.V, lw, v);
+        if (k >= g.K) continue;
+        if (tags && cnt < cap) { tags[2 * cnt] = p; tags[2 * cnt + 1] = k; }
+        ++cnt;
+      }
+    }
+  return cnt;
+}
+}  // namespace
+
+int svils_report_tag_count(svils_handle *h, int ticket, uint64_t *ntags) {
+  if (!h || !ntags || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_tag_count: bad ticket");
+  svils_handle::ReportSlot &rs = h->rslot[ticket];
+  if (!rs.with_member) return fail(SVILS_ERR_ARG, "svils_report_tag_count: this report was enqueued without communities");
+  HIPCHK(hipEventSynchronize(rs.landed));
+  *ntags = tags_of_bits(h->geo, (const uint64_t *)(rs.host + h->rlay.off_member), nullptr, 0);
+  return 0;
+}
+
+int svils_report_fetch_tags(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows,
+                            uint32_t *tags, uint64_t cap, uint64_t *ntags) {
+  if (!h || !ntags || (!tags && cap)) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: null argument");
+  if (ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: bad ticket");
+  if (!h->rslot[ticket].with_member) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: this report was enqueued without communities");
+  HIPCHK(hipEventSynchronize(h->rslot[ticket].landed));
+  const uint64_t cnt = tags_of_bits(h->geo, (const uint64_t *)(h->rslot[ticket].host + h->rlay.off_member), tags, cap);
+  *ntags = cnt;
+  if (cnt > cap) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: %llu tags, room for %llu (svils_report_tag_count says how many); the slot is kept",
+                             (unsigned long long)cnt, (unsigned long long)cap);
+  return svils_report_fetch(h, ticket, ctrl, rows, nrows, nullptr);
+}
+
+int svils_get_community_tags(svils_handle *h, uint32_t *tags, uint64_t cap, uint64_t *ntags) {
+  if (!h || !ntags || (!tags && cap)) return fail(SVILS_ERR_ARG, "svils_get_community_tags: null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const Geometry &g = h->geo;
+  std::vector<uint64_t> bits((size_t)g.n * g.kw);
+  HIPCHK(hipMemcpy(bits.data(), h->d.member, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  *ntags = tags_of_bits(g, bits.data(), tags, cap);
+  if (tags && *ntags > cap) return fail(SVILS_ERR_ARG, "svils_get_community_tags: %llu tags, room for %llu", (unsigned long long)*ntags, (unsigned long long)cap);
+  return 0;
+}
+
 int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *converged) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_get_state: null handle");
   HIPCHK(hipSetDevice(h->cfg.device));

@@ -643,12 +643,15 @@ void LinkSampling::fetch_communities_ksharded() {
   for (uint32_t i = 0; i < n_; ++i) std::copy(&mine[(size_t)i * w], &mine[(size_t)i * w] + w, &send[(size_t)i * wmax]);
   if (svils_comm_allgather_host(h_, send.data(), all.data(), send.size())) die_svils("svils_comm_allgather_host");
   if (!env_.write_files) return;   // the other ranks only take part in the collective; rank 0 writes
-  member_.assign((size_t)n_ * k_, 0);
-  for (uint32_t r = 0; r < G; ++r) {
-    const uint32_t a = (uint32_t)((uint64_t)k_ * r / G), b = (uint32_t)((uint64_t)k_ * (r + 1) / G);
-    const uint8_t *src = &all[(size_t)r * send.size()];
-    for (uint32_t i = 0; i < n_; ++i) std::copy(src + (size_t)i * wmax, src + (size_t)i * wmax + (b - a), &member_[(size_t)i * k_ + a]);
-  }
+  // the ranks' column slices -> (node, community) pairs in node order
+  tags_.clear();
+  for (uint32_t i = 0; i < n_; ++i)
+    for (uint32_t r = 0; r < G; ++r) {
+      const uint32_t a = (uint32_t)((uint64_t)k_ * r / G), b = (uint32_t)((uint64_t)k_ * (r + 1) / G);
+      const uint8_t *src = &all[(size_t)r * send.size() + (size_t)i * wmax];
+      for (uint32_t c = 0; c < b - a; ++c)
+        if (src[c]) { tags_.push_back(i); tags_.push_back(a + c); }
+    }
 }
 
 void LinkSampling::write_groups() {                        // src/linksampling.cc:1452-1476
@@ -665,9 +668,11 @@ void LinkSampling::write_groups() {                        // src/linksampling.c
 }
 
 void LinkSampling::log_communities() {                     // :839-852, :882-917
-  if (!env_.kshard) {   // -kshard: fetch_communities_ksharded() has filled member_ on every rank
-    member_.assign((size_t)n_ * k_, 0);
-    if (svils_get_communities(h_, member_.data())) die_svils("svils_get_communities");
+  if (!env_.kshard) {   // -kshard: fetch_communities_ksharded() has filled tags_ on rank 0
+    uint64_t nt = 0;
+    if (svils_get_community_tags(h_, nullptr, 0, &nt)) die_svils("svils_get_community_tags");
+    tags_.resize(2 * (size_t)nt);
+    if (svils_get_community_tags(h_, tags_.data(), nt, &nt)) die_svils("svils_get_community_tags");
   }
   write_communities_file();
 }
@@ -754,34 +759,36 @@ void LinkSampling::send_graph() {
 
 // communities.txt of a report (src/linksampling.cc:839-852,882-917) from tags already on the host
 void LinkSampling::write_communities_file() {
-  if (!dev_of_.empty()) {
-    std::vector<uint8_t> t((size_t)n_ * k_);
-    for (uint32_t i = 0; i < n_; ++i)
-      std::copy(&member_[(size_t)dev_of_[i] * k_], &member_[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
-    member_.swap(t);
-  }
   const std::vector<uint32_t> &s2i = network_.seq2id();
-  // one pass over the tags: members of every community in node order, then sorted by external id
-  std::vector<std::vector<uint32_t>> ids(k_);
-  for (uint32_t p = 0; p < n_; ++p) {   // a node tags one or two communities: skip its zero bytes eight at a time
-    const uint8_t *m = &member_[(size_t)p * k_];
-    uint32_t c = 0;
-    for (; c + 8 <= k_; c += 8) {
-      uint64_t w;
-      memcpy(&w, m + c, 8);
-      if (!w) continue;
-      for (uint32_t j = c; j < c + 8; ++j)
-        if (m[j]) ids[j].push_back(s2i[p]);
-    }
-    for (; c < k_; ++c)
-      if (m[c]) ids[c].push_back(s2i[p]);
+  // one pass over the (device row, community) pairs -- a node tags one or two communities, so this is O(n), not the
+  // O(n k) of a pass over the tag matrix (n = 1e6, k = 512: 512 MB per report) -- then every community sorted by external id
+  // ... visited in the order of the external ids (a counting sort of the pairs by the node's rank in that order, the ranks
+  // computed once per run), so that every community's member list comes out sorted and no per-report sort is needed
+  if (ext_rank_.empty()) {
+    std::vector<uint32_t> order(n_);
+    for (uint32_t i = 0; i < n_; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s2i[a] < s2i[b]; });
+    ext_rank_.resize(n_);
+    for (uint32_t r = 0; r < n_; ++r) ext_rank_[order[r]] = r;
   }
+  const size_t nt = tags_.size() / 2;
+  std::vector<uint32_t> start((size_t)n_ + 1, 0), slot(2 * nt);
+  auto seq_of_tag = [&](size_t i) { return dev_of_.empty() ? tags_[2 * i] : seq_of_[tags_[2 * i]]; };   // device rows back to sequence ids
+  for (size_t i = 0; i < nt; ++i) start[ext_rank_[seq_of_tag(i)] + 1]++;
+  for (uint32_t r = 0; r < n_; ++r) start[r + 1] += start[r];
+  for (size_t i = 0; i < nt; ++i) {
+    const uint32_t p = seq_of_tag(i);
+    const uint32_t at = start[ext_rank_[p]]++;
+    slot[2 * (size_t)at] = s2i[p];
+    slot[2 * (size_t)at + 1] = tags_[2 * i + 1];
+  }
+  std::vector<std::vector<uint32_t>> ids(k_);
+  for (size_t i = 0; i < nt; ++i) ids[slot[2 * i + 1]].push_back(slot[2 * i]);
   std::string out;
   Cover found;
   char buf[16];
   for (uint32_t c = 0; c < k_; ++c) {
     if (ids[c].empty()) continue;            // empty communities have no map entry => no line
-    std::sort(ids[c].begin(), ids[c].end());
     for (uint32_t id : ids[c]) {             // "%d " per member
       char *e = buf + sizeof buf;
       char *b = e;
@@ -893,11 +900,15 @@ int LinkSampling::sweep_loop_pipelined() {
     // (-nmi scores every report's communities -- one mutual.txt line per report, :843-851 -- so nothing is skipped then)
     const bool superseded = !env_.nmi && !flight.empty() && flight.front().with_comm && svils_report_ready(h_, flight.front().ticket) == 1;
     const bool want_comm = f.with_comm && env_.write_files && !superseded;
-    if (want_comm) member_.assign((size_t)n_ * k_, 0);
     uint32_t have_t = 0;
     const bool with_test = !test_sorted_.empty() && !env_.accuracy;
     if (with_test && svils_report_test_rows(h_, f.ticket, trows.data(), &have_t)) die_svils("svils_report_test_rows");
-    if (svils_report_fetch(h_, f.ticket, &c, rows.data(), &have, want_comm ? member_.data() : nullptr)) die_svils("svils_report_fetch");
+    if (want_comm) {
+      uint64_t nt = 0;
+      if (svils_report_tag_count(h_, f.ticket, &nt)) die_svils("svils_report_tag_count");
+      tags_.resize(2 * (size_t)nt);
+      if (svils_report_fetch_tags(h_, f.ticket, &c, rows.data(), &have, tags_.data(), nt, &nt)) die_svils("svils_report_fetch_tags");
+    } else if (svils_report_fetch(h_, f.ticket, &c, rows.data(), &have, nullptr)) die_svils("svils_report_fetch");
     const double t0 = now_s();
     // (without a test set every report that does not end the run still gets its row of 0/0 ratios)
     if (!with_test) have_t = (c.stopped && have && rows_logged_ + have == c.rows) ? have - 1 : have;

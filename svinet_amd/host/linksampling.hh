@@ -71,7 +71,7 @@ class LinkSampling {
   void write_max(const double *row, int why, double max_h) const;
   void do_on_stop_impl();
   void log_communities();
-  void write_communities_file();               // communities.txt (+ mutual.txt) from member_
+  void write_communities_file();               // communities.txt (+ mutual.txt) from tags_
   void log_rows(const double *rows, uint32_t count, int why, double max_h, const double *test, uint32_t ntest);   // validation.txt, test.txt, max.txt
   int sweep_loop_pipelined();                  // reports taken off the device's critical path (svils_report_*)
   // one whole-graph engine driving full sweeps: the pipelined loop; SVINET_SYNC_REPORTS=1 keeps the per-batch synchronous one
@@ -79,7 +79,7 @@ class LinkSampling {
   void send_graph();                           // training links to the device (once)
   int sweep_loop();                            // the body of infer()
   void fetch_state_ksharded(std::vector<double> &g, std::vector<double> &l);   // -kshard: merged gamma / lambda (collective)
-  void fetch_communities_ksharded();           // -kshard: merged member_ (collective)
+  void fetch_communities_ksharded();           // -kshard: merged tags_ (collective)
   void write_groups();
   uint32_t duration() const { return (uint32_t)(time(0) - start_time_); }
   bool fetch_and_log_rows();
@@ -97,10 +97,11 @@ class LinkSampling {
   std::vector<uint32_t> links_;
   bool links_done_ = false;
   uint32_t k0_ = 0, k1_ = 0;                   // -kshard: this rank's columns
-  std::vector<uint8_t> member_;                // last downloaded communities [n][k]
+  std::vector<uint32_t> tags_;                 // last downloaded communities: (device row, community) pairs (svils_get_community_tags)
   // mini-batch mode: nodes are handed to the device under a random relabelling so that a window of
   // consecutive device ids is a uniform random subset; dev_of_[seq] / seq_of_[dev], empty otherwise
   std::vector<uint32_t> dev_of_, seq_of_;
+  std::vector<uint32_t> ext_rank_;             // rank of a sequence id in the order of the external ids (communities.txt lists members by external id)
   Cover ground_truth_;                         // -nmi: the reference cover (external ids)
   svils_handle *h_ = nullptr;
   bool graph_sent_ = false;

@@ -4,8 +4,8 @@ HBM-bound parity point against the oracle.
 At n = 10^6 the oracle needs ~155 s per sweep: too slow to run beside the test, so the full-size parity check
 compares with a DIGEST of the oracle's state that tools/make_config5_digest.py produced in the build container
 (tests/golden/config5/).  The full-size run is also checked through the size-independent properties of the sweep
-(tests/test_gpu_properties.py), and one size down (n = 2*10^5, k = 512: 0.82 GB per n-by-k array, far outside the
-256 MB Infinity Cache, the same kernels and layouts) against the oracle running live.
+(tests/test_gpu_properties.py), and at n = 10^5, k = 512 (0.41 GB per n-by-k array, outside the 256 MB Infinity Cache,
+the same kernels and layouts) against the oracle running live.
 """
 import numpy as np
 import pytest
@@ -13,12 +13,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_config5_full_size_invariants():
+@pytest.fixture(scope="module")
+def config5():
+    """the full-size graph, its planted truth and the host side (LinkSampling ls(env, network): held-out set, seeded
+    gamma -- ~25 s of host work, 4.1 GB) ONCE for the three full-size tests; every test builds its own engines from it"""
     from svinet_amd import mmsbgen_sparse as G
     from svinet_amd.host_api import Setup
     n, k = 1_000_000, 512
-    pairs = G.generate(n, k, 24)
+    pairs, truth = G.generate(n, k, 24, return_truth=True)
     s = Setup(n=n, k=k, pairs=pairs)
+    yield n, k, pairs, truth, s
+    s.close()
+
+
+def test_config5_full_size_invariants(config5):
+    n, k, pairs, _, s = config5
     assert s.n == n and s.singles == 0                     # SURVEY 8d: no isolated node, so -n 1000000 holds (Q9)
     L = int(s.nlinks)
     assert 1.0e7 < L < 6.0e7                               # below the reference's 6e7-link cap (Q6)
@@ -49,9 +58,11 @@ def test_config5_full_size_invariants():
     rows = e1.rows()
     assert np.isfinite(rows).all() and list(rows[:, 0]) == [0.0, 1.0] and rows[0, 2] == s.validation_sorted.shape[0]
     assert np.array_equal(rows, e2.rows())
+    e1.close()
+    e2.close()
 
 
-def test_config5_full_size_against_oracle_digest():
+def test_config5_full_size_against_oracle_digest(config5):
     """BASELINE config 5 at FULL size (n = 1,000,000, k = 512) against the ORACLE: tools/make_config5_digest.py ran the
     sequential oracle for 2 sweeps on this graph in the build container (~2.5 min per sweep, 25 GB -- too slow to repeat
     on the GPU box) and committed a digest of its state (tests/golden/config5/); the HIP run must reproduce it --
@@ -60,14 +71,11 @@ def test_config5_full_size_against_oracle_digest():
     import hashlib
     import json
     import os
-    from svinet_amd import mmsbgen_sparse as G
-    from svinet_amd.host_api import Setup
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5")
     meta = json.load(open(os.path.join(d, "digest.json")))
     dg = np.load(os.path.join(d, "digest.npz"))
-    n, k = meta["n"], meta["k"]
-    assert (n, k) == (1_000_000, 512)
-    s = Setup(n=n, k=k, pairs=G.generate(n, k, meta["mean_degree"]))
+    n, k, _, _, s = config5
+    assert (n, k) == (meta["n"], meta["k"]) and meta["mean_degree"] == 24
     # the same graph, the same held-out set, the same wrapped total_pairs (quirk Q5) as the oracle saw
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     assert int(s.nlinks) == meta["nlinks"] and sha(s.links.astype(np.uint32)) == meta["links_sha256"]
@@ -94,9 +102,10 @@ def test_config5_full_size_against_oracle_digest():
     np.testing.assert_allclose(row0[1:], want[0, 1:], rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(eng.rows()[:, 1:], want[1:, 1:], rtol=1e-9, atol=1e-13)
     assert list(eng.rows()[:, 0]) == list(want[1:, 0])
+    eng.close()
 
 
-def test_config5_full_size_planted_state_against_oracle_digest():
+def test_config5_full_size_planted_state_against_oracle_digest(config5):
     """The same full-size graph in the regime a long run ends in, which two sweeps from the seeded state never reach:
     started from tools/make_config5_digest.py::planted_state (gamma = alpha + degree x planted membership, every third node
     pure and flagged converged) at _iter = 999 with annealing off, the oracle ran four sweeps -- two dense ones with O(1)
@@ -107,8 +116,6 @@ def test_config5_full_size_planted_state_against_oracle_digest():
     import importlib.util
     import json
     import os
-    from svinet_amd import mmsbgen_sparse as G
-    from svinet_amd.host_api import Setup
     here = os.path.dirname(os.path.abspath(__file__))
     d = os.path.join(here, "golden", "config5")
     meta = json.load(open(os.path.join(d, "digest_planted.json")))
@@ -116,12 +123,11 @@ def test_config5_full_size_planted_state_against_oracle_digest():
     spec = importlib.util.spec_from_file_location("make_config5_digest", os.path.join(os.path.dirname(here), "tools", "make_config5_digest.py"))
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
-    n, k = meta["n"], meta["k"]
-    pairs, truth = G.generate(n, k, meta["mean_degree"], return_truth=True)
+    n, k, pairs, truth, s = config5
+    assert (n, k) == (meta["n"], meta["k"]) and meta["mean_degree"] == 24
     g0, lam0, conv0 = tool.planted_state(pairs, truth, n, k)
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     assert sha(g0) == meta["gamma0_sha256"]
-    s = Setup(n=n, k=k, pairs=pairs)
     assert sha(s.links.astype(np.uint32)) == meta["links_sha256"] and sha(s.validation_sorted.astype(np.uint32)) == meta["validation_sha256"]
     eng = s.engine(use_validation_stop=False)
     eng.set_state(g0, lam0, conv0)
@@ -149,15 +155,18 @@ def test_config5_full_size_planted_state_against_oracle_digest():
     # value, (sum pi_p)(sum pi_q) - sum pi_p pi_q beta; validation.txt prints these columns to 1e-9.
     np.testing.assert_allclose(eng.rows()[:, 1:], want[1:, 1:], rtol=1e-9, atol=1e-10)
     assert list(eng.rows()[:, 0]) == list(want[1:, 0])
+    eng.close()
 
 
 def test_hbm_bound_sweep_against_oracle():
-    """three sweeps at n = 2e5, k = 512 on the planted MMSB graph: gamma / lambda within 1e-5 relative
-    (the north-star bar; observed ~1e-13), flags, counters and the likelihood row equal"""
+    """three sweeps at n = 1e5, k = 512 on the planted MMSB graph against the oracle RUNNING LIVE (0.41 GB per n-by-k
+    array: outside the 256 MB Infinity Cache; the full-size runs above compare with committed digests): gamma / lambda
+    within 1e-5 relative (the north-star bar; observed ~1e-13), flags, counters and the likelihood row equal.
+    (n = 2e5 until round 4: 107 s of the suite for the oracle's three sweeps, now that the full size itself is covered.)"""
     from oracle import oracle as O
     from svinet_amd import mmsbgen_sparse as G
     from svinet_amd.host_api import Setup
-    n, k = 200_000, 512
+    n, k = 100_000, 512
     pairs = G.generate(n, k, 24)
     s = Setup(n=n, k=k, pairs=pairs)
     ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, use_validation_stop=False)

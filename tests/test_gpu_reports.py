@@ -71,3 +71,38 @@ def test_report_after_the_stop_rule_and_slot_accounting(graph_files):
         eng.report_fetch(t, 1, False)
     with pytest.raises(_svils.SvilsError):
         eng.report_enqueue(0, 65, False)                  # SVILS_REPORT_MAX_ROWS
+
+
+@pytest.mark.parametrize("graph,n,k", [("lfr", 1000, 28), ("astroph", 17903, 200)])
+def test_community_tags_are_the_member_matrix(graph_files, graph, n, k):
+    """svils_get_community_tags / svils_report_fetch_tags: the (node, community) pairs of exactly the ones of the member
+    matrix, by ascending node, for both layouts (K = 28: lane per link, K = 200: row per wavefront with its interleaved
+    lane layout of the bitmask); too little room is an error that keeps the slot; a report without communities has none."""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    setup = Setup(graph_files[graph], n, k)
+    eng = setup.engine(use_validation_stop=False)
+    eng.sweep(12)
+    t = eng.report_enqueue(0, 12, True)
+    eng.sweep(3)
+    member = eng.communities()                                  # after 15 sweeps
+    want = np.argwhere(member)                                  # row-major: ascending node, then community
+    assert want.shape[0] > 100
+    tags = eng.community_tags()
+    assert tags.dtype == np.uint32 and np.all(np.diff(tags[:, 0].astype(np.int64)) >= 0)
+    assert np.array_equal(tags[np.lexsort((tags[:, 1], tags[:, 0]))], want)
+    with pytest.raises(_svils.SvilsError):
+        eng.report_fetch_tags(t, 12, cap=3)                     # does not fit: nothing is freed
+    c, rows, rtags = eng.report_fetch_tags(t, 12)               # the snapshot taken after 12 sweeps
+    other = setup.engine(use_validation_stop=False)
+    other.sweep(12)
+    assert c.sweeps_done == 12 and rows.shape[0] == 12 and rtags.shape[0] > 3
+    assert np.array_equal(rtags[np.lexsort((rtags[:, 1], rtags[:, 0]))], np.argwhere(other.communities()))
+    with pytest.raises(_svils.SvilsError):
+        eng.report_fetch_tags(t, 12)                            # the slot went with the successful fetch
+    t2 = eng.report_enqueue(0, 1, False)
+    with pytest.raises(_svils.SvilsError):
+        eng.report_fetch_tags(t2, 1)                            # enqueued without communities
+    eng.report_fetch(t2, 1, False)
+    other.close()
+    eng.close()
