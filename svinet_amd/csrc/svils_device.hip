@@ -364,8 +364,24 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
   const uint32_t c = blk * 4 + cl;
   double s = 0.0;
   if (c < j.ncols) {
-#pragma unroll 8
-    for (uint32_t b = seg; b < j.nb; b += 64) s += j.part[(size_t)b * j.ncols + c];
+    // 32 rows per batch in flight (was 8: at 1280 partial rows a thread's 20 loads were three dependent round trips of
+    // cold misses -- the rows were written by the launch before); the additions keep their order, so the bits do not change
+    uint32_t b = seg;
+    for (; b + 31u * 64u < j.nb; b += 32u * 64u) {
+      double v[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = j.part[(size_t)(b + 64u * i) * j.ncols + c];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) s += v[i];
+    }
+    {
+      double v[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = (b + 64u * i < j.nb) ? j.part[(size_t)(b + 64u * i) * j.ncols + c] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+        if (b + 64u * i < j.nb) s += v[i];
+    }
   }
   lds[seg][cl] = s;
   __syncthreads();
@@ -958,7 +974,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   if (c.stopped) return;
   STAMP(3, 1);
   constexpr int G = 64 / W;
-  constexpr int NPRE = V <= 2 ? 2 : 1;   // held-out pairs whose rows are fetched before lambda is known
+  constexpr int NPRE = V <= 4 ? 2 : 1;   // held-out pairs whose rows are fetched before lambda is known (a group has ~2 pairs at 2000 held-out links: V = 4, K = 129..256, took its second pair in a dependent round of its own until round 4)
   __shared__ double red[2][256];
   __shared__ unsigned long long cred[4][256];
   __shared__ double2 logtab[128];
