@@ -1,4 +1,5 @@
-"""print the planted-state digest comparison in detail (which likelihood columns differ, by how much)"""
+"""The planted-state config-5 run against its committed oracle digest, column by column: which likelihood columns differ
+and by how much (profiles/r04i_planted_state_likelihood_rows_diff.txt).  python tools/planted_state_diff.py  (GPU, ~1 min)"""
 import sys, os, json, hashlib, importlib.util
 import numpy as np
 sys.path.insert(0, ".")
