@@ -66,7 +66,9 @@ def main():
         lines.append("%-24s %-34s %48.0f %6d" % (wl, ("whole sweep: " + "+".join(sorted(x.split("<")[0] for x in in_loop)))[:34], sweep, nphi))
         rec[wl] = {"phi_hbm_bytes_per_launch": phi, "sweep_hbm_bytes": sweep,
                    "sweep_kernels": {k: {"hbm_bytes_per_launch": v[0], "launches": v[1]} for k, v in sorted(in_loop.items())},
-                   "source": None, "commit": commit, "source_hashes": kernel_source_hashes(workload_k(wl)),
+                   # where tools/evidence.sh's table is kept once copied: profiles/<tag>_hbm_traffic_pmc.txt (TRAFFIC_SOURCE overrides)
+                   "source": os.environ.get("TRAFFIC_SOURCE") or "profiles/%s_%s" % (os.path.basename(os.path.dirname(os.path.abspath(table))), os.path.basename(table)),
+                   "commit": commit, "source_hashes": kernel_source_hashes(workload_k(wl)),
                    "counters": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB"}
     open(table, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
