@@ -9,6 +9,7 @@
 #   bench-extra  LFR K=28 and ca-AstroPh K=200 lines
 #   bench2       bare `python bench.py --gpus 2 --test-one-gpu` (self-spawned ranks on GPU 0, tests' transport, async)
 #   prof         rocprofv3 --kernel-trace --stats of the default command (ca-AstroPh K=20) and of LFR K=28
+#   prof-large   the same for ca-AstroPh K=200 and the config-5 workload (n=1e6, k=512)
 #   pmc          rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the three roofline workloads -> traffic.json + table
 #   pmc-small    the same for astroph-k20 only
 #   native       tests/test_gpu_native_ranks.py
@@ -48,6 +49,9 @@ for step in "$@"; do
     prof)
       prof_one astroph_k20 --no-cpu-baseline --no-hbm-bound --no-config5
       prof_one lfr_k28 --workload lfr-k28 --no-cpu-baseline --no-hbm-bound --no-config5 ;;
+    prof-large)   # rocprofv3 kernel stats of BASELINE config 4's shape and of config 5 at full size (one GPU)
+      prof_one astroph_k200 --workload astroph-k200 --no-cpu-baseline --no-hbm-bound --no-config5 --no-cli
+      prof_one mmsb_n1m_k512 --workload mmsb:1000000:512:24 --steps 10 --warmup 2 --reps 0 --no-cpu-baseline --no-hbm-bound --no-config5 --no-cli ;;
     pmc|pmc-small)
       WLS="astroph-k20 synthetic:200000:512:24 mmsb:1000000:512:24"; [ $step = pmc-small ] && WLS="astroph-k20"
       ARGS=""
