@@ -110,7 +110,11 @@ def _check_node_block(states, ref, n, world, tags=True):
                                                                # of uneven size
                                                                ("lfr", 3, 28, 35, 3, False), ("lfr", 2, 100, 8, 5, False), ("astroph", 3, 200, 3, 4, False),
                                                                # and once each on the synchronous transport
-                                                               ("lfr", 2, 28, 40, 1, True), ("lfr", 3, 28, 35, 3, True)])
+                                                               ("lfr", 2, 28, 40, 1, True), ("lfr", 3, 28, 35, 3, True),
+                                                               # the world sizes the driver's scaling run uses (2, 4, 8): four and
+                                                               # eight node blocks, the headline graph at its own K on eight
+                                                               ("lfr", 4, 28, 35, 1, False), ("lfr", 8, 28, 35, 3, False),
+                                                               ("astroph", 8, 20, 6, 1, False), ("astroph", 4, 200, 3, 2, False)])
 def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps, chunks, sync):
     """svils_sweep_sharded in `world` processes: all-reduce of sum[k], the grouped in-place all-gather of the
     gamma rows and packed flags at rank * B * ld, all-reduce of s1,s2,s3 (grouped with sum[k] once annealing is
@@ -172,7 +176,9 @@ def test_native_step_sharded_windows(graph_files, tmp_path, world):
 
 
 @pytest.mark.parametrize("world,k,sweeps,mode", [(2, 28, 40, "kshard"), (3, 100, 6, "kshard"), (3, 130, 5, "kshard-log"),
-                                                  (2, 28, 40, "kshard-log"), (3, 28, 30, "kshard-lowt")])
+                                                  (2, 28, 40, "kshard-log"), (3, 28, 30, "kshard-lowt"),
+                                                  # four and eight column slices (K = 28 on eight ranks: slices of 3 and 4 columns)
+                                                  (4, 28, 35, "kshard"), (8, 28, 35, "kshard"), (8, 200, 4, "kshard")])
 def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mode):
     """svils_ksh_init_state + svils_sweep_ksharded in `world` processes (uneven slices at K=100/3, 130/3): the column
     slices put together equal the oracle, flags / rows / counters replicated; svils_validation_row and
@@ -240,7 +246,10 @@ def _cmp_numeric(path_a, path_b, skip, atol):
     np.testing.assert_allclose(a[:, skip:], b[:, skip:], rtol=1e-5, atol=atol)
 
 
-@pytest.mark.parametrize("world,extra", [(2, []), (3, ["-sweep-batch", "7"]), (2, ["-kshard"]), (3, ["-kshard", "-sweep-batch", "4"])])
+@pytest.mark.parametrize("world,extra", [(2, []), (3, ["-sweep-batch", "7"]), (2, ["-kshard"]), (3, ["-kshard", "-sweep-batch", "4"]),
+                                         # (eight forked ranks pass as well -- profiles/r04t -- but take 5 minutes on the tests' transport:
+                                         #  sixteen spinning host threads under the box's 16-core quota; four are enough here)
+                                         (4, []), (4, ["-kshard"])])
 def test_cli_gpus_ranks_files_equal_oracle(graph_files, tmp_path, world, extra):
     """`svinet -gpus N [-kshard]` with N forked ranks on GPU 0 (the id through the pipes, every rank its own
     LinkSampling, the gathers behind the files): rank 0's files equal the oracle's writers, nobody else writes"""
