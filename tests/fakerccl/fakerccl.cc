@@ -126,7 +126,9 @@ bool barrier(Comm *c) {
   while (h->generation.load() == gen) {
     if (h->failed.load()) return false;
     if ((++spins & 1023u) == 0) {
-      sched_yield();
+      // a short spin, then sleep: eight ranks of spinning host threads exhaust a 16-core CPU quota and get throttled
+      // for the rest of every scheduler period (a collective then takes ~80 ms)
+      if (spins > 8192u) usleep(50); else sched_yield();
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
         h->failed.store(1);
         fprintf(stderr, "fakerccl: rank %d waited %.0f s at a barrier (a peer is missing)\n", c->rank, lim);
@@ -250,7 +252,7 @@ void host_exchange(void *arg) {
   unsigned spins = 0;
   while (c->completed.load(std::memory_order_acquire) != a->seq) {   // RCCL serialises the ops of one communicator
     if ((++spins & 1023u) == 0) {
-      sched_yield();
+      if (spins > 8192u) usleep(50); else sched_yield();
       if (c->hdr->failed.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s()) {
         c->hdr->failed.store(1);
         fprintf(stderr, "fakerccl: rank %d op %llu never got its turn (the ops of one communicator are serialised)\n", c->rank,

@@ -66,7 +66,7 @@ for step in "$@"; do
       python tools/pmc_traffic.py $O/traffic.json $O/hbm_traffic_pmc.txt $ARGS
       rm -rf $O/pmcf_* $O/pmcw_* ;;
     native) timeout 2400 python -m pytest tests/test_gpu_native_ranks.py tests/test_gpu_fakerccl_async.py -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_native.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_native.txt; tail -25 $O/pytest_native.txt ;;
-    pytest) timeout 3000 python -m pytest ${PYTEST_PATHS:-tests} -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -25 $O/pytest_gpu.txt ;;
+    pytest) timeout 3000 python -m pytest ${PYTEST_PATHS:-tests} -q -m gpu --timeout 900 --durations=15 $PYTEST_ARGS > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -25 $O/pytest_gpu.txt ;;
     kscan) bash tools/k_scan.sh 2>&1 | tee $O/k_scan_astroph.txt ;;
     shardcost)
       (cd /tmp; export TMPDIR=/tmp
