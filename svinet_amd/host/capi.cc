@@ -2,6 +2,7 @@
 // (bench.py, tests) to obtain the product's own inputs for the C ABI of
 // include/svils.h: graph reading, held-out sampling, gamma/lambda
 // initialisation and the training-link list.  No device is touched here.
+#include "fixedfmt.hh"
 #include <cstring>
 #include <memory>
 
@@ -139,5 +140,24 @@ double svih_batch_eta1(const svih_batch *b) { return b->env->eta1; }
 double svih_batch_ones_prob(const svih_batch *b) { return b->env->ones_prob; }
 const uint32_t *svih_batch_edges(const svih_batch *b) { return &b->net->edges()[0].first; }
 uint32_t svih_batch_ones(const svih_batch *b) { return b->net->ones(); }
+
+// tests: how many of `count` values differ between the writers' fixed-point formatter (fixedfmt.hh) and printf's
+// "%.5f" / "%.3f" -- the values come as they are, the test chooses them
+uint64_t svih_fixed_format_mismatches(const double *v, uint64_t count) {
+  uint64_t bad = 0;
+  std::string a;
+  char tmp[400];
+  for (uint64_t i = 0; i < count; ++i) {
+    a.clear();
+    append_fixed<5>(a, v[i], '\t');
+    snprintf(tmp, sizeof tmp, "%.5f\t", v[i]);
+    bad += a != tmp;
+    a.clear();
+    append_fixed<3>(a, v[i], '\n');
+    snprintf(tmp, sizeof tmp, "%.3f\n", v[i]);
+    bad += a != tmp;
+  }
+  return bad;
+}
 
 }  // extern "C"

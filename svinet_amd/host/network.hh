@@ -6,10 +6,10 @@
 #include <cstdint>
 #include <map>
 #include <string>
-#include <unordered_map>
-#include <unordered_set>
 #include <utility>
 #include <vector>
+
+#include "flathash.hh"
 
 namespace svinet {
 
@@ -54,8 +54,8 @@ class Network {
   std::vector<std::vector<uint32_t> > adj_;
   std::vector<Edge> edges_;
   std::vector<uint32_t> seq2id_;
-  std::unordered_map<uint32_t, uint32_t> id2seq_;
-  std::unordered_set<uint64_t> pair_set_;
+  FlatIdMap id2seq_;          // external id -> sequence id
+  FlatPairSet pair_set_;      // the links read so far (both directions of a pair are one key)
   std::map<std::string, uint32_t> str2id_;
 };
 

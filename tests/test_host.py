@@ -157,3 +157,28 @@ def test_cli_gpus_argument_checks(tmp_path, graph_files):
         r = subprocess.run([SVINET, "-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling"] + extra,
                            cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "error" in r.stderr, extra
+
+
+def test_fixed_point_formatter_writes_printf_bytes():
+    """gamma.txt ("%.5f") and groups.txt ("%.3f") are written by a scaled-integer formatter with an snprintf fallback
+    (svinet_amd/host/fixedfmt.hh): every value must come out byte for byte as printf writes it -- random magnitudes,
+    values a hair on either side of a rounding tie at 5 and at 3 decimals, exact ties, zeros, negatives, huge, inf/nan."""
+    import ctypes as C
+    from svinet_amd import host_api
+    L = host_api.load()
+    L.svih_fixed_format_mismatches.argtypes = [C.c_void_p, C.c_uint64]
+    L.svih_fixed_format_mismatches.restype = C.c_uint64
+    rng = np.random.default_rng(7)
+    m = 400_000
+    k5 = rng.integers(0, 10**9, m).astype(np.float64)
+    k3 = rng.integers(0, 10**7, m).astype(np.float64)
+    tie5, tie3 = (k5 + 0.5) / 1e5, (k3 + 0.5) / 1e3
+    vals = np.concatenate([
+        rng.random(m), rng.random(m) * 1e3, np.exp(rng.random(m) * 60 - 40), rng.integers(0, 200000, m) + rng.random(m),
+        tie5, np.nextafter(tie5, np.inf), np.nextafter(tie5, -np.inf), tie3, np.nextafter(tie3, np.inf), np.nextafter(tie3, -np.inf),
+        -rng.random(1000), rng.random(1000) * 1e12,
+        np.array([0.0, -0.0, 1e300, 5e-6, 4.9999999999e-6, 0.0005, 0.0015, 0.0025, 171798.69183, 171798.69185, 99999.999995,
+                  0.9999995, np.inf, -np.inf, np.nan]),
+    ])
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    assert L.svih_fixed_format_mismatches(vals.ctypes.data, vals.size) == 0
