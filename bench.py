@@ -585,6 +585,7 @@ def main():
         # bare `python bench.py --gpus N`: be the launcher (before anything touches HIP in this process)
         raise SystemExit(_spawn_ranks(args.gpus))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (ranks started by a launcher other than _spawn_ranks: before HIP is touched)
     import torch
     from svinet_amd import _svils
 

@@ -196,6 +196,10 @@ int main(int argc, char **argv) {
   // directory and the files, the others compute their node block (or column slice) only.  The communicator
   // id goes from rank 0 to rank r through a pipe made here.
   if (a.link_sampling && a.gpus > 1) {
+    // RCCL shares device buffers between the ranks' processes: the host driver of this GPU pool only supports dmabuf
+    // IPC (without it: hipIpcGetMemHandle: invalid argument).  The runtime reads the variable when HIP is first
+    // touched -- in the ranks, after the fork below; a value the user exported stays.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     std::vector<int> rfds((size_t)a.gpus, -1), wfds((size_t)a.gpus, -1);
     for (int r = 1; r < a.gpus; ++r) {
       int fd[2];
