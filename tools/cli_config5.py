@@ -4,7 +4,7 @@
 gamma.txt / lambda.txt / groups.txt (512 M numbers each).  Prints the CLI's own clocks (SVINET_TIMING_FILE), the wall time
 and the sizes of the files; the state is checked through the C ABI run of the same inputs by tests/test_gpu_config5.py, here
 only lambda.txt is compared with an engine run of the same sweeps (1e-5 relative: the file carries five decimals).
-  python tools/cli_config5.py [max_iterations] [n] [k]
+  python tools/cli_config5.py [max_iterations | stop] [n] [k]        (stop: the default flags, the run ends on its stop rule)
 """
 import json
 import os
@@ -22,7 +22,8 @@ from svinet_amd import mmsbgen_sparse as G          # noqa: E402
 
 
 def main():
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    to_stop = len(sys.argv) > 1 and sys.argv[1] == "stop"
+    M = 0 if to_stop else (int(sys.argv[1]) if len(sys.argv) > 1 else 4)
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
     k = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     d = tempfile.mkdtemp(prefix="svinet_cfg5_", dir=os.environ.get("TMPDIR", "/tmp"))
@@ -38,8 +39,8 @@ def main():
         tf = os.path.join(d, "timing.json")
         env = dict(os.environ, SVINET_TIMING_FILE=tf)
         t1 = time.perf_counter()
-        r = subprocess.run([os.path.join(ROOT, "svinet_amd", "bin", "svinet"), "-file", path, "-n", str(n), "-k", str(k), "-link-sampling",
-                            "-no-stop", "-max-iterations", str(M)], cwd=d, env=env, capture_output=True, text=True, timeout=3000)
+        r = subprocess.run([os.path.join(ROOT, "svinet_amd", "bin", "svinet"), "-file", path, "-n", str(n), "-k", str(k), "-link-sampling"]
+                           + ([] if to_stop else ["-no-stop", "-max-iterations", str(M)]), cwd=d, env=env, capture_output=True, text=True, timeout=3000)
         wall = time.perf_counter() - t1
         print("svinet rc=%d wall %.1f s" % (r.returncode, wall), flush=True)
         if r.returncode:
@@ -52,6 +53,10 @@ def main():
         lam = np.loadtxt(os.path.join(d, outdir, "lambda.txt"))[:, 1:]
         val = np.loadtxt(os.path.join(d, outdir, "validation.txt"))
         print("validation.txt rows:", val.shape, "last:", val[-1].tolist())
+        if to_stop:
+            print("max.txt:", open(os.path.join(d, outdir, "max.txt")).read().strip())
+            print("ok (ran to its stop rule)")
+            return
         # the same sweeps through the C ABI
         from svinet_amd.host_api import Setup
         s = Setup(path, n, k)
