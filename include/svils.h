@@ -103,7 +103,10 @@ int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv);
  * with svils_get_test_rows or a report.  The caller has already taken the pairs out of the training links
  * (edge_ok, src/linksampling.hh:296-305).  Sweeps of a handle with a test set run as four launches (the three-launch
  * form of K <= 32 defers the stop rule to the next launch, too late to decide whether the test row exists).
- * nt == 0 removes the set.  Not for K-sharded handles. */
+ * nt == 0 removes the set.  Not for K-sharded handles.  Test rows share the row numbers of the validation rows: a handle
+ * without a validation set (svils_set_validation with nv == 0) records neither (the reference always has one on this
+ * path: its constructor samples it before anything else, src/linksampling.cc:84-109).  Calling it again re-uses the
+ * device buffers (they grow when a larger set arrives; nothing accumulates). */
 int svils_set_test(svils_handle *h, const uint32_t *pairs_y, uint64_t nt);
 /* out[count][10]: the test rows of reports [first, first + count) (numbered like the validation rows); a report that
  * recorded none (the stopping sweep) reads as NaN.  Synchronises. */

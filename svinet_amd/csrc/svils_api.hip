@@ -102,7 +102,7 @@ struct svils_handle {
   // -load-test (svils_set_test): a second pair set through the validation kernel, rows in a ring of their own
   uint32_t *t_pairs = nullptr;
   double *t_uval = nullptr, *t_rows = nullptr;
-  uint32_t nt = 0;
+  uint32_t nt = 0, t_cap = 0;
   ReportSlot rslot[SVILS_REPORT_SLOTS];
   ReportLayout rlay{};
   hipStream_t copy_stream = nullptr;
@@ -142,6 +142,16 @@ int dalloc(svils_handle *h, T **p, size_t count, bool zero = true) {
   if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, h->stream));
   *p = (T *)q;
   return 0;
+}
+
+// give a dalloc()ed buffer back before svils_destroy (buffers that are re-sized by a later call)
+template <class T>
+void dfree(svils_handle *h, T **p) {
+  if (!*p) return;
+  auto it = std::find(h->allocs.begin(), h->allocs.end(), (void *)*p);
+  if (it != h->allocs.end()) h->allocs.erase(it);
+  (void)hipFree((void *)*p);
+  *p = nullptr;
 }
 
 int drain_timing(svils_handle *h) {
@@ -1881,8 +1891,14 @@ int svils_set_test(svils_handle *h, const uint32_t *pairs_y, uint64_t nt) {
   h->nt = 0;
   if (!nt) return 0;
   int rc;
-  if ((rc = dalloc(h, &h->t_pairs, 3 * (size_t)nt))) return rc;
-  if ((rc = dalloc(h, &h->t_uval, (size_t)nt))) return rc;
+  if (nt > h->t_cap) {          // a larger set than any before: the old buffers go back (the stream is idle here)
+    dfree(h, &h->t_pairs);
+    dfree(h, &h->t_uval);
+    h->t_cap = 0;
+    if ((rc = dalloc(h, &h->t_pairs, 3 * (size_t)nt))) return rc;
+    if ((rc = dalloc(h, &h->t_uval, (size_t)nt))) return rc;
+    h->t_cap = (uint32_t)nt;
+  }
   if (!h->t_rows) {
     if ((rc = dalloc(h, &h->t_rows, (size_t)h->d.rows_cap * 10, false))) return rc;
     // a report without a test row reads as NaN

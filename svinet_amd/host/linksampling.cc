@@ -403,9 +403,14 @@ void LinkSampling::init_gamma_external() {
   size_t cap = 0;
   uint32_t cid = 0;
   ssize_t got;
+  std::string prev;     // the reference's scratch buffer `s` (src/network.cc:382,391)
   while ((got = getline(&line, &cap, f)) > 0) {
-    // (the reference skips a line only when sscanf fails on it, i.e. at end of input: an empty line IS a community)
-    const char *p = line;
+    // The reference copies the line into `s` with sscanf("%[^\n]") and skips it only when that returns < 0.  On an EMPTY
+    // line the directive matches nothing and sscanf returns 0: `s` keeps the PREVIOUS line, whose members are parsed
+    // again as community `cid` (:391-416).  Reproduced; a blank FIRST line reads the reference's uninitialised buffer --
+    // here it is an empty community.
+    if (line[0] != '\n') prev.assign(line, strcspn(line, "\n"));
+    const char *p = prev.c_str();
     for (;;) {
       char *e = nullptr;
       const long u = strtol(p, &e, 10);
@@ -829,12 +834,14 @@ void LinkSampling::write_communities_file() {
   char buf[16];
   for (uint32_t c = 0; c < k_; ++c) {
     if (ids[c].empty()) continue;            // empty communities have no map entry => no line
-    for (uint32_t id : ids[c]) {             // "%d " per member
+    for (uint32_t id : ids[c]) {             // "%d " per member: the id goes through (int), as printf("%d ") sees it
       char *e = buf + sizeof buf;
       char *b = e;
       *--b = ' ';
-      uint32_t v = id;
+      const int32_t sv = (int32_t)id;
+      uint32_t v = sv < 0 ? 0u - (uint32_t)sv : (uint32_t)sv;
       do { *--b = (char)('0' + v % 10); v /= 10; } while (v);
+      if (sv < 0) *--b = '-';
       out.append(b, (size_t)(e - b));
     }
     out.push_back('\n');
@@ -920,7 +927,9 @@ int LinkSampling::sweep_loop_pipelined() {
       printf("\riteration %d: processing %d links", issued_iter, (int)nlinks);
       fflush(stdout);
       if (svils_sweep(h_, batch)) die_svils("svils_sweep");
-      const uint32_t new_rows = (issued_iter + batch) / rf - issued_iter / rf;   // multiples of rf in (iter, iter + batch]
+      // the device records a row for every sweep whose pre-increment _iter is a multiple of rf (k_tail; _iter starts at
+      // 0, so sweep 0 records row 0): the multiples of rf in [iter, iter + batch)
+      const uint32_t new_rows = (issued_iter + batch + rf - 1) / rf - (issued_iter + rf - 1) / rf;
       issued_iter += batch;
       Flight f{-1, new_rows, new_rows > 0 || always_report};
       if (svils_report_enqueue(h_, rows_issued, new_rows, f.with_comm ? 1 : 0, &f.ticket)) die_svils("svils_report_enqueue");
@@ -963,6 +972,9 @@ int LinkSampling::sweep_loop_pipelined() {
         uint32_t hv = 0;
         if (svils_report_fetch(h_, g.ticket, &cc, rows.data(), &hv, nullptr)) die_svils("svils_report_fetch");
       }
+      // every recorded row reaches the files: whatever the landed reports did not carry (none, if the row bookkeeping
+      // above is right) is read from the ring before the final files are written
+      if (c.rows > rows_logged_) fetch_and_log_rows();
       timing_.sweeps_t1 = now_s();
       timing_.sweeps = c.sweeps_done;
       do_on_stop();

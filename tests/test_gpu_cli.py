@@ -303,18 +303,25 @@ def test_cli_load_test(graph_files, tmp_path, sync):
         assert (int(row[0]), int(row[1]), int(row[2])) == (int(s2i[lo]), int(s2i[hi]), net.y(int(lo), int(hi)))
 
 
-def test_cli_init_communities(graph_files, tmp_path):
+@pytest.mark.parametrize("blank", [False, True])
+def test_cli_init_communities(graph_files, tmp_path, blank):
     """-init-communities <file> (one community per line, external ids; Network::load_init_communities,
     src/network.cc:374-440; LinkSampling::init_gamma_external, src/linksampling.cc:405-453): no random gamma, the model
     starts from the listed memberships.  Files against the oracle's counterpart; init_memberships.txt as the reference
-    writes it."""
+    writes it.  blank: an EMPTY line is not an empty community in the reference -- sscanf("%[^\\n]") matches nothing,
+    returns 0 and leaves the previous line in the scratch buffer, whose members become that community as well
+    (src/network.cc:391-416)."""
     net = O.Network(graph_files["lfr"], 1000)
     s2i = net.seq2id()
     rng = np.random.default_rng(5)
     comms = [sorted(rng.choice(1000, size=int(rng.integers(20, 60)), replace=False).tolist()) for _ in range(28)]
     comms[5] = comms[5] + comms[5][:3]                   # a node listed twice on one line counts twice
     cf = tmp_path / "init.txt"
-    cf.write_text("".join(" ".join(str(int(s2i[p])) for p in c) + "\n" for c in comms))
+    lines = [" ".join(str(int(s2i[p])) for p in c) + "\n" for c in comms]
+    if blank:
+        lines[10] = "\n"
+        comms[10] = list(comms[9])
+    cf.write_text("".join(lines))
     r = _run(["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-init-communities", str(cf),
               "-no-stop", "-max-iterations", "25"], str(tmp_path))
     assert r.returncode == 0, r.stderr
@@ -336,3 +343,62 @@ def test_cli_init_communities(graph_files, tmp_path):
     for c, nodes in enumerate(comms):
         for p in nodes:
             assert c in of[int(s2i[p])]
+
+
+def _files_equal_but_duration(da, db, names=("gamma.txt", "lambda.txt", "groups.txt", "communities.txt", "max.txt")):
+    for nme in names:
+        if (da / nme).exists() or (db / nme).exists():
+            if nme == "max.txt":   # iteration, duration, likelihood, why: drop the duration
+                a, b = (da / nme).read_text().split(), (db / nme).read_text().split()
+                assert a[:1] + a[2:] == b[:1] + b[2:], nme
+            else:
+                assert (da / nme).read_bytes() == (db / nme).read_bytes(), nme
+    va, vb = np.loadtxt(da / "validation.txt"), np.loadtxt(db / "validation.txt")
+    assert va.shape == vb.shape
+    assert np.array_equal(np.delete(va, 1, axis=1), np.delete(vb, 1, axis=1))
+
+
+@pytest.mark.parametrize("extra", [["-no-stop", "-max-iterations", "100"], ["-no-stop", "-max-iterations", "98"],
+                                   ["-no-stop", "-max-iterations", "103", "-sweep-batch", "3"], []])
+def test_cli_pipelined_rfreq_rows(graph_files, tmp_path, extra):
+    """-rfreq 5 through the PIPELINED loop (the default): the device records a row for every sweep whose _iter is a
+    multiple of 5 -- [iter, iter + batch), sweep 0 included -- and every one of them reaches validation.txt, also the
+    last one before -max-iterations ends the run and the row on which the stop rule fires (extra == []: the run ends
+    by its stop rule).  Same files as the synchronous loop; rows against the oracle."""
+    args = ["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-rfreq", "5"] + extra
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = _run(args, str(tmp_path / "a"), env={"SVINET_SYNC_REPORTS": "0"})
+    rb = _run(args, str(tmp_path / "b"), env={"SVINET_SYNC_REPORTS": "1"})
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    da, db = tmp_path / "a" / "n1000-k28-mmsb-linksampling", tmp_path / "b" / "n1000-k28-mmsb-linksampling"
+    _files_equal_but_duration(da, db)
+    v = np.loadtxt(da / "validation.txt")
+    if extra:
+        m = int(extra[2])
+        ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, use_validation_stop=False, max_iterations=m, reportfreq=5)
+        while ref.sweep() == 0:
+            pass
+        assert np.array_equal(v[1:, 0], np.arange(0, m + 1, 5))      # sweeps 0, 5, ..., the last multiple of 5 <= m
+    else:
+        ref = O.LinkSampling(O.Network(graph_files["lfr"], 1000), 28, reportfreq=5)
+        while ref.sweep() != 2:
+            assert ref.iter < 2000
+        assert v[-1, 0] % 5 == 0
+    np.testing.assert_allclose(np.delete(v, 1, axis=1), ref.rows, rtol=0, atol=6e-10)
+
+
+def test_cli_default_graph_threshold_in_a_pipelined_run(graph_files, tmp_path):
+    """The product default (SVILS_GRAPH_AFTER unset = 128): hipGraph capture happens in the MIDDLE of a pipelined run, at
+    the first chunk past 128 sweeps, with report copies in flight on the copy stream.  300 sweeps; files equal those of
+    the synchronous loop."""
+    args = ["-file", graph_files["lfr"], "-n", "1000", "-k", "28", "-link-sampling", "-no-stop", "-max-iterations", "299"]
+    env = {k: v for k, v in os.environ.items() if k != "SVILS_GRAPH_AFTER"}
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = subprocess.run([SVINET] + args, cwd=str(tmp_path / "a"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                        timeout=900, env=dict(env, SVINET_SYNC_REPORTS="0"))
+    rb = subprocess.run([SVINET] + args, cwd=str(tmp_path / "b"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                        timeout=900, env=dict(env, SVINET_SYNC_REPORTS="1"))
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    da, db = tmp_path / "a" / "n1000-k28-mmsb-linksampling", tmp_path / "b" / "n1000-k28-mmsb-linksampling"
+    _files_equal_but_duration(da, db)
+    assert np.loadtxt(da / "validation.txt").shape == (301, 11)
