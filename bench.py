@@ -435,15 +435,27 @@ class _Sharded:
     """One chain over all ranks: node-block sharding with the exchanges issued by the device library itself
     (svils_sweep_sharded: RCCL all-reduce / all-gather on the engine's stream between the phases of a sweep)."""
 
-    def __init__(self, setup, rank, world, device, dist):
+    def __init__(self, setup, rank, world, device, dist, equal_blocks=False):
+        import numpy as np
         from svinet_amd import _svils
-        from svinet_amd.sharded import block_size, node_block
+        from svinet_amd.sharded import balanced_bounds, block_size, equal_bounds
+        # node blocks balanced by work (CSR entries + a per-node share: svils_balance_node_blocks); mini-batch steps keep
+        # the equal blocks they need
+        self.bounds = equal_bounds(setup.n, world) if equal_blocks else balanced_bounds(setup.links, setup.n, world)
         B = block_size(setup.n, world)
         self.eng = setup.engine(use_validation_stop=False, device=device,
-                                node_block=node_block(setup.n, world, rank), n_alloc=B * world)
+                                node_block=(int(self.bounds[rank]), int(self.bounds[rank + 1])),
+                                n_alloc=B * world if equal_blocks else 0)
+        if not equal_blocks:
+            self.eng.set_node_blocks(rank, world, self.bounds)
         ids = [_svils.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         self.eng.comm_init(ids[0], rank, world)
+        deg = np.bincount(np.asarray(setup.links).ravel(), minlength=setup.n)
+        ent = np.array([int(deg[int(self.bounds[r]):int(self.bounds[r + 1])].sum()) for r in range(world)], dtype=np.float64)
+        self.balance = {"node_blocks": [int(x) for x in self.bounds], "csr_entries_per_rank": [int(x) for x in ent],
+                        "max_over_mean": float(ent.max() / ent.mean()) if ent.sum() else None,
+                        "cut": "equal node counts" if equal_blocks else "svils_balance_node_blocks (entries + 0.5 per node); s3 pass cut by link count"}
 
     def sweep(self, n):
         self.eng.sweep_sharded(n)
@@ -457,7 +469,7 @@ class _ShardedSteps(_Sharded):
 
     def __init__(self, setup, rank, world, device, dist):
         from svinet_amd.sharded import block_size
-        super().__init__(setup, rank, world, device, dist)
+        super().__init__(setup, rank, world, device, dist, equal_blocks=True)
         B = block_size(setup.n, world)
         self.eng.set_stochastic(batch_nodes=(B + self.WINDOWS - 1) // self.WINDOWS, tau0=64.0, kappa=0.6, shard_block=B)
 
@@ -769,11 +781,11 @@ def main():
             "data": data,
             "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
-                       "parallelism": ("one chain, node-block sharding x%d: per sweep the gamma rows (n*ld*8 B) + packed flags of every block (one "
-                                       "grouped RCCL all-gather; above 128 MB in chunks on a stream of their own, each expanded while the next "
-                                       "travels) and one grouped all-reduce (K + 3K doubles) -- while annealing (the first ~20 sweeps "
-                                       "here) the K-vector sum[k] is all-reduced on its own before the finalise pass, a third "
-                                       "exchange point -- issued by the device library between the phases (svils_sweep_sharded)" % world) if world > 1 else "single GPU",
+                       "parallelism": ("one chain, node blocks balanced by work x%d: per sweep ONE grouped launch {all-reduce of sum[k] (K doubles), "
+                                       "all-gather of the unscaled new rows (n*ld*8 B, slices padded to the largest block; above 128 MB in chunks on "
+                                       "a stream of their own, each expanded while the next travels)} and one all-reduce of s1,s2,s3 (3K doubles) -- two "
+                                       "exchange points in both phases of the run, flags recomputed not exchanged -- issued by the device library "
+                                       "between the phases and replayed with them as hipGraphs (svils_sweep_sharded)" % world) if world > 1 else "single GPU",
                        "converged_nodes_at_end": int((conv > 0).sum()),
                        # how the last sweep's links were evaluated (src/linksampling.cc:622-719): full softmax,
                        # active-set path (_iter > 1000 only), O(1) shortcut of links with exactly one converged endpoint
@@ -794,7 +806,7 @@ def main():
         else:   # this rank's node block: no PMC record describes it
             roof.update(same_window)
             roof["achieved_survey_model"], roof["frac_survey_model"] = roof.pop("achieved"), roof.pop("frac")
-            roof["pull_model"] = _pull_model(same_window, k, (n + world - 1) // world)
+            roof["pull_model"] = _pull_model(same_window, k, int(runner.bounds[rank + 1]) - int(runner.bounds[rank]))
             roof["traffic"], roof["frac_basis"] = None, "pull_model"
             roof["achieved"], roof["frac"] = roof["pull_model"]["achieved"], roof["pull_model"]["frac"]
         roof["timing"] = ("hipEvents around the phi launch on the engine's own stream, in an event pass of its own after the "
@@ -818,8 +830,10 @@ def main():
                 out["speedup_vs_cpu_1core"] = out["value"] / cpu_rec["value"]
         if exch is not None:
             out["exchange"] = {"ms_per_sweep": exch[0] / exch[1],
-                               "note": "hipEvent time of the RCCL collectives on the engine stream (3 event brackets per sweep), "
-                                       "measured in the event pass after the timed region"}
+                               "note": "hipEvent time of the RCCL collectives on the engine stream (2 event brackets per sweep: rows + sum, "
+                                       "s1/s2/s3), measured in the event pass after the timed region (eager launches; the timed region "
+                                       "replays hipGraphs)"}
+            out["load_balance"] = runner.balance
         if not multi and n * k * 8 < 256e6:
             try:
                 out["roofline_dense_only"] = dense_only_window(setup, k, local_rank)
@@ -910,6 +924,8 @@ def main():
                                    "phi_us_rank0": tm["phi"][0] / max(tm["phi"][1], 1) * 1e3,
                                    "exchange_ms_per_sweep_rank0": tm["exchange"][0] / nev2,
                                    "row_communicator": r2.eng.comm_query()["row_communicator"]}
+                    if hasattr(r2, "balance"):
+                        extra[name]["csr_entries_max_over_mean"] = r2.balance["max_over_mean"]
                 r2.eng.close()
                 s2.close()
                 if p2:

@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 5   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags */
+#define SVILS_ABI_VERSION 6   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags;
+                                 6: work-balanced node blocks (svils_balance_node_blocks / svils_set_node_blocks), the node-block sweep
+                                    with ONE row exchange (SVILS_PHASE_B_LIGHT / SVILS_PHASE_EXPAND_ALL, SVILS_BUF_GSTAGE) */
 
 typedef enum {
   SVILS_OK = 0,
@@ -155,7 +157,8 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps);
 int svils_synchronize(svils_handle *h);
 
 /* phases of a sweep / mini-batch step between exchange points (see "multi-GPU hooks" below) */
-typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D, SVILS_PHASE_EXPAND } svils_phase;
+typedef enum { SVILS_PHASE_A = 0, SVILS_PHASE_B, SVILS_PHASE_C, SVILS_PHASE_D, SVILS_PHASE_EXPAND,
+               SVILS_PHASE_B_LIGHT = 5, SVILS_PHASE_EXPAND_ALL = 6 } svils_phase;
 
 /* ---- mini-batch mode (an ADDITION of this build; SURVEY 8f N4, BASELINE north_star) ----
  * The reference revision's -link-sampling loop is a deterministic full sweep with step size 1
@@ -279,17 +282,36 @@ int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint6
 int svils_get_timed_links(svils_handle *h, uint64_t *out3);
 
 /* ---- multi-GPU hooks (one process per GPU; collectives stay with the caller) */
-/* The sweep split at its two exchange points.  With node-block ownership each
- * handle runs phase A on its rows, the caller all-reduces the K-vector partial
- * buffer, phase B finalises the owned rows, the caller all-gathers the gamma row
- * blocks (+ the converged / active flags), phase EXPAND re-derives Elogpi (digamma)
- * and the mean indicators m = (gamma/scale - alpha)/(n-1) of the rows it does NOT
- * own from the gathered gamma -- so only ONE n-by-k array crosses the links per
- * sweep instead of three --, phase C does the s3 pass on owned rows, the caller
- * all-reduces the second K-vector buffer, and phase D (replicated) closes the
- * sweep.  svils_sweep() == A,B,C,D with no exchange (EXPAND is a no-op when the
- * handle owns every row). */
+/* The sweep split at its exchange points.  Node-block ownership, whole sweeps (what svils_sweep_sharded issues itself):
+ *   A            phi pass over the owned rows                  -> partial `sum[k]` in SVILS_BUF_KVEC_A
+ *   B_LIGHT      mean indicators, s1 / s2 partials, tags and the UNSCALED new row of every owned node, written to this
+ *                rank's slice of SVILS_BUF_GSTAGE ([world][bmax][ld]: slice r = the rows of rank r's block)
+ *   -- exchange 1: all-reduce(SUM) KVEC_A; all-gather of the GSTAGE slices (in place: the send block IS slice `rank`)
+ *   EXPAND_ALL   every row, owned or not: annealing scale ones / sum[k], gamma, Elogpi (digamma), the mean indicators of
+ *                the other blocks m = (row - alpha) / (n - 1), prune() flags -- computed by every rank from the same
+ *                bytes, so flags never cross the links and ONE n-by-k array does
+ *   C            s3 pass over this rank's share of the links   -> SVILS_BUF_KVEC_C (s1, s2, s3)
+ *   -- exchange 2: all-reduce(SUM) KVEC_C
+ *   D            lambda, likelihood, stop rule, annealing switch (replicated)
+ * Two exchange points in both phases of a run: the annealing scale is applied behind the row exchange (until ABI 5
+ * `sum` had an exchange point of its own while annealing).  Mini-batch steps (svils_step_phase) keep the older split
+ * A | B | EXPAND | C | D with the gamma / mphi / packed-flag rows of the windows exchanged in place.
+ * svils_sweep() == A,B,C,D with no exchange. */
 int svils_sweep_phase(svils_handle *h, svils_phase phase);
+
+/* Node blocks.  Rank r of `world` owns the nodes [bounds[r], bounds[r + 1]); the handle of rank r is created with
+ * svils_config.node_begin / node_end = that range.  svils_balance_node_blocks cuts [0, n) so that every block carries
+ * the same WORK, not the same number of nodes ("balanced by sum of degree"): cost of a node = its CSR
+ * entries (2 per training link it touches) + node_weight (per-node share of the finalise pass in units of one entry;
+ * < 0 = the default 0.5).  The reference numbers nodes by first appearance (src/network.cc:10-116), so on its own
+ * example graphs the hubs sit at the low ids: equal-count blocks give rank 0 of 8 on ca-AstroPh 2.96 x the mean number
+ * of entries.  Pure host code (no device needed); every rank computes the same bounds from the same link list.
+ * svils_set_node_blocks declares the blocks of ALL ranks to a handle (bounds[world + 1]; NULL = equal blocks of
+ * ceil(n / world) nodes, what svils_comm_init assumes by itself), before or after svils_set_graph, before
+ * svils_comm_init.  With caller-given bounds the s3 pass is cut by link count (equal runs of the link list) instead of
+ * by node block, and mini-batch steps (which need equal blocks) are refused.  At most 64 ranks. */
+int svils_balance_node_blocks(const uint32_t *links, uint64_t nlinks, uint32_t n, int world, double node_weight, uint32_t *bounds);
+int svils_set_node_blocks(svils_handle *h, int rank, int world, const uint32_t *bounds);
 
 typedef enum {
   SVILS_BUF_KVEC_A = 0,   /* double[k]   : sum (phase A -> all-reduce SUM)          */
@@ -301,9 +323,13 @@ typedef enum {
   SVILS_BUF_ACTIVE,       /* uint32[n_pad] active_comms                             */
   SVILS_BUF_AMASK,        /* uint64[n_pad][kw] active-set bitmask                   */
   SVILS_BUF_MEMBER,       /* uint64[n_pad][kw] community bitmask                    */
-  SVILS_BUF_XFLAGS        /* uint32[n_pad][2+2kw] new converged flag, active_comms and active-set
+  SVILS_BUF_XFLAGS,       /* uint32[n_pad][2+2kw] new converged flag, active_comms and active-set
                              bitmask of every row, packed by phase B: all-gather THIS by node block
-                             (instead of CONV/ACTIVE/AMASK); PHASE_EXPAND unpacks the others' rows */
+                             (instead of CONV/ACTIVE/AMASK); PHASE_EXPAND unpacks the others' rows
+                             (mini-batch steps only since ABI 6) */
+  SVILS_BUF_GSTAGE        /* double[world * bmax][ld]: staging of the row exchange of whole node-block sweeps; slice r
+                             (bmax rows, bmax = the largest block) holds the unscaled new rows of rank r's block.
+                             row_bytes = ld * 8, bytes = the whole buffer.  Exists once the blocks are declared. */
 } svils_buffer;
 /* device pointer + geometry of an exchange buffer (valid until destroy) */
 int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr,
@@ -314,14 +340,15 @@ int svils_stream(svils_handle *h, void **stream);
 /* ---- native multi-GPU driver: one process per GPU, RCCL over xGMI ------------------------------
  * The reference has no distributed path; its one reduce analogue is the in-process sum of per-thread
  * partials in MMSBInfer::multithreaded_process (src/mmsbinfer.cc:1770-1827).  Here every process
- * creates its handle on its own GPU with the node block of its rank (svils_config node_begin /
- * node_end = [rank*B, min(n, (rank+1)*B)), n_alloc = world*B, B = ceil(n/world)) and the library
- * issues the exchanges itself, on the handle's stream, between the phases of a sweep:
- *   phi pass -> all-reduce(sum) -> finalise -> all-gather(gamma rows, packed flags) -> expand ->
- *   s3 pass -> all-reduce(s1,s2,s3) -> tail (replicated).
- * Once the annealing flag is off (it is replicated, only goes 1 -> 0 inside a run, and is read when a call
- * starts and every 16 sweeps until then) sum[k] has one reader left, lambda[k][0] in the tail: its all-reduce
- * is grouped with the one of s1,s2,s3 -- two exchange points per sweep instead of three.
+ * creates its handle on its own GPU with the node block of its rank (svils_config node_begin / node_end =
+ * [bounds[rank], bounds[rank + 1]) of svils_balance_node_blocks + svils_set_node_blocks; or, without them, the equal
+ * blocks [rank*B, min(n, (rank+1)*B)), B = ceil(n/world) -- mini-batch steps also need n_alloc = world*B) and the
+ * library issues the exchanges itself, on the handle's stream, between the phases of a sweep:
+ *   phi pass -> light finalise -> {all-reduce(sum), all-gather(unscaled rows)} -> expand (scale, Elogpi, flags of every
+ *   row) -> s3 pass -> all-reduce(s1,s2,s3) -> tail (replicated):
+ * two exchange points per sweep in both phases of a run, nothing on the host looks at the control block, and runs of
+ * sweeps -- collectives included -- replay as hipGraphs under svils_sweep's rule (eager until the handle has run 128
+ * sweeps; SVILS_SHARDED_GRAPHS=0 keeps them eager; a capture that fails once leaves the handle eager).
  * The K-vector all-reduces run on the handle's stream.  When the n-by-k payload is large enough to be pipelined
  * (chunks on a communication stream of their own, each expanded while the next one travels) the row chunks use a
  * SECOND communicator, formed by the same ranks the first time it is needed (rank 0 draws another unique id and

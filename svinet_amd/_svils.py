@@ -32,6 +32,7 @@ EXPORTS = (
     "svils_report_enqueue", "svils_report_ready", "svils_report_fetch", "svils_report_test_rows",
     "svils_set_test", "svils_get_test_rows",
     "svils_report_tag_count", "svils_report_fetch_tags", "svils_get_community_tags",
+    "svils_set_node_blocks", "svils_balance_node_blocks",
 )
 
 
@@ -125,6 +126,8 @@ def load():
     L.svils_get_timed_links.argtypes = [vp, vp]
     L.svils_comm_unique_id.argtypes = [vp]
     L.svils_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.svils_set_node_blocks.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.svils_balance_node_blocks.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_double, vp]
     L.svils_sweep_sharded.argtypes = [vp, C.c_uint32]
     L.svils_gather_communities.argtypes = [vp]
     L.svils_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t]
@@ -154,7 +157,7 @@ def _chk(rc):
 
 
 BUF_KVEC_A, BUF_KVEC_C, BUF_GAMMA, BUF_ELOGPI, BUF_MPHI, BUF_CONV, BUF_ACTIVE, BUF_AMASK, \
-    BUF_MEMBER, BUF_XFLAGS = range(10)
+    BUF_MEMBER, BUF_XFLAGS, BUF_GSTAGE = range(11)
 COMM_ID_BYTES = 128
 
 
@@ -163,7 +166,16 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _chk(load().svils_comm_unique_id(buf))
     return buf.raw
-PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND = range(5)
+PHASE_A, PHASE_B, PHASE_C, PHASE_D, PHASE_EXPAND, PHASE_B_LIGHT, PHASE_EXPAND_ALL = range(7)
+
+
+def balance_node_blocks(links, n, world, node_weight=-1.0):
+    """svils_balance_node_blocks: bounds[world + 1] of contiguous node blocks of equal WORK (CSR entries + node_weight per
+    node; < 0 = the library's default).  Host code only: works without a device."""
+    links = np.ascontiguousarray(links, dtype=np.uint32)
+    b = np.zeros(world + 1, dtype=np.uint32)
+    _chk(load().svils_balance_node_blocks(links.ctypes.data, links.shape[0], n, world, float(node_weight), b.ctypes.data))
+    return b
 KPHASE_DEN, KPHASE_PHI, KPHASE_FIN, KPHASE_LAMBDA, KPHASE_STOP, KPHASE_INIT_ROWS, KPHASE_INIT_EXPAND, KPHASE_DENMAX = range(8)
 KSH_DEN, KSH_ROWX, KSH_Q2, KSH_VDOT, KSH_DMAX, KSH_EARG = range(6)
 
@@ -426,6 +438,15 @@ class Engine:
     def comm_init(self, comm_id, rank, world):
         assert len(comm_id) == COMM_ID_BYTES
         _chk(load().svils_comm_init(self._h, C.c_char_p(comm_id), rank, world))
+
+    def set_node_blocks(self, rank, world, bounds=None):
+        """declare the node blocks of all ranks (bounds[world + 1]; None = equal blocks of ceil(n / world) nodes)"""
+        if bounds is None:
+            _chk(load().svils_set_node_blocks(self._h, rank, world, None))
+        else:
+            b = np.ascontiguousarray(bounds, dtype=np.uint32)
+            assert b.shape == (world + 1,)
+            _chk(load().svils_set_node_blocks(self._h, rank, world, b.ctypes.data))
 
     def comm_query(self):
         """what the bound RCCL says about this handle's communicator (ncclCommCount / UserRank / CuDevice / GetVersion)"""

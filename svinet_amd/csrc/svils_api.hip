@@ -51,6 +51,7 @@ struct EvPair {
 }  // namespace
 
 struct svils_handle {
+  static constexpr uint32_t kGraphMaxLog = 6;
   svils_config cfg;
   Geometry geo;
   DeviceState d;
@@ -80,6 +81,14 @@ struct svils_handle {
   unsigned char *stage = nullptr;   // device staging of svils_comm_allgather_host: world x stage_bytes, grown collectively
   size_t stage_bytes = 0;
   uint32_t *stage_flag = nullptr;   // device word: "my allocation failed", summed over the ranks
+  // node blocks of a node-block run (svils_set_node_blocks, or the equal blocks svils_comm_init assumes)
+  Blocks blk{};
+  bool blocks_set = false;
+  bool blocks_explicit = false;     // bounds came from the caller (balanced): the s3 pass is split by link count, no mini-batch steps
+  std::vector<uint32_t> h_upper;    // [n] offset of the first q > x inside row x (host copy, for the s3 split)
+  // hipGraphs of node-block sweeps (with their collectives captured): [i] = 2^i sweeps
+  hipGraphExec_t sgexec[kGraphMaxLog + 1] = {};
+  bool sgraphs_ok = true;
   std::vector<uint32_t> timed_sweeps;   // sweeps_done index of every sweep whose phi launch was bracketed
   uint64_t sweeps_issued = 0;           // sweeps enqueued so far (== DevCtrl.sweeps_done unless stopped)
   // hipGraph replay of whole sweeps (host launch cost: 8 launches x ~7 us per sweep eager)
@@ -87,7 +96,6 @@ struct svils_handle {
   hipGraphExec_t gexec1 = nullptr, gexecN = nullptr;   // 1 sweep / kGraphSweeps sweeps
   // other powers of two up to kGraphMax sweeps, captured on first use: 20 sweeps replay as 16 + 4, 100 as 64 + 32 + 4
   // (every graph launch is ~4.5 us of idle device: profiles/r03zb_graph_granularity.txt)
-  static constexpr uint32_t kGraphMaxLog = 6;
   hipGraphExec_t gexecP[kGraphMaxLog + 1] = {};        // [i]: 2^i sweeps (i = 0 and 3 stay null: gexec1, gexecN)
   bool graphs_ok = true;                               // false after a capture failure: stay eager
   uint32_t graph_after = 128;                          // sweeps a handle runs eagerly before it captures graphs (svils_sweep)
@@ -198,6 +206,61 @@ int fault_error(uint32_t code) {
   return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
 }
 
+// ---- node blocks ------------------------------------------------------------------------------------------------
+int apply_s3_split(svils_handle *h);
+int ensure_classes(svils_handle *h);
+// The staging of the row exchange, [world][bmax][ld]; slice `rank` is where the light finalise pass writes.
+int apply_blocks(svils_handle *h, int rank, int world, const uint32_t *bounds, bool explicit_bounds) {
+  const Geometry &g = h->geo;
+  if (world < 1 || world > SVILS_MAX_WORLD || rank < 0 || rank >= world)
+    return fail(SVILS_ERR_ARG, "node blocks: rank %d of %d (at most %d ranks)", rank, world, SVILS_MAX_WORLD);
+  Blocks b{};
+  b.world = (uint32_t)world;
+  b.chunk = 0;
+  b.nchunks = 1;
+  if (bounds) {
+    for (int r = 0; r <= world; ++r) b.bounds[r] = bounds[r];
+  } else {   // equal blocks of ceil(n / world) nodes
+    const uint32_t B = (g.n + (uint32_t)world - 1) / (uint32_t)world;
+    for (int r = 0; r <= world; ++r) b.bounds[r] = (uint32_t)std::min<uint64_t>(g.n, (uint64_t)r * B);
+  }
+  if (b.bounds[0] != 0 || b.bounds[world] != g.n) return fail(SVILS_ERR_ARG, "node blocks: bounds must run from 0 to n = %u", g.n);
+  b.bmax = 0;
+  for (int r = 0; r < world; ++r) {
+    if (b.bounds[r + 1] < b.bounds[r]) return fail(SVILS_ERR_ARG, "node blocks: bounds must not decrease (rank %d)", r);
+    b.bmax = std::max(b.bmax, b.bounds[r + 1] - b.bounds[r]);
+  }
+  if (b.bounds[rank] != g.node_begin || b.bounds[rank + 1] != g.node_end)
+    return fail(SVILS_ERR_ARG, "node blocks: rank %d of %d owns [%u,%u) but the handle was created for [%u,%u)", rank, world,
+                b.bounds[rank], b.bounds[rank + 1], g.node_begin, g.node_end);
+  if (h->blocks_set) {
+    if (h->blk.world != b.world || memcmp(h->blk.bounds, b.bounds, sizeof(uint32_t) * (size_t)(world + 1)) != 0 || h->rank != rank)
+      return fail(SVILS_ERR_ARG, "node blocks: already declared differently for this handle");
+    if (explicit_bounds && !h->blocks_explicit) {
+      h->blocks_explicit = true;
+      return apply_s3_split(h);
+    }
+    return 0;
+  }
+  if (h->d.ksh) return fail(SVILS_ERR_ARG, "node blocks: a K-sharded handle holds every node");
+  int rc = dalloc(h, &h->d.gstage, (size_t)world * std::max(b.bmax, 1u) * g.ld);
+  if (rc) return rc;
+  h->d.gown = h->d.gstage + (size_t)rank * b.bmax * g.ld;
+  h->blk = b;
+  h->rank = rank;
+  h->world = world;
+  h->blocks_set = true;
+  h->blocks_explicit = explicit_bounds;
+  return apply_s3_split(h);
+}
+// a whole-graph handle that never heard of blocks is a world of one
+int ensure_blocks(svils_handle *h) {
+  if (h->blocks_set) return 0;
+  if (h->geo.node_begin != 0 || h->geo.node_end != h->geo.n)
+    return fail(SVILS_ERR_ARG, "this node-block handle needs svils_set_node_blocks (or svils_comm_init) first");
+  return apply_blocks(h, 0, 1, nullptr, false);
+}
+
 // (re)classify the links of the sweep about to run from the flags as they stand
 int classify_now(svils_handle *h, const Geometry &g, const DeviceState &d, const Params &prm) {
   Timed t(h, SVILS_KERNEL_CLASSIFY);
@@ -264,6 +327,25 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
     case SVILS_PHASE_EXPAND: {
       launch_expand(g, d, prm, s);
     } break;
+    case SVILS_PHASE_B_LIGHT: {
+      if (prm.stoch) return fail(SVILS_ERR_ARG, "SVILS_PHASE_B_LIGHT belongs to whole sweeps, not to mini-batch steps");
+      int rc = ensure_blocks(h);
+      if (rc) return rc;
+      d.gstage = h->d.gstage;
+      d.gown = h->d.gown;
+      d.light = 1;
+      Timed t(h, SVILS_KERNEL_FINALIZE);
+      launch_finalize(g, d, prm, s);
+    } break;
+    case SVILS_PHASE_EXPAND_ALL: {
+      int rc = ensure_blocks(h);
+      if (rc) return rc;
+      d.gstage = h->d.gstage;
+      Blocks b = h->blk;
+      b.chunk = 0;
+      b.nchunks = 1;
+      launch_expand_all(g, d, prm, b, s);
+    } break;
     case SVILS_PHASE_D: {
       if (!d.fused3) {
         Timed t(h, SVILS_KERNEL_TAIL);
@@ -293,6 +375,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
 int run_phase(svils_handle *h, svils_phase ph, bool fused) { return run_phase(h, ph, h->geo, h->d, h->prm, fused); }
 
 void drop_graphs_of(svils_handle *h) {
+  for (auto &g_ : h->sgexec) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
   if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
   if (h->gexecN) { (void)hipGraphExecDestroy(h->gexecN); h->gexecN = nullptr; }
   for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
@@ -319,6 +402,54 @@ void chunk_row(std::vector<Item> &items, uint32_t p, uint32_t off, uint32_t len,
     items.push_back(Item{p, o, l, slot});
     o += l;
   }
+}
+
+// Node-block sweeps with caller-given (work-balanced) blocks: the s3 pass is not tied to the node blocks -- it reads the
+// replicated mean indicators of both endpoints and leaves a K-vector -- so the link list is simply cut into `world`
+// equal runs.  (With first-appearance numbering the low blocks hold the upper ends of most links: blocks balanced by
+// CSR entries would leave rank 0 with twice its share of the s3 pass.)
+int apply_s3_split(svils_handle *h) {
+  if (!h->have_graph || !h->blocks_set || !h->blocks_explicit || h->world <= 1) return 0;
+  const Geometry &g = h->geo;
+  DeviceState &d = h->d;
+  const uint64_t L = d.nlinks;
+  const uint64_t lb = L * (uint64_t)h->rank / (uint64_t)h->world, le = L * ((uint64_t)h->rank + 1) / (uint64_t)h->world;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  drop_graphs_of(h);
+  auto cap = [](uint64_t x, uint32_t lim) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(x, lim)); };
+  d.link_begin = lb;
+  d.link_end = le;
+  uint32_t nb_c;
+  if (d.lpl) {
+    nb_c = cap((le - lb + d.s3_threads - 1) / d.s3_threads, 192);
+  } else {
+    const int G = 64 / g.W;
+    const uint32_t ch = 32u * (uint32_t)G;
+    std::vector<Item> items;
+    // first node whose links reach past lb
+    uint32_t p = (uint32_t)(std::upper_bound(h->h_linkptr.begin(), h->h_linkptr.end(), lb) - h->h_linkptr.begin());
+    p = p ? p - 1 : 0;
+    for (; p < g.n && h->h_linkptr[p] < le; ++p) {
+      const uint64_t a = std::max(lb, h->h_linkptr[p]), b = std::min(le, h->h_linkptr[p + 1]);
+      if (b <= a) continue;
+      chunk_row(items, p, h->h_upper[p] + (uint32_t)(a - h->h_linkptr[p]), (uint32_t)(b - a), ch, nullptr, nullptr, nullptr);
+    }
+    dfree(h, &d.items_s3);
+    int rc = dalloc(h, &d.items_s3, items.size(), false);
+    if (rc) return rc;
+    if (!items.empty()) HIPCHK(hipMemcpyAsync(d.items_s3, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    d.nitems_s3 = (uint32_t)items.size();
+    d.item0_s3 = 0;
+    nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
+  }
+  if (nb_c > d.nb_c) {
+    dfree(h, &d.part_c);
+    int rc = dalloc(h, &d.part_c, (size_t)nb_c * g.K);
+    if (rc) return rc;
+  }
+  d.nb_c = nb_c;
+  return 0;
 }
 
 }  // namespace
@@ -610,14 +741,15 @@ int svils_comm_unique_id(void *id128) {
 int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
   if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SVILS_ERR_ARG, "svils_comm_init: bad argument");
   if (h->comm) return fail(SVILS_ERR_ARG, "svils_comm_init: communicator already initialised");
-  const Geometry &g = h->geo;
-  const uint32_t B = (g.n + (uint32_t)world - 1) / (uint32_t)world;
-  if (!h->d.ksh && (g.n_alloc != B * (uint32_t)world || g.node_begin != std::min(g.n, (uint32_t)rank * B) ||
-      g.node_end != std::min(g.n, ((uint32_t)rank + 1) * B)))
-    return fail(SVILS_ERR_ARG, "svils_comm_init: rank %d of %d needs node block [%u,%u) and n_alloc %u (handle has [%u,%u), %u)",
-                rank, world, std::min(g.n, (uint32_t)rank * B), std::min(g.n, ((uint32_t)rank + 1) * B), B * world,
-                g.node_begin, g.node_end, g.n_alloc);
-  int rc = rccl_load();
+  int rc;
+  if (!h->d.ksh) {
+    // the node blocks: what svils_set_node_blocks declared, else equal blocks of ceil(n / world) nodes
+    if (h->blocks_set && ((int)h->blk.world != world || h->rank != rank))
+      return fail(SVILS_ERR_ARG, "svils_comm_init: rank %d of %d, but svils_set_node_blocks declared rank %d of %u", rank, world,
+                  h->rank, h->blk.world);
+    if (!h->blocks_set && (rc = apply_blocks(h, rank, world, nullptr, false))) return rc;
+  }
+  rc = rccl_load();
   if (rc) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   ncclUniqueId id;
@@ -654,52 +786,38 @@ int exchange_sum(svils_handle *h, double *v, size_t count) {
   NCCLCHK(g_rccl.AllReduce(v, v, count, ncclDouble, ncclSum, h->comm, h->stream));
   return 0;
 }
-int exchange_sum2(svils_handle *h, double *a, size_t na, double *b, size_t nb) {   // one grouped launch
-  if (!h->comm) return 0;
-  Timed t(h, SVILS_KERNEL_EXCHANGE);
-  NCCLCHK(g_rccl.GroupStart());
-  NCCLCHK(g_rccl.AllReduce(a, a, na, ncclDouble, ncclSum, h->comm, h->stream));
-  NCCLCHK(g_rccl.AllReduce(b, b, nb, ncclDouble, ncclSum, h->comm, h->stream));
-  NCCLCHK(g_rccl.GroupEnd());
-  return 0;
-}
-int exchange_rows(svils_handle *h) {
-  if (!h->comm) return 0;
-  Timed t(h, SVILS_KERNEL_EXCHANGE);
-  const Geometry &g = h->geo;
-  const DeviceState &d = h->d;
-  const size_t B = g.n_alloc / (size_t)h->world;
-  NCCLCHK(g_rccl.GroupStart());
-  NCCLCHK(g_rccl.AllGather(d.gamma + (size_t)h->rank * B * g.ld, d.gamma, B * g.ld, ncclDouble, h->comm, h->stream));
-  NCCLCHK(g_rccl.AllGather(d.xflags + (size_t)h->rank * B * d.xf_ld, d.xflags, B * d.xf_ld, ncclUint32, h->comm, h->stream));
-  NCCLCHK(g_rccl.GroupEnd());
-  return 0;
-}
-
-// chunks of the pipelined row exchange: one (the grouped all-gather above) while the whole n-by-k payload is below
+// chunks of the pipelined row exchange: one (a grouped all-gather) while the whole n-by-k payload is below
 // 256 MB, then one per 128 MB, at most eight
 uint32_t exchange_chunks(const svils_handle *h) {
   if (h->xchunks) return h->xchunks;
-  const uint64_t bytes = (uint64_t)h->geo.n_alloc * h->geo.ld * sizeof(double);
+  const uint64_t bytes = (uint64_t)h->geo.n * h->geo.ld * sizeof(double);
   return (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, bytes / (128ull << 20)));
 }
 
-// Phase B -> [row exchange || PHASE_EXPAND] -> phase C of a node-block sweep.  The gamma rows and packed flags of every
-// rank's node block travel in C chunks on the communication stream (chunk c = rows [c B / C, (c+1) B / C) of EVERY
-// block: one grouped launch of world x 2 in-place broadcasts, rank r the root of its own rows); as soon as chunk c has
-// arrived the compute stream re-derives Elogpi / exp(Elogpi) / mphi / flags of those rows (k_expand: n k digammas in
-// total, ~1 ms at n = 1e6, k = 512) while chunk c + 1 is on the links.  Exposed: the first chunk's transfer and the
-// last chunk's expansion instead of the whole gather followed by the whole expansion.
+// The ONE row exchange of a node-block sweep, between the light finalise pass and the s3 pass:
+//   all-reduce(SUM) of `sum[k]` (K doubles)  +  the unscaled new rows of every block, staged in gstage [world][bmax][ld]
+//   -> k_expand_all: annealing scale, gamma, Elogpi / exp(Elogpi), mean indicators of the other blocks, prune() flags of
+//      EVERY row (computed redundantly from identical bytes: flags are not exchanged).
+// Small payloads: one grouped launch {all-reduce, in-place all-gather of the slices padded to the largest block}.
+// From 256 MB on the rows travel in C chunks on the communication stream and a second communicator (chunk c = rows
+// [s c / C, s (c + 1) / C) of EVERY block of s rows: one grouped launch of `world` in-place broadcasts with the exact
+// counts, rank r the root of its own rows); as soon as chunk c has arrived the compute stream expands it while chunk
+// c + 1 is on the links.  Exposed: the first chunk's transfer and the last chunk's expansion.
 int exchange_rows_and_expand(svils_handle *h) {
-  const uint32_t C = h->comm ? exchange_chunks(h) : 1u;
-  if (C <= 1) {
-    int rc = exchange_rows(h);
-    if (rc) return rc;
-    return run_phase(h, SVILS_PHASE_EXPAND, false);
-  }
   const Geometry &g = h->geo;
   const DeviceState &d = h->d;
-  const uint32_t B = g.n_alloc / (uint32_t)h->world;
+  Blocks b = h->blk;
+  const uint32_t C = h->comm ? exchange_chunks(h) : 1u;
+  if (C <= 1) {
+    if (h->comm) {
+      Timed t(h, SVILS_KERNEL_EXCHANGE);
+      NCCLCHK(g_rccl.GroupStart());
+      NCCLCHK(g_rccl.AllReduce(d.kvec_a, d.kvec_a, g.K, ncclDouble, ncclSum, h->comm, h->stream));
+      NCCLCHK(g_rccl.AllGather(d.gown, d.gstage, (size_t)b.bmax * g.ld, ncclDouble, h->comm, h->stream));
+      NCCLCHK(g_rccl.GroupEnd());
+    }
+    return run_phase(h, SVILS_PHASE_EXPAND_ALL, false);
+  }
   if (!h->comm_stream) HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   if (!h->ev_ready) HIPCHK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
   {
@@ -715,25 +833,57 @@ int exchange_rows_and_expand(svils_handle *h) {
   Timed t(h, SVILS_KERNEL_EXCHANGE);   // on the compute stream: from "rows may leave" to "last chunk expanded"
   HIPCHK(hipEventRecord(h->ev_ready, h->stream));
   HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+  NCCLCHK(g_rccl.AllReduce(d.kvec_a, d.kvec_a, g.K, ncclDouble, ncclSum, h->comm, h->stream));   // k_expand_all reads it
+  b.nchunks = C;
   for (uint32_t c = 0; c < C; ++c) {
-    const uint32_t xb = (uint32_t)((uint64_t)B * c / C), xe = (uint32_t)((uint64_t)B * (c + 1) / C);
-    if (xe <= xb) continue;
-    const size_t rows = xe - xb;
     NCCLCHK(g_rccl.GroupStart());
     for (int r = 0; r < h->world; ++r) {
-      const size_t row0 = (size_t)r * B + xb;
-      double *gp = d.gamma + row0 * g.ld;
-      uint32_t *xp = d.xflags + row0 * d.xf_ld;
-      NCCLCHK(g_rccl.Broadcast(gp, gp, rows * g.ld, ncclDouble, r, rows_comm, h->comm_stream));
-      NCCLCHK(g_rccl.Broadcast(xp, xp, rows * d.xf_ld, ncclUint32, r, rows_comm, h->comm_stream));
+      uint32_t lo, hi;
+      chunk_range(b.bounds[r + 1] - b.bounds[r], c, C, &lo, &hi);
+      if (hi <= lo) continue;
+      double *gp = d.gstage + ((size_t)r * b.bmax + lo) * g.ld;
+      NCCLCHK(g_rccl.Broadcast(gp, gp, (size_t)(hi - lo) * g.ld, ncclDouble, r, rows_comm, h->comm_stream));
     }
     NCCLCHK(g_rccl.GroupEnd());
     HIPCHK(hipEventRecord(h->ev_chunk[c], h->comm_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chunk[c], 0));
-    launch_expand_chunk(g, d, h->prm, xb, xe, B, h->stream);
+    b.chunk = c;
+    launch_expand_all(g, d, h->prm, b, h->stream);
     HIPCHK(hipGetLastError());
   }
   return 0;
+}
+
+// one node-block sweep: two exchange points, whatever the annealing flag says (nothing here looks at the control block)
+int sharded_sweep_once(svils_handle *h) {
+  int rc;
+  if ((rc = run_phase(h, SVILS_PHASE_A, false))) return rc;
+  if ((rc = run_phase(h, SVILS_PHASE_B_LIGHT, false))) return rc;
+  if ((rc = exchange_rows_and_expand(h))) return rc;
+  if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
+  if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)h->geo.K))) return rc;
+  return run_phase(h, SVILS_PHASE_D, false);
+}
+
+// `nsweeps` node-block sweeps, collectives included, captured into an executable graph.  RCCL's collectives are
+// stream-capturable; the communication stream of the pipelined exchange forks from and joins the handle's stream through
+// events, which capture follows.  Anything that fails ends the capture and the caller stays eager for good.
+hipGraphExec_t capture_sharded(svils_handle *h, uint32_t nsweeps) {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const uint64_t issued = h->sweeps_issued;
+  const uint32_t saved = h->tmask;
+  h->tmask = 0;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { h->tmask = saved; (void)hipGetLastError(); return nullptr; }
+  int rc = 0;
+  for (uint32_t i = 0; i < nsweeps && !rc; ++i) rc = sharded_sweep_once(h);
+  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  h->tmask = saved;
+  h->sweeps_issued = issued;   // nothing ran
+  if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+  (void)hipGraphDestroy(graph);
+  return exec;
 }
 }  // namespace
 
@@ -749,35 +899,39 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
     return fail(SVILS_ERR_ARG, "svils_sweep_sharded: at most %llu sweeps per call",
                 (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
   HIPCHK(hipSetDevice(h->cfg.device));
-  const Geometry &g = h->geo;
-  // `sum[k]` is needed between the phi pass and the finalise pass only while annealing (the ones/sum[k]
-  // scale, src/linksampling.cc:542); afterwards its only reader is lambda[k][0] in the tail, so its
-  // all-reduce rides with the one of s1,s2,s3: two collectives' latencies per sweep instead of three.
-  // The flag is replicated in every rank's control block and only ever goes from 1 to 0 inside a run, so
-  // every rank takes the same form; it is looked at (one stream synchronisation) when a call starts and
-  // every 16 sweeps until it is off.
-  bool annealing = true;
-  for (uint32_t i = 0; i < nsweeps; ++i) {
-    int rc;
-    if (annealing && (i & 15u) == 0u) {
-      DevCtrl c;
-      HIPCHK(hipMemcpyAsync(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      if (c.fault) return fault_error(c.fault);
-      annealing = c.annealing != 0;
+  int rc = ensure_blocks(h);
+  if (rc) return rc;
+  // The sweep has the same shape in both phases of a run (the annealing scale is applied on the device, behind the
+  // exchange), so nothing here reads the control block and whole runs of sweeps replay as hipGraphs -- under the same
+  // rule as svils_sweep: eager until the handle has run graph_after sweeps, timing brackets need eager launches.
+  // SVILS_SHARDED_GRAPHS=0 keeps every sweep eager.  Every rank takes the same decisions (same arguments, same
+  // history), so the ranks enqueue the same collectives in the same order whether they replay or launch.
+  static const bool graphs_wanted = !(getenv("SVILS_SHARDED_GRAPHS") && atoi(getenv("SVILS_SHARDED_GRAPHS")) == 0);
+  const bool warm = h->sgexec[0] != nullptr || h->sweeps_issued + nsweeps >= h->graph_after || nsweeps >= 64;
+  uint32_t left = nsweeps;
+  if (graphs_wanted && h->sgraphs_ok && h->tmask == 0 && nsweeps >= 4 && warm) {
+    // the first sweep of a handle runs eagerly: lazily created objects (communication stream, second communicator,
+    // events, the first stand-alone classification) must exist before a capture
+    if (h->sweeps_issued == 0) { if ((rc = sharded_sweep_once(h))) return rc; --left; }
+    if ((rc = ensure_classes(h))) return rc;
+    for (int i = (int)svils_handle::kGraphMaxLog; i >= 0 && h->sgraphs_ok; --i) {
+      const uint32_t m = 1u << i;
+      if (left < m) continue;
+      if (!h->sgexec[i]) {
+        h->sgexec[i] = capture_sharded(h, m);
+        if (!h->sgexec[i]) {
+          if (i == 0) { h->sgraphs_ok = false; drop_graphs_of(h); }   // not even one sweep captures: eager from now on
+          continue;
+        }
+      }
+      for (; left >= m; left -= m) {
+        HIPCHK(hipGraphLaunch(h->sgexec[i], h->stream));
+        h->sweeps_issued += m;
+      }
     }
-    if ((rc = run_phase(h, SVILS_PHASE_A, false))) return rc;
-    if (annealing && (rc = exchange_sum(h, h->d.kvec_a, g.K))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_B, false))) return rc;
-    if ((rc = exchange_rows_and_expand(h))) return rc;
-    if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
-    if (annealing) {
-      if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)g.K))) return rc;
-    } else if ((rc = exchange_sum2(h, h->d.kvec_a, g.K, h->d.kvec_c, 3 * (size_t)g.K))) {
-      return rc;
-    }
-    if ((rc = run_phase(h, SVILS_PHASE_D, false))) return rc;
   }
+  for (; left > 0; --left)
+    if ((rc = sharded_sweep_once(h))) return rc;
   return 0;
 }
 
@@ -813,8 +967,12 @@ int svils_step_sharded(svils_handle *h, uint32_t nsteps) {
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_sharded: call svils_set_stochastic first");
   if (!h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step_sharded: svils_set_stochastic needs shard_block (the node-block size)");
   if (!h->comm && h->geo.n_alloc != h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step_sharded: call svils_comm_init first");
-  if (h->comm && (size_t)h->geo.n_alloc / (size_t)h->world != h->scfg.shard_block)
-    return fail(SVILS_ERR_ARG, "svils_step_sharded: shard_block %u is not the communicator's node-block size", h->scfg.shard_block);
+  if (h->blocks_explicit)
+    return fail(SVILS_ERR_ARG, "svils_step_sharded: mini-batch steps need the equal node blocks of svils_comm_init, not caller-given ones");
+  if (h->comm && ((size_t)h->geo.n_alloc != (size_t)h->world * h->scfg.shard_block ||
+                  h->scfg.shard_block != (h->geo.n + (uint32_t)h->world - 1) / (uint32_t)h->world))
+    return fail(SVILS_ERR_ARG, "svils_step_sharded: need shard_block = ceil(n / world) = %u and n_alloc = world * shard_block (have %u, %u)",
+                (h->geo.n + (uint32_t)h->world - 1) / (uint32_t)h->world, h->scfg.shard_block, h->geo.n_alloc);
   if (nsteps > (uint64_t)h->d.rows_cap * h->prm.reportfreq)
     return fail(SVILS_ERR_ARG, "svils_step_sharded: at most %llu steps per call",
                 (unsigned long long)h->d.rows_cap * h->prm.reportfreq);
@@ -1069,8 +1227,53 @@ int svils_gather_communities(svils_handle *h) {
   if (!h->comm) return h->world == 1 ? 0 : fail(SVILS_ERR_ARG, "svils_gather_communities: call svils_comm_init first");
   HIPCHK(hipSetDevice(h->cfg.device));
   const Geometry &g = h->geo;
-  const size_t B = g.n_alloc / (size_t)h->world;
-  NCCLCHK(g_rccl.AllGather(h->d.member + (size_t)h->rank * B * g.kw, h->d.member, B * g.kw, ncclUint64, h->comm, h->stream));
+  // every block's rows of the community bitmask, in place, with the exact counts (the blocks differ in size)
+  NCCLCHK(g_rccl.GroupStart());
+  for (int r = 0; r < h->world; ++r) {
+    const size_t rows = h->blk.bounds[r + 1] - h->blk.bounds[r];
+    if (!rows) continue;
+    uint64_t *mp = h->d.member + (size_t)h->blk.bounds[r] * g.kw;
+    NCCLCHK(g_rccl.Broadcast(mp, mp, rows * g.kw, ncclUint64, r, h->comm, h->stream));
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  return 0;
+}
+
+int svils_set_node_blocks(svils_handle *h, int rank, int world, const uint32_t *bounds) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_set_node_blocks: null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  return apply_blocks(h, rank, world, bounds, bounds != nullptr);
+}
+
+int svils_balance_node_blocks(const uint32_t *links, uint64_t nlinks, uint32_t n, int world, double node_weight, uint32_t *bounds) {
+  if ((!links && nlinks) || !bounds || n == 0 || world < 1 || world > SVILS_MAX_WORLD)
+    return fail(SVILS_ERR_ARG, "svils_balance_node_blocks: bad argument (at most %d ranks)", SVILS_MAX_WORLD);
+  if (node_weight < 0.0) node_weight = 0.5;
+  std::vector<uint32_t> deg(n, 0);
+  for (uint64_t l = 0; l < nlinks; ++l) {
+    const uint32_t p = links[2 * l], q = links[2 * l + 1];
+    if (p >= n || q >= n) return fail(SVILS_ERR_ARG, "svils_balance_node_blocks: link %llu names node %u / %u (n = %u)", (unsigned long long)l, p, q, n);
+    deg[p]++;
+    deg[q]++;
+  }
+  // cost of a node = its CSR entries (the phi pass evaluates each once) + node_weight (the per-node part of the finalise
+  // pass, in units of one entry); cut r goes where the running cost is closest to r / world of the total
+  const double total = 2.0 * (double)nlinks + node_weight * (double)n;
+  bounds[0] = 0;
+  double run = 0.0;
+  uint32_t x = 0;
+  for (int r = 1; r < world; ++r) {
+    const double target = total * (double)r / (double)world;
+    while (x < n) {
+      const double c = (double)deg[x] + node_weight;
+      if (run + c > target && (run + c - target) > (target - run)) break;   // taking x overshoots by more than stopping short
+      run += c;
+      ++x;
+      if (run >= target) break;
+    }
+    bounds[r] = x;
+  }
+  bounds[world] = n;
   return 0;
 }
 
@@ -1084,6 +1287,7 @@ int svils_destroy(svils_handle *h) {
   if (h->gexec1) (void)hipGraphExecDestroy(h->gexec1);
   if (h->gexecN) (void)hipGraphExecDestroy(h->gexecN);
   for (auto &g_ : h->gexecP) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
+  for (auto &g_ : h->sgexec) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);   // nothing of a communicator may still be enqueued
   comm_destroy(h);
   if (h->stage) (void)hipFree(h->stage);
@@ -1313,8 +1517,9 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->h_rowptr.swap(rowptr);
+  h->h_upper.swap(upper);
   h->have_graph = true;
-  return 0;
+  return apply_s3_split(h);
 }
 
 int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) {
@@ -2186,6 +2391,9 @@ int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr, size_t
     case SVILS_BUF_AMASK: *dptr = d.amask; *row_bytes = g.kw * sizeof(uint64_t); *bytes = *row_bytes * g.n_alloc; return 0;
     case SVILS_BUF_MEMBER: *dptr = d.member; *row_bytes = g.kw * sizeof(uint64_t); *bytes = *row_bytes * g.n_alloc; return 0;
     case SVILS_BUF_XFLAGS: *dptr = d.xflags; *row_bytes = d.xf_ld * sizeof(uint32_t); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_GSTAGE:
+      if (!h->blocks_set) return fail(SVILS_ERR_ARG, "svils_device_buffer: SVILS_BUF_GSTAGE exists once the node blocks are declared (svils_set_node_blocks)");
+      *dptr = d.gstage; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * h->blk.bmax * h->blk.world; return 0;
     default: return fail(SVILS_ERR_ARG, "svils_device_buffer: unknown buffer %d", (int)which);
   }
 }

@@ -398,7 +398,11 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
 // compute_mean_indicators (src/linksampling.cc:526-545), the gamma swap/reset
 // (:751-755), set_dir_exp (src/linksampling.hh:170-187) and prune (:455-491),
 // one group per owned node.
-template <int W, int V, bool STOCH>
+// LIGHT (node-block sweeps, svils_sweep_sharded): only what does not need the all-reduced `sum` -- the mean indicators, their
+// s1 / s2 partials, the community tags and the UNSCALED new row, written to this rank's slice of the exchange staging
+// (d.gown) instead of gamma; the annealing scale, Elogpi and prune() follow for every row, owned or not, in k_expand_all
+// once the rows and `sum` have crossed the ranks (one exchange point instead of two).
+template <int W, int V, bool STOCH, bool LIGHT = false>
 // V = 16: two waves per SIMD asked for (256 VGPRs with spills instead of 277 + one wave): ca-AstroPh K=1024 354 -> 273 us,
 // n=1e5 K=1024 1.22 -> 1.04 ms
 __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
   const int lane = threadIdx.x & 63, wave = (W == 64) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
-  const bool annealing = ctrl->annealing != 0;
+  const bool annealing = !LIGHT && ctrl->annealing != 0;
   const bool write_comm = ctrl->write_comm != 0;
   const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
   uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
 #pragma unroll
   for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
   // 1 / scale of this sweep, for whoever derives the mean indicators from the gamma rows written below
-  if (blockIdx.x == 0 && threadIdx.x < W) {
+  if (!LIGHT && blockIdx.x == 0 && threadIdx.x < W) {
 #pragma unroll
     for (int v = 0; v < V; ++v)
       if (kval[v]) d.iscale[kidx[v]] = annealing ? (STOCH ? d.kvec_a[kidx[v]] * prm.scale_a : d.kvec_a[kidx[v]]) / (double)prm.ones : 1.0;
@@ -502,11 +506,15 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
           }
         if (lw == 0) d.ncnt[p] = c + 1u;
       }
-      if (STOCH || !d.derive_m) store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+      if (STOCH || LIGHT || !d.derive_m) store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     } else {
       // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
 #pragma unroll
       for (int v = 0; v < V; ++v) gn[v] = kval[v] ? prm.alpha : 0.0;
+    }
+    if constexpr (LIGHT) {
+      store_row<W, V>(d.gown + (size_t)i * ld, lw, ld, gn);
+      continue;
     }
     store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
     double rs = 0.0;
@@ -666,6 +674,100 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
     store_epi<W, V>(d, p, lw, ld, K, el);
     store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
+  }
+}
+
+// Node-block sweeps, second half of the node finalise for EVERY row (owned or not), after the exchange: the staged row
+// is the unscaled gammanext of compute_mean_indicators (src/linksampling.cc:536-540); here the annealing scale
+// ones / sum[k] (:541-542, `sum` all-reduced by now), the swap into gamma (:751), set_dir_exp (src/linksampling.hh:170-187)
+// and prune (:455-491).  Every rank computes every row's flags from the same bytes with the same instructions, so the
+// flags are replicated without being exchanged.  The mean indicators of rows another rank owns are re-derived from the
+// staged row, m = (row - alpha) / (n - 1) (gammanext = alpha + acc + (n - tl - 1) acc / tl = alpha + acc (n - 1) / tl);
+// the owner stored its own in the light finalise pass.
+template <int W, int V>
+__global__ __launch_bounds__(256) void k_expand_all(Geometry geo, DeviceState d, Params prm, Blocks blk) {
+  const DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  constexpr int G = 64 / W;
+  __shared__ double2 logtab[128];
+  load_logtab(logtab, d.logtab);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / W, lw = lane % W;
+  const uint32_t K = geo.K, ld = geo.ld;
+  const bool annealing = ctrl->annealing != 0;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
+  int kidx[V];
+  bool kval[V];
+  double scale[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    kidx[v] = kmap<W, V>(lw, v);
+    kval[v] = (uint32_t)kidx[v] < K;
+    scale[v] = (annealing && kval[v]) ? (double)prm.ones / d.kvec_a[kidx[v]] : 1.0;   // _network.ones() / _sum[k]
+  }
+  if (blockIdx.x == 0 && threadIdx.x < W && blk.chunk == 0) {
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      if (kval[v]) d.iscale[kidx[v]] = annealing ? d.kvec_a[kidx[v]] / (double)prm.ones : 1.0;
+  }
+  const double inv_nm1 = 1.0 / ((double)geo.n - 1.0);
+  // rows of a slice this launch may touch: the whole slice, or one chunk of it (+1: chunk boundaries are rounded per block)
+  const uint32_t clen = blk.nchunks > 1 ? (blk.bmax + blk.nchunks - 1) / blk.nchunks + 1u : blk.bmax;
+  const uint64_t total = (uint64_t)blk.world * clen;
+  for (uint64_t i = (uint64_t)(blockIdx.x * 4 + wave) * G + g; i < total; i += (uint64_t)gridDim.x * 4 * G) {
+    const uint32_t r = (uint32_t)(i / clen), jj = (uint32_t)(i % clen);
+    uint32_t lo, hi;
+    chunk_range(blk.bounds[r + 1] - blk.bounds[r], blk.chunk, blk.nchunks, &lo, &hi);
+    const uint32_t j = lo + jj;
+    if (j >= hi) continue;
+    const uint32_t p = blk.bounds[r] + j;
+    const bool own = p >= geo.node_begin && p < geo.node_end;
+    const bool has = d.rowptr[p + 1] != d.rowptr[p];
+    double gn[V];
+    load_row<W, V>(d.gstage + ((size_t)r * blk.bmax + j) * ld, lw, ld, gn);
+    double m[V];
+    double rs = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      m[v] = (kval[v] && has) ? (gn[v] - prm.alpha) * inv_nm1 : 0.0;
+      if (has) gn[v] *= scale[v];       // rows without a training link stay alpha, unscaled (:532-533)
+      if (!kval[v]) gn[v] = 0.0;
+      rs += gn[v];
+    }
+    store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+    if (!own) store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
+    rs = group_sum<W>(rs);
+    const double psi_rs = digamma(rs, logtab);
+    double el[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
+    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    store_epi<W, V>(d, p, lw, ld, K, el);
+    // prune / check_and_set_converged, src/linksampling.cc:455-475
+    uint32_t active = 0;
+    int last_k = -1;
+    unsigned long long bits[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const bool a = kval[v] && (gn[v] - prm.alpha >= 1.0);
+      const unsigned long long b = (__ballot(a) >> (g * W)) & (W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull));
+      bits[v] = b;
+      active += (uint32_t)__popcll(b);
+      if (a) last_k = max(last_k, kidx[v]);
+    }
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) last_k = max(last_k, __shfl_xor(last_k, o, 64));
+    if (lw == 0) {
+      const uint32_t cnew = (active == 1) ? (uint32_t)last_k + 1u : conv_old[p];
+      conv_new[p] = cnew;
+      d.active_cnt[p] = active;
+      const uint8_t cf = cflag_pack(cnew, active < geo.k10);
+      if (d.cflag[p] != cf) { d.cflag[p] = cf; d.cls_epoch[0] = ctrl->sweeps_done + 1u; }   // see k_finalize_lpl
+#pragma unroll
+      for (int v = 0; v < V; ++v) d.amask[(size_t)p * geo.kw + v] = (active <= geo.k10) ? bits[v] : 0ull;
+    }
   }
 }
 
@@ -1379,6 +1481,7 @@ void launch_finalize(const Geometry &g, const DeviceState &d, const Params &p, h
 #define CALL(W_, V_)                                                                                     \
   do {                                                                                                   \
     if (p.stoch) hipLaunchKernelGGL((k_finalize<W_, V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p); \
+    else if (d.light) hipLaunchKernelGGL((k_finalize<W_, V_, false, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p); \
     else hipLaunchKernelGGL((k_finalize<W_, V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p);        \
   } while (0)
   SVILS_DISPATCH_V(g, CALL);
@@ -1477,6 +1580,16 @@ void launch_expand_chunk(const Geometry &g, const DeviceState &d, const Params &
 }
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   launch_expand_chunk(g, d, p, 0, 0, 0, s);
+}
+void launch_expand_all(const Geometry &g, const DeviceState &d, const Params &p, const Blocks &b, hipStream_t s) {
+  const uint32_t clen = b.nchunks > 1 ? (b.bmax + b.nchunks - 1) / b.nchunks + 1u : b.bmax;
+  const uint64_t total = (uint64_t)b.world * clen;
+  if (total == 0) return;
+  const int G = 64 / g.W;
+  const uint32_t nb = (uint32_t)std::min<uint64_t>((total + 4 * G - 1) / (4 * G), 2048);
+#define CALL(W_, V_) hipLaunchKernelGGL((k_expand_all<W_, V_>), dim3(nb), dim3(256), 0, s, g, d, p, b)
+  SVILS_DISPATCH(g, CALL);
+#undef CALL
 }
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s) {
   const int G = 64 / g.W;

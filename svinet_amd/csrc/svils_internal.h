@@ -134,6 +134,11 @@ struct DeviceState {
   uint32_t *fcnt;       // [n_alloc][ld] tag counts (lt_min_deg > 0), else null
   // state
   double *gamma;        // [n_alloc][ld]; doubles as gammanext-accumulator inside a sweep
+  // Node-block sweeps (svils_sweep_sharded): the staging of the row exchange, [world][bmax][ld] -- the light finalise pass
+  // writes the UNSCALED new rows of the owned block into slice `rank` (gown = its first row), the all-gather (or the
+  // chunked broadcasts) fills the other slices, k_expand_all turns every row into gamma / Elogpi / flags
+  double *gstage, *gown;
+  int light;            // 1: this launch of the finalise pass is the light one
   double *gacc;         // where the phi pass accumulates gammanext: == gamma for full sweeps, a separate
                         // [n_alloc][ld] buffer in mini-batch mode (the old gamma row is blended in)
   uint32_t *ncnt;       // [n_alloc] mini-batch mode: number of updates each node has received
@@ -198,6 +203,20 @@ struct DeviceState {
   const double *logtab;      // [128][2] {1/c_i, ln c_i} for log_tab()
 };
 
+// The node blocks of all ranks of a node-block run: rank r owns nodes [bounds[r], bounds[r + 1]), balanced by work
+// (svils_balance_node_blocks), not equal in size; passed by value to the kernels that walk the staged rows.
+constexpr int SVILS_MAX_WORLD = 64;
+struct Blocks {
+  uint32_t world, bmax;                 // ranks; rows of the largest block = rows of a staging slice
+  uint32_t chunk, nchunks;              // this launch covers chunk `chunk` of `nchunks` of EVERY block (pipelined exchange)
+  uint32_t bounds[SVILS_MAX_WORLD + 1];
+};
+// rows [lo, hi) of a block of `size` rows that chunk c of C covers
+__host__ __device__ inline void chunk_range(uint32_t size, uint32_t c, uint32_t C, uint32_t *lo, uint32_t *hi) {
+  *lo = (uint32_t)((uint64_t)size * c / C);
+  *hi = (uint32_t)((uint64_t)size * (c + 1) / C);
+}
+
 struct Params {
   uint64_t ones;
   double alpha, eta0, eta1, epsilon, link_thresh;
@@ -244,6 +263,7 @@ void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
                           uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s);
 void launch_expand(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
+void launch_expand_all(const Geometry &g, const DeviceState &d, const Params &p, const Blocks &b, hipStream_t s);
 void launch_expand_chunk(const Geometry &g, const DeviceState &d, const Params &p, uint32_t xb, uint32_t xe, uint32_t block,
                          hipStream_t s);
 void launch_dir_exp(const Geometry &g, const DeviceState &d, hipStream_t s);

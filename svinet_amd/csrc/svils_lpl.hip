@@ -565,7 +565,9 @@ __device__ __forceinline__ FinIdx fin_load_idx(const DeviceState &d, uint32_t p,
   return x;
 }
 
-template <int FW, int NC, bool STOCH>
+// LIGHT: the node-block form (see k_finalize in svils_device.hip): mean indicators, s1 / s2, tags and the unscaled row into
+// the exchange staging; scale, Elogpi and prune() follow in k_expand_all behind the exchange.
+template <int FW, int NC, bool STOCH, bool LIGHT = false>
 __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(1, 0);
   DevCtrl *ctrl = d.ctrl;
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
   load_logtab(logtab, d.logtab);
   if (stopped) return;
   STAMP(1, 1);
-  const bool annealing = c_ann != 0;
+  const bool annealing = !LIGHT && c_ann != 0;
   const bool write_comm = c_wc != 0;
   const uint32_t *__restrict__ conv_old = d.conv + (size_t)c_par * geo.n_alloc;
   uint32_t *__restrict__ conv_new = d.conv + (size_t)(c_par ^ 1u) * geo.n_alloc;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
         for (int j = 0; j < NC; ++j) acc[j] += (double)hh[lw + j * FW];
       }
     }
-    const uint32_t cf_old = (ok && lw == 0) ? (uint32_t)d.cflag[p] : 0u;
+    const uint32_t cf_old = (!LIGHT && ok && lw == 0) ? (uint32_t)d.cflag[p] : 0u;
     // graphs of more nodes than resident groups: the NEXT node's index words travel while this one is finalised (a
     // round is a chain of dependent misses -- index words -> pieces -> stores -- and at n = 1e6 a wave runs ~40 of them)
     const bool ok_next = (uint64_t)i + stride < nown;
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     }
     if (first) {
       // everything the first node needs is in flight; now `sum`
-      if (threadIdx.x < 64) {
+      if (!LIGHT && threadIdx.x < 64) {
         double t = 1.0;
         if (d.fold) {
           t = (c_cpar & 1u) ? fx_value(ah1, al1, d.fx_inv) + (double)sh1 : fx_value(ah0, al0, d.fx_inv) + (double)sh0;
@@ -816,6 +818,13 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
       // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
 #pragma unroll
       for (int j = 0; j < NC; ++j) { gn[j] = kv[j] ? prm.alpha : 0.0; m[j] = 0.0; }
+    }
+    if constexpr (LIGHT) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (ST(j)) d.gown[(size_t)i * ld + lw + j * FW] = gn[j];
+      ix = ix_next;
+      continue;
     }
     double rsl = 0.0;
 #pragma unroll
@@ -1288,6 +1297,7 @@ void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &
 #define FIN(W_, NC_)                                                                                \
   do {                                                                                              \
     if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, true>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p); \
+    else if (d.light) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false, true>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p); \
     else hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p);  \
   } while (0)
   FIN_DISPATCH(g.K, FIN);

@@ -23,6 +23,12 @@
 //     instead of hidden bugs.  FAKERCCL_DELAY_US stretches every collective (the stream stays blocked that long after
 //     the peers met), which turns "usually fast enough" races into certain ones.  The operations of ONE communicator
 //     are executed in issue order whatever their streams, as RCCL serialises them.
+//   Stream capture (asynchronous mode only): a collective issued on a CAPTURING stream becomes graph nodes (copy to a
+//     staging buffer that lives as long as the communicator, host node, copy back) and runs at every replay of the graph,
+//     as RCCL's captured collectives do.  Captured operations take their turn in stream order (every communicator of the
+//     library is used from one stream); the synchronous mode refuses a capturing stream with ncclInvalidUsage, which is
+//     how the tests reach the library's "capture failed, stay eager" path.
+//   FAKERCCL_EXECUTED=<file>: rank 0 writes "<collectives executed> <of which from captured graphs>" at exit.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -49,6 +55,7 @@ struct Header {
   std::atomic<uint32_t> failed;
   std::atomic<uint64_t> calls;   // collectives executed (all ranks count the same ones): test evidence
 };
+std::atomic<uint64_t> g_executed{0}, g_executed_captured{0};   // this process: collectives that ran / ran from a graph replay
 
 struct AsyncOp;
 struct Comm {
@@ -62,6 +69,8 @@ struct Comm {
   uint64_t issued = 0;                        // operations enqueued (host order)
   std::atomic<uint64_t> completed{0};         // operations whose host function has run: ops of one communicator go in issue order
   std::vector<AsyncOp *> inflight;            // staging of operations that may still be running, reaped at later calls
+  std::vector<AsyncOp *> graph_ops;           // operations captured into graphs: alive until the communicator goes
+  std::mutex graph_mu;                        // captured operations of one communicator run one at a time
   std::vector<std::pair<unsigned char *, size_t>> pool;   // pinned buffers free for reuse
 };
 
@@ -89,6 +98,18 @@ void write_stats(const Comm *c) {   // test evidence: "<rank> <world> <collectiv
 }
 
 void at_exit() {
+  if (const char *path = getenv("FAKERCCL_EXECUTED")) {
+    bool rank0 = false;
+    for (const Comm *c : g_live) rank0 = rank0 || c->rank == 0;
+    static bool written = false;
+    if ((rank0 || g_live.empty()) && !written) {
+      if (FILE *f = fopen(path, "w")) {
+        fprintf(f, "%llu %llu\n", (unsigned long long)g_executed.load(), (unsigned long long)g_executed_captured.load());
+        fclose(f);
+        written = true;
+      }
+    }
+  }
   for (const Comm *c : g_live) write_stats(c);
   g_live.clear();
 }
@@ -155,6 +176,11 @@ ncclResult_t run(const Op &o) {
   if (o.kind == 0 && !(o.red == ncclSum || o.red == ncclMax || o.red == ncclMin)) return ncclInvalidArgument;
   if (o.kind == 0 && !(o.dt == ncclFloat64 || o.dt == ncclUint32 || o.dt == ncclUint64 || o.dt == ncclInt32 || o.dt == ncclInt64))
     return ncclInvalidArgument;
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(o.stream, &cap);
+    if (cap == hipStreamCaptureStatusActive) return ncclInvalidUsage;   // the synchronous mode cannot be captured
+  }
   HIPOK(hipStreamSynchronize(o.stream));
   const size_t per = (kSlot / es) * es / 8 * 8;   // elements' bytes per round, multiple of 8
   const size_t total = o.count * es;
@@ -189,6 +215,7 @@ ncclResult_t run(const Op &o) {
     if (total == 0) break;
   }
   if (c->rank == 0) c->hdr->calls.fetch_add(1);
+  g_executed.fetch_add(1);
   c->calls++;
   c->moved += total;
   return ncclSuccess;
@@ -206,6 +233,7 @@ long delay_us() {
 
 struct AsyncOp {
   Op o;
+  bool captured = false;                         // a graph node: runs at every replay, takes its turn in stream order
   uint64_t seq = 0;
   unsigned char *in = nullptr, *out = nullptr;   // pinned staging
   size_t in_cap = 0, out_cap = 0;
@@ -250,7 +278,9 @@ void host_exchange(void *arg) {
   Comm *c = o.comm;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
-  while (c->completed.load(std::memory_order_acquire) != a->seq) {   // RCCL serialises the ops of one communicator
+  std::unique_lock<std::mutex> turn(c->graph_mu, std::defer_lock);
+  if (a->captured) turn.lock();
+  while (!a->captured && c->completed.load(std::memory_order_acquire) != a->seq) {   // RCCL serialises the ops of one communicator
     if ((++spins & 1023u) == 0) {
       if (spins > 8192u) usleep(50); else sched_yield();
       if (c->hdr->failed.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s()) {
@@ -295,7 +325,9 @@ void host_exchange(void *arg) {
   if (!ok) fprintf(stderr, "fakerccl: rank %d: asynchronous op %llu failed (a peer is missing)\n", c->rank, (unsigned long long)a->seq);
   if (const long us = delay_us()) usleep((useconds_t)us);   // the collective "takes" this long: the stream stays blocked
   if (c->rank == 0) c->hdr->calls.fetch_add(1);
-  c->completed.store(a->seq + 1, std::memory_order_release);
+  g_executed.fetch_add(1);
+  if (a->captured) g_executed_captured.fetch_add(1);
+  else c->completed.store(a->seq + 1, std::memory_order_release);
 }
 
 ncclResult_t enqueue(const Op &o) {
@@ -306,23 +338,31 @@ ncclResult_t enqueue(const Op &o) {
   if (o.kind == 0 && !(o.dt == ncclFloat64 || o.dt == ncclUint32 || o.dt == ncclUint64 || o.dt == ncclInt32 || o.dt == ncclInt64))
     return ncclInvalidArgument;
   if (c->hdr->failed.load()) return ncclSystemError;
-  reap(c, false);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(o.stream, &cap);
+  const bool capturing = cap == hipStreamCaptureStatusActive;
+  if (!capturing) reap(c, false);
   const size_t total = o.count * es;
   AsyncOp *a = new AsyncOp;
   a->o = o;
-  a->seq = c->issued++;
+  a->captured = capturing;
+  if (!capturing) a->seq = c->issued++;
   const bool contributes = o.kind != 2 || c->rank == o.root;
   const size_t out_bytes = o.kind == 1 ? total * (size_t)c->world : total;
   if (contributes) a->in = pinned(c, total, &a->in_cap);
   a->out = pinned(c, out_bytes, &a->out_cap);
   if ((contributes && !a->in) || !a->out) return ncclUnhandledCudaError;
-  HIPOK(hipEventCreateWithFlags(&a->done, hipEventDisableTiming));
+  if (!capturing) HIPOK(hipEventCreateWithFlags(&a->done, hipEventDisableTiming));
   if (contributes && total) HIPOK(hipMemcpyAsync(a->in, o.send, total, hipMemcpyDeviceToHost, o.stream));
   HIPOK(hipLaunchHostFunc(o.stream, host_exchange, a));
   if (out_bytes && !(o.kind == 2 && c->rank == o.root && o.recv == o.send))
     HIPOK(hipMemcpyAsync(o.recv, a->out, out_bytes, hipMemcpyHostToDevice, o.stream));
-  HIPOK(hipEventRecord(a->done, o.stream));
-  c->inflight.push_back(a);
+  if (capturing) {
+    c->graph_ops.push_back(a);     // the graph may be replayed until the communicator is destroyed
+  } else {
+    HIPOK(hipEventRecord(a->done, o.stream));
+    c->inflight.push_back(a);
+  }
   c->calls++;
   c->moved += total;
   return ncclSuccess;
@@ -384,6 +424,13 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm *c = (Comm *)comm;
   if (!c) return ncclSuccess;
   reap(c, true);                                     // asynchronous mode: whatever is still enqueued completes first
+  (void)hipDeviceSynchronize();                      // ... and no graph holding a captured operation is still running
+  for (AsyncOp *a : c->graph_ops) {
+    if (a->in) (void)hipHostFree(a->in);
+    if (a->out) (void)hipHostFree(a->out);
+    delete a;
+  }
+  c->graph_ops.clear();
   for (auto &b : c->pool) (void)hipHostFree(b.first);
   c->pool.clear();
   write_stats(c);

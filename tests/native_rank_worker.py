@@ -40,7 +40,7 @@ def main():
     assert os.environ.get("SVILS_RCCL_LIBRARY"), "the test names the transport"
     from svinet_amd import _svils
     from svinet_amd.host_api import Setup
-    from svinet_amd.sharded import block_size, node_block
+    from svinet_amd.sharded import balanced_bounds, block_size, node_block
     setup = Setup(path, n, k, link_thresh=0.3 if mode == "kshard-lowt" else 0.5)
     extra = {}
     if mode.startswith("kshard") or mode.startswith("kstep"):
@@ -74,9 +74,16 @@ def main():
         extra["gathered"] = eng.allgather_host(send, world)
     else:
         B = block_size(n, world)
-        eng = setup.engine(device=0, node_block=node_block(n, world, rank), n_alloc=B * world, use_validation_stop=False)
+        if mode.startswith("step") or mode == "sweep-equal":   # mini-batch steps need the equal blocks svils_comm_init assumes
+            eng = setup.engine(device=0, node_block=node_block(n, world, rank), n_alloc=B * world, use_validation_stop=False)
+        else:                                                   # whole sweeps: the work-balanced blocks, declared before the communicator
+            bounds = balanced_bounds(setup.links, n, world)
+            eng = setup.engine(device=0, node_block=(int(bounds[rank]), int(bounds[rank + 1])), use_validation_stop=False)
+            eng.set_node_blocks(rank, world, bounds)
+            extra_bounds = bounds
         eng.comm_init(comm_id(out, rank), rank, world)
-        eng.enable_timing(1 << _svils.KERNEL_EXCHANGE)
+        if not os.environ.get("NATIVE_RANK_NO_TIMING"):       # (timing brackets keep the sweeps eager: graphs need it off)
+            eng.enable_timing(1 << _svils.KERNEL_EXCHANGE)
         if mode.startswith("step"):
             _, nwin, kappa = mode.split(":")
             bn = (B + int(nwin) - 1) // int(nwin)

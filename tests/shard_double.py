@@ -1,32 +1,40 @@
-"""CPU test double for svinet_amd.sharded.HipShard: the four sweep phases on one
+"""CPU test double for svinet_amd.sharded.HipShard: the phases of a node-block sweep on one
 node block in numpy (pull-style, dense path), exposing the same surface
-(kvec_a, kvec_c, gather_list(), phase(), end_sweep()) with CPU torch tensors,
+(kvec_a, kvec_c, gstage, bounds, bmax, phase(), end_sweep()) with CPU torch tensors,
 so ShardedSweep's exchange protocol can be exercised with gloo.
 Test infrastructure only."""
 import numpy as np
 import torch
 from scipy.special import digamma
 
-from svinet_amd.sharded import block_size, node_block
+from svinet_amd.sharded import balanced_bounds, equal_bounds
 
 
 class NumpyShard:
-    def __init__(self, n, k, ones, ones_prob, eta, links, validation_sorted, gamma, lam, rank, world):
+    def __init__(self, n, k, ones, ones_prob, eta, links, validation_sorted, gamma, lam, rank, world, balanced=True):
         self.rank, self.world = rank, world
         self.n, self.k, self.ones = n, k, ones
         self.ones_prob, self.zeros_prob = ones_prob, 1 - ones_prob
         self.eta0, self.eta1 = eta
         self.alpha = 1.0 / k
-        self.B = block_size(n, world)
-        self.n_alloc = self.B * world
-        self.lo, self.hi = node_block(n, world, rank)
         links = np.asarray(links, dtype=np.int64)
+        # the library's own cut (host code of libsvils.so: no device needed), or the equal blocks
+        self.bounds = (balanced_bounds(links, n, world) if balanced else equal_bounds(n, world)).astype(np.int64)
+        self.bmax = int(np.diff(self.bounds).max())
+        self.n_alloc = n
+        self.lo, self.hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
         self.P = np.concatenate([links[:, 0], links[:, 1]])      # directed entries
         self.Q = np.concatenate([links[:, 1], links[:, 0]])
         own = (self.P >= self.lo) & (self.P < self.hi)
         self.P, self.Q = self.P[own], self.Q[own]
-        up = (links[:, 0] >= self.lo) & (links[:, 0] < self.hi)
-        self.UP, self.UQ = links[up, 0], links[up, 1]
+        # the s3 pass is cut by link count, not by node block (svils_set_node_blocks with caller-given bounds)
+        L = len(links)
+        if balanced and world > 1:
+            sl = slice(L * rank // world, L * (rank + 1) // world)
+            self.UP, self.UQ = links[sl, 0], links[sl, 1]
+        else:
+            up = (links[:, 0] >= self.lo) & (links[:, 0] < self.hi)
+            self.UP, self.UQ = links[up, 0], links[up, 1]
         self.deg = np.bincount(np.concatenate([links[:, 0], links[:, 1]]), minlength=n).astype(np.float64)
         self.val = np.asarray(validation_sorted, dtype=np.int64)
 
@@ -36,11 +44,10 @@ class NumpyShard:
         self.t_gamma[:n] = torch.from_numpy(np.array(gamma))
         g = self.t_gamma[:n].numpy()
         self.t_elogpi[:n] = torch.from_numpy(digamma(g) - digamma(g.sum(1, keepdims=True)))
+        self.gstage = torch.zeros(world * self.bmax, k, dtype=torch.float64)
         self.conv = torch.zeros(2, self.n_alloc, dtype=torch.int32)
         self.active = torch.zeros(self.n_alloc, 1, dtype=torch.int32)
-        self.amask = torch.zeros(self.n_alloc, 1, dtype=torch.int64)
         self.member = torch.zeros(self.n_alloc, 1, dtype=torch.int64)
-        self.xflags = torch.zeros(self.n_alloc, 4, dtype=torch.int32)   # conv (new), active, amask lo/hi
         self.kvec_a = torch.zeros(k, dtype=torch.float64)
         self.kvec_c = torch.zeros(3 * k, dtype=torch.float64)
         self.lam = np.array(lam, dtype=np.float64)
@@ -50,27 +57,36 @@ class NumpyShard:
         self.rows = []
 
     # ---- surface shared with HipShard ----
-    def gather_list(self):
-        return [self.t_gamma, self.xflags]
-
     def end_sweep(self):
         self.sweeps += 1
 
     def phase(self, ph):
-        (self._a, self._b, self._c, self._d, self._expand)[ph]()
+        # svils_phase: A, B, C, D, EXPAND, B_LIGHT, EXPAND_ALL
+        (self._a, None, self._c, self._d, None, self._b_light, self._expand_all)[ph]()
 
-    def _expand(self):
-        # rows of the other ranks: flags unpacked, Elogpi and mphi from the gathered gamma
-        n, lo, hi = self.n, self.lo, self.hi
+    def _expand_all(self):
+        """every row from the staged (unscaled) rows: annealing scale, gamma, Elogpi, mphi of the other blocks,
+        prune() flags -- the same on every rank"""
+        n, k = self.n, self.k
+        st = self.gstage.numpy()
+        raw = np.empty((n, k))
+        for r in range(self.world):
+            b0, b1 = int(self.bounds[r]), int(self.bounds[r + 1])
+            raw[b0:b1] = st[r * self.bmax:r * self.bmax + (b1 - b0)]
+        has = self.deg > 0
+        scale = (self.ones / self.kvec_a.numpy()) if self.annealing else np.ones(k)
+        g = np.where(has[:, None], raw * scale, raw)
         oth = np.ones(n, dtype=bool)
-        oth[lo:hi] = False
-        xf = self.xflags.numpy()[:n]
-        self.conv[self.parity ^ 1].numpy()[:n][oth] = xf[oth, 0]
-        self.active.numpy()[:n, 0][oth] = xf[oth, 1]
-        g = self.t_gamma.numpy()[:n][oth]
-        self.t_elogpi.numpy()[:n][oth] = digamma(g) - digamma(g.sum(1, keepdims=True))
-        isc = (self.kvec_a.numpy() / self.ones) if self.annealing else 1.0
-        self.t_mphi.numpy()[:n][oth] = (g * isc - self.alpha) / (n - 1.0)
+        oth[self.lo:self.hi] = False
+        self.t_mphi.numpy()[:n][oth] = np.where(has[oth, None], (raw[oth] - self.alpha) / (n - 1.0), 0.0)
+        self.t_gamma.numpy()[:n] = g
+        self.t_elogpi.numpy()[:n] = digamma(g) - digamma(g.sum(1, keepdims=True))
+        act = (g - self.alpha >= 1)
+        cnt = act.sum(1)
+        lastk = k - 1 - np.argmax(act[:, ::-1], axis=1)
+        old = self.conv[self.parity].numpy()[:n]
+        self.conv[self.parity ^ 1].numpy()[:n] = np.where(cnt == 1, lastk + 1, old)
+        self.active.numpy()[:n, 0] = cnt
 
     # ---- phases ----
     def _a(self):
@@ -90,29 +106,17 @@ class NumpyShard:
         self.acc = acc
         self.kvec_a[:] = torch.from_numpy(acc[self.lo:self.hi].sum(0))
 
-    def _b(self):
+    def _b_light(self):
         n, k, lo, hi = self.n, self.k, self.lo, self.hi
         acc = self.acc[lo:hi]
         tl = 2.0 * self.deg[lo:hi][:, None]
         has = tl[:, 0] > 0
         m = np.where(tl > 0, acc / np.where(tl > 0, tl, 1.0), 0.0)
-        g = self.alpha + acc + (n - tl - 1.0) * m
-        if self.annealing:
-            g = g * (self.ones / self.kvec_a.numpy())
+        g = self.alpha + acc + (n - tl - 1.0) * m          # unscaled
         g[~has] = self.alpha
         mph = self.t_mphi.numpy()
         mph[lo:hi][has] = m[has]
-        self.t_gamma.numpy()[lo:hi] = g
-        self.t_elogpi.numpy()[lo:hi] = digamma(g) - digamma(g.sum(1, keepdims=True))
-        act = (g - self.alpha >= 1)
-        cnt = act.sum(1)
-        lastk = k - 1 - np.argmax(act[:, ::-1], axis=1)
-        old = self.conv[self.parity].numpy()[lo:hi]
-        self.conv[self.parity ^ 1].numpy()[lo:hi] = np.where(cnt == 1, lastk + 1, old)
-        self.active.numpy()[lo:hi, 0] = cnt
-        xf = self.xflags.numpy()
-        xf[lo:hi, 0] = self.conv[self.parity ^ 1].numpy()[lo:hi]
-        xf[lo:hi, 1] = cnt
+        self.gstage.numpy()[self.rank * self.bmax:self.rank * self.bmax + (hi - lo)] = g
         kc = self.kvec_c.numpy()
         kc[:k] = m[has].sum(0)
         kc[k:2 * k] = (m[has] ** 2).sum(0)

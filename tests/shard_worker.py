@@ -38,7 +38,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    shard = HipShard(setup, rank, world, 0, use_validation_stop=False)
+    # whole sweeps: work-balanced blocks (the default); mini-batch steps: the equal blocks they need
+    shard = HipShard(setup, rank, world, 0, equal=mode.startswith("step"), use_validation_stop=False)
     if mode.startswith("step"):
         _, nwin, kappa = mode.split(":")
         bn = (shard.B + int(nwin) - 1) // int(nwin)

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), "libsvils.so does not export %s" % n
     assert sorted(_svils.EXPORTS) == names
-    assert lib.svils_abi_version() == 5
+    assert lib.svils_abi_version() == 6
 
 
 def test_kernel_names():

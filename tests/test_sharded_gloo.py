@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from oracle import oracle as O
 from svinet_amd.host_api import Setup
-from svinet_amd.sharded import ShardedSweep, block_size, node_block
+from svinet_amd.sharded import ShardedSweep, balanced_bounds, block_size, node_block
 from shard_double import NumpyShard
 
 
@@ -24,14 +24,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, path, n, k, sweeps, out):
+def _worker(rank, world, port, path, n, k, sweeps, out, balanced=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         s = Setup(path, n, k)
         shard = NumpyShard(s.n, s.k, s.ones, s.ones_prob, s.eta, s.links, s.validation_sorted,
-                           s.gamma, s.lam, rank, world)
+                           s.gamma, s.lam, rank, world, balanced=balanced)
         ShardedSweep(shard, dist).sweep(sweeps)
         if rank == 0:
             np.savez(out, gamma=shard.t_gamma.numpy()[:s.n], lam=shard.lam,
@@ -51,12 +51,29 @@ def test_block_partition():
     assert node_block(2, 4, 3) == (2, 2)
 
 
-@pytest.mark.parametrize("world,sweeps", [(2, 25), (3, 70)])
-def test_sharded_equals_oracle(graph_files, tmp_path, world, sweeps):
-    """LFR n=1000 k=28; 70 sweeps crosses the annealing switch and the converged shortcuts."""
+def test_balanced_blocks_of_the_headline_graph(graph_files):
+    """svils_balance_node_blocks (host code of the library) on ca-AstroPh: the reference numbers nodes by first
+    appearance, equal-count blocks give rank 0 of 8 2.96 x the mean number of CSR entries; the balanced cut keeps every
+    rank within 10 % of the mean at worlds 2, 4 and 8, and the bounds are a partition of [0, n)."""
+    s = Setup(graph_files["astroph"], 17903, 20)
+    deg = np.bincount(np.asarray(s.links).ravel(), minlength=s.n)
+    B = block_size(s.n, 8)
+    eq = np.array([deg[r * B:(r + 1) * B].sum() for r in range(8)], dtype=np.float64)
+    assert 2.9 < eq.max() / eq.mean() < 3.0
+    for world in (1, 2, 4, 8):
+        b = balanced_bounds(s.links, s.n, world).astype(np.int64)
+        assert b[0] == 0 and b[-1] == s.n and np.all(np.diff(b) > 0)
+        ent = np.array([deg[b[r]:b[r + 1]].sum() for r in range(world)], dtype=np.float64)
+        assert np.all(np.abs(ent / ent.mean() - 1.0) < 0.10), (world, ent / ent.mean())
+
+
+@pytest.mark.parametrize("world,sweeps,balanced", [(2, 25, True), (3, 70, True), (2, 12, False)])
+def test_sharded_equals_oracle(graph_files, tmp_path, world, sweeps, balanced):
+    """LFR n=1000 k=28; 70 sweeps crosses the annealing switch and the converged shortcuts.  Work-balanced blocks (the
+    default of every driver) and the equal blocks."""
     path, n, k = graph_files["lfr"], 1000, 28
     out = str(tmp_path / "r0.npz")
-    mp.spawn(_worker, args=(world, _free_port(), path, n, k, sweeps, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), path, n, k, sweeps, out, balanced), nprocs=world, join=True)
     got = np.load(out)
     ref = O.LinkSampling(O.Network(path, n), k, use_validation_stop=False)
     for _ in range(sweeps):
