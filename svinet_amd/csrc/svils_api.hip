@@ -831,9 +831,13 @@ int exchange_rows_and_expand(svils_handle *h) {
     h->ev_chunk.push_back(e);
   }
   Timed t(h, SVILS_KERNEL_EXCHANGE);   // on the compute stream: from "rows may leave" to "last chunk expanded"
+  // `sum` first, on the compute stream (k_expand_all reads it), and the rows leave behind it: the K doubles cost one
+  // small-collective latency in front of a transfer of hundreds of megabytes, and no two collectives of this handle are
+  // ever in flight on two streams at once (a transport that runs its host side on one thread per process -- the tests'
+  // -- would otherwise see rank A inside the all-reduce and rank B inside the first broadcast, each waiting for the other)
+  NCCLCHK(g_rccl.AllReduce(d.kvec_a, d.kvec_a, g.K, ncclDouble, ncclSum, h->comm, h->stream));
   HIPCHK(hipEventRecord(h->ev_ready, h->stream));
   HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
-  NCCLCHK(g_rccl.AllReduce(d.kvec_a, d.kvec_a, g.K, ncclDouble, ncclSum, h->comm, h->stream));   // k_expand_all reads it
   b.nchunks = C;
   for (uint32_t c = 0; c < C; ++c) {
     NCCLCHK(g_rccl.GroupStart());

@@ -2,6 +2,7 @@
 // (bench.py, tests) to obtain the product's own inputs for the C ABI of
 // include/svils.h: graph reading, held-out sampling, gamma/lambda
 // initialisation and the training-link list.  No device is touched here.
+#include <chrono>
 #include "fixedfmt.hh"
 #include <cstring>
 #include <memory>
@@ -91,6 +92,27 @@ uint32_t svih_deg(const svih_setup *s, uint32_t p) { return s->net->deg(p); }
 
 // normalised mutual information of a communities.txt-style file against a ground-truth file in the
 // "node<TAB>community ..." format of -nmi; < 0 when a file cannot be read
+// jump-ahead of the random stream (rng.hh / mtjump.hh) against drawing: the `count` outputs from position `pos` on, once by
+// GslMt19937::at(pos) and once by `pos` calls of get().  0: equal; 1: different; -1: the jump machinery is unavailable.
+// out_ms (may be null): [0] time of the jump, [1] time of drawing up to pos.
+int svih_mt_jump_check(unsigned long seed, uint64_t pos, uint32_t count, double *out_ms) {
+  using clk = std::chrono::steady_clock;
+  svinet::GslMt19937 a(seed), b(seed), j;
+  const auto t0 = clk::now();
+  if (!a.at(pos, &j)) return -1;
+  const auto t1 = clk::now();
+  for (uint64_t i = 0; i < pos; ++i) (void)b.get();
+  const auto t2 = clk::now();
+  if (out_ms) {
+    out_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  }
+  if (j.position() != pos || b.position() != pos) return 1;
+  for (uint32_t i = 0; i < count; ++i)
+    if (j.get() != b.get()) return 1;
+  return j.position() == pos + count ? 0 : 1;
+}
+
 double svih_nmi(const char *communities_path, const char *ground_truth_path) {
   Cover x, y;
   if (!read_cover_lines(communities_path, &x) || !read_cover_memberships(ground_truth_path, &y)) return -1.0;

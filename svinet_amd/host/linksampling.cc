@@ -1,9 +1,12 @@
 #include "linksampling.hh"
 
+#include <array>
 #include <random>
 #include <thread>
 
 #include <algorithm>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <cerrno>
 #include <cmath>
@@ -480,10 +483,11 @@ void LinkSampling::init_gamma2() {
   unsigned T = std::thread::hardware_concurrency();
   T = std::max(1u, std::min(T, 32u));
   if (E * K < (1u << 22)) T = 1;   // small problems: threads cost more than they save
-  const size_t C = std::max<size_t>(256, ((size_t)32 << 20) / (K * sizeof(double)));   // links per chunk
+  size_t C = std::max<size_t>(256, ((size_t)32 << 20) / (K * sizeof(double)));   // links per chunk
+  // (tests reach the threaded paths on small graphs with these two)
+  if (const char *e = getenv("SVINET_INIT_THREADS")) T = (unsigned)std::max(1, atoi(e));
+  if (const char *e = getenv("SVINET_INIT_CHUNK_LINKS")) C = (size_t)std::max(1, atoi(e));
   std::vector<double> buf[2];
-  buf[0].resize(std::min(C, std::max<size_t>(E, 1)) * K);
-  if (T > 1) buf[1].resize(buf[0].size());
 
   // normalise rows [b, e) of a chunk in place: sequential sum over k, then the division (:392-396)
   auto normalise = [&](double *v, size_t b, size_t e) {
@@ -513,6 +517,65 @@ void LinkSampling::init_gamma2() {
     for (auto &x : th) x.join();
   };
 
+  // Large problems: the draws themselves are spread over the threads.  Every link consumes exactly K outputs, so chunk c
+  // (links [c C, (c + 1) C)) starts at output o0 + K C c of the stream: thread t jumps there (mtjump.hh) and draws its chunk
+  // on its own; in round r the T threads hold chunks r T .. r T + T - 1, which the node-range owners add into gamma in
+  // chunk order while round r + 1 is being drawn -- the same stream, the same per-row order of additions, the same bits.
+  // One polynomial (x^(T C K) mod phi) carries every thread from its chunk of round r to its chunk of round r + 1.
+  if (T > 1 && E > 4 * C) {
+    const uint64_t o0 = rng_.position();
+    MtJump stride;
+    std::vector<std::array<uint32_t, 624>> st(T);
+    std::vector<char> ok(T, 1);
+    bool have = stride.make((uint64_t)T * C * K);
+    if (have) {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+          GslMt19937 g;
+          if (!rng_.at(o0 + (uint64_t)K * C * t, &g) || !g.canonical_state(st[t].data())) ok[t] = 0;
+        });
+      for (auto &x : th) x.join();
+      for (unsigned t = 0; t < T; ++t) have = have && ok[t];
+    }
+    if (have) {
+      const size_t W = (size_t)T * C, rounds = (E + W - 1) / W;
+      std::vector<std::vector<double>> bufs(2 * (size_t)T);
+      for (auto &b : bufs) b.resize(C * K);
+      auto draw = [&](size_t r, unsigned t) {
+        const size_t l0 = r * W + (size_t)t * C;
+        if (l0 < E) {
+          const size_t cnt = std::min(C, E - l0);
+          double *v = bufs[(r & 1) * T + t].data();
+          GslMt19937 g(st[t].data(), rng_.seed_state(), o0 + (uint64_t)K * l0);
+          g.fill_uniform(v, cnt * K);
+          normalise(v, 0, cnt);
+        }
+        stride.apply(st[t].data());
+      };
+      auto gather = [&](size_t r, unsigned w) {
+        const uint32_t nb = (uint32_t)((uint64_t)n_ * w / T), ne = (uint32_t)((uint64_t)n_ * (w + 1) / T);
+        for (unsigned t = 0; t < T; ++t) {
+          const size_t l0 = r * W + (size_t)t * C;
+          if (l0 >= E) break;
+          accumulate(bufs[(r & 1) * T + t].data(), l0, std::min(C, E - l0), nb, ne);
+        }
+      };
+      for (size_t r = 0; r <= rounds; ++r) {
+        std::vector<std::thread> th;
+        if (r < rounds) for (unsigned t = 0; t < T; ++t) th.emplace_back(draw, r, t);
+        if (r > 0) for (unsigned w = 0; w < T; ++w) th.emplace_back(gather, r - 1, w);
+        for (auto &x : th) x.join();
+      }
+      GslMt19937 after;
+      if (!rng_.at(o0 + (uint64_t)E * K, &after)) { fprintf(stderr, "error: random stream jump failed\n"); exit(-1); }
+      rng_ = after;
+      return;
+    }
+  }
+
+  buf[0].resize(std::min(C, std::max<size_t>(E, 1)) * K);
+  if (T > 1) buf[1].resize(buf[0].size());
   std::thread pending;
   int cur = 0;
   for (size_t l0 = 0; l0 < E; l0 += C) {
@@ -604,19 +667,55 @@ void LinkSampling::write_max(const double *r, int why, double max_h) const {   /
 
 namespace {
 // Rows of a text matrix (gamma.txt, groups.txt: n rows of k numbers -- 5 GB and 3 GB at n = 1e6, k = 512) formatted by
-// worker threads in blocks of rows and written in order; the numbers go through append_fixed (fixedfmt.hh: printf's
-// own bytes, six times faster).  The sequential fprintf loop was 101 s of a 124 s run at that size (tools/cli_config5.py);
-// small matrices keep one thread.
+// worker threads in blocks of rows; the numbers go through append_fixed (fixedfmt.hh: printf's own bytes, six times
+// faster).  The sequential fprintf loop was 101 s of a 124 s run at that size (tools/cli_config5.py).  A wave of T blocks
+// is formatted while the previous wave goes to the file -- not through write(): buffered writes to ONE file are
+// serialised by the inode lock (8 threads of pwrite: no faster than one), so the wave's range of the file is mapped and
+// the T blocks are copied into the mapping by T threads (page-cache pages are faulted in concurrently).  Small matrices
+// keep one thread and plain writes; a file system that cannot map the file falls back to pwrite.
 template <class RowFn>
-void write_rows(FILE *f, uint32_t n, uint32_t k, size_t bytes_per_number, RowFn row) {
+void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t k, size_t bytes_per_number, RowFn row) {
+  const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) {
+    printf("cannot open %s file:%s\n", what, strerror(errno));
+    exit(-1);
+  }
   unsigned T = std::thread::hardware_concurrency();
   T = std::max(1u, std::min(T, 16u));
   if ((uint64_t)n * k < (1u << 22)) T = 1;
+  if (const char *e = getenv("SVINET_WRITE_THREADS")) T = (unsigned)std::max(1, atoi(e));   // (tests: the threaded path on small files)
   const uint32_t B = (uint32_t)std::max<size_t>(16, ((size_t)8 << 20) / ((size_t)k * bytes_per_number + 24));   // ~8 MB of text per block
   std::vector<std::string> buf[2] = {std::vector<std::string>(T), std::vector<std::string>(T)};
+  uint64_t off = 0;
+  auto write_all = [&](const char *p, size_t len, uint64_t at) {
+    while (len) {
+      const ssize_t w = pwrite(fd, p, len, (off_t)at);
+      if (w <= 0) { printf("cannot write %s file:%s\n", what, strerror(errno)); exit(-1); }
+      p += w; len -= (size_t)w; at += (uint64_t)w;
+    }
+  };
+  bool can_map = T > 1;
   auto flush = [&](std::vector<std::string> &bs) {
-    for (std::string &b : bs)
-      if (!b.empty()) { fwrite(b.data(), 1, b.size(), f); b.clear(); }
+    uint64_t total = 0;
+    std::vector<uint64_t> at(bs.size());
+    for (size_t t = 0; t < bs.size(); ++t) { at[t] = off + total; total += bs[t].size(); }
+    if (!total) return;
+    char *m = (char *)MAP_FAILED;
+    const uint64_t a0 = off & ~(uint64_t)4095;
+    if (can_map && ftruncate(fd, (off_t)(off + total)) == 0)
+      m = (char *)mmap(nullptr, (size_t)(off + total - a0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
+    if (m == (char *)MAP_FAILED) {
+      can_map = false;
+      for (size_t t = 0; t < bs.size(); ++t) write_all(bs[t].data(), bs[t].size(), at[t]);
+    } else {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < bs.size(); ++t)
+        if (!bs[t].empty()) th.emplace_back([&, t] { memcpy(m + (at[t] - a0), bs[t].data(), bs[t].size()); });
+      for (auto &x : th) x.join();
+      munmap(m, (size_t)(off + total - a0));
+    }
+    off += total;
+    for (std::string &b : bs) b.clear();
   };
   int cur = 0;
   for (uint32_t base = 0; base < n; base += T * B, cur ^= 1) {
@@ -632,6 +731,7 @@ void write_rows(FILE *f, uint32_t n, uint32_t k, size_t bytes_per_number, RowFn 
     for (auto &x : th) x.join();
   }
   flush(buf[cur ^ 1]);
+  close(fd);
 }
 inline void append_int(std::string &o, long v, char sep) {
   char tmp[32];
@@ -650,15 +750,13 @@ void LinkSampling::save_model() {                          // src/linksampling.c
       std::copy(&g[(size_t)dev_of_[i] * k_], &g[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
     g.swap(t);
   }
-  FILE *gf = open_or_die(Env::file_str("/gamma.txt"), "gamma");
   const std::vector<uint32_t> &s2i = network_.seq2id();
-  write_rows(gf, n_, k_, 10, [&](uint32_t i, std::string &o) {     // "%d\t%d\t" then "%.5f\t" ... "%.5f\n"
+  write_rows(Env::file_str("/gamma.txt"), "gamma", n_, k_, 10, [&](uint32_t i, std::string &o) {     // "%d\t%d\t" then "%.5f\t" ... "%.5f\n"
     append_int(o, (long)(int)i, '\t');
     append_int(o, (long)(int)s2i[i], '\t');
     const double *row = &g[(size_t)i * k_];
     for (uint32_t k = 0; k < k_; ++k) append_fixed<5>(o, row[k], k == k_ - 1 ? '\n' : '\t');   // %.5f, byte for byte (fixedfmt.hh)
   });
-  fclose(gf);
   FILE *lf = open_or_die(Env::file_str("/lambda.txt"), "lambda");
   for (uint32_t k = 0; k < k_; ++k) fprintf(lf, "%d\t%.5f\t%.5f\n", k, l[2 * k], l[2 * k + 1]);
   fclose(lf);
@@ -709,9 +807,8 @@ void LinkSampling::fetch_communities_ksharded() {
 }
 
 void LinkSampling::write_groups() {                        // src/linksampling.cc:1452-1476
-  FILE *f = open_or_die(Env::file_str("/groups.txt"), "groups");
   const std::vector<uint32_t> &s2i = network_.seq2id();
-  write_rows(f, n_, k_, 6, [&](uint32_t i, std::string &o) {
+  write_rows(Env::file_str("/groups.txt"), "groups", n_, k_, 6, [&](uint32_t i, std::string &o) {
     const double *g = &gamma_[(size_t)i * k_];
     double s = .0;
     for (uint32_t k = 0; k < k_; ++k) s += g[k];
@@ -719,7 +816,6 @@ void LinkSampling::write_groups() {                        // src/linksampling.c
     append_int(o, (long)(int)s2i[i], '\t');
     for (uint32_t k = 0; k < k_; ++k) append_fixed<3>(o, g[k] / s, k == k_ - 1 ? '\n' : '\t');   // %.3f
   });
-  fclose(f);
 }
 
 void LinkSampling::log_communities() {                     // :839-852, :882-917

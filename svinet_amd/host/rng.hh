@@ -11,6 +11,9 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+
+#include "mtjump.hh"
 
 namespace svinet {
 
@@ -20,7 +23,37 @@ class GslMt19937 {
     uint32_t s = seed == 0 ? 4357u : (uint32_t)seed;
     mt_[0] = s;
     for (int i = 1; i < N; ++i) mt_[i] = 1812433253u * (mt_[i - 1] ^ (mt_[i - 1] >> 30)) + (uint32_t)i;
+    memcpy(seed_, mt_, sizeof seed_);
     idx_ = N;
+  }
+  // a generator whose next output is the first one of `state` (canonical form: the next word comes from updating
+  // state[0]) and which says it stands at output number `position` of the stream that started at `seed_state`
+  GslMt19937(const uint32_t state[624], const uint32_t seed_state[624], uint64_t position) {
+    memcpy(mt_, state, sizeof mt_);
+    memcpy(seed_, seed_state, sizeof seed_);
+    idx_ = N;
+    blocks_ = 0;
+    base_ = position;
+  }
+  // outputs drawn since the seed
+  uint64_t position() const { return base_ + (blocks_ ? (blocks_ - 1) * (uint64_t)N + (uint64_t)idx_ : 0); }
+  const uint32_t *seed_state() const { return seed_; }
+  // the generator `steps` outputs after the SEED (not after the current position), by jump-ahead (mtjump.hh: ~20 ms for
+  // the polynomial, ~1 ms for its application); false if the jump machinery is unavailable
+  bool at(uint64_t pos, GslMt19937 *out) const {
+    MtJump j;
+    if (!j.make(pos)) return false;
+    uint32_t st[N];
+    memcpy(st, seed_, sizeof st);
+    j.apply(st);
+    *out = GslMt19937(st, seed_, pos);
+    return true;
+  }
+  // this generator's state in canonical form, valid only at a block boundary of its own (freshly built or jumped)
+  bool canonical_state(uint32_t st[624]) const {
+    if (idx_ != N) return false;
+    memcpy(st, mt_, sizeof mt_);
+    return true;
   }
   uint32_t get() {
     if (idx_ >= N) refill();
@@ -71,10 +104,14 @@ class GslMt19937 {
       out_[k] = y;
     }
     idx_ = 0;
+    ++blocks_;
   }
   uint32_t mt_[N];
   uint32_t out_[N];
+  uint32_t seed_[N];       // the state the stream started from (jump-ahead works from here)
   int idx_;
+  uint64_t blocks_ = 0;    // refills since construction
+  uint64_t base_ = 0;      // position of the state this object was built from
 };
 
 }  // namespace svinet

@@ -402,3 +402,18 @@ def test_cli_default_graph_threshold_in_a_pipelined_run(graph_files, tmp_path):
     da, db = tmp_path / "a" / "n1000-k28-mmsb-linksampling", tmp_path / "b" / "n1000-k28-mmsb-linksampling"
     _files_equal_but_duration(da, db)
     assert np.loadtxt(da / "validation.txt").shape == (301, 11)
+
+
+def test_cli_threaded_file_writers(graph_files, tmp_path):
+    """gamma.txt / groups.txt through the threaded writers (waves of blocks formatted by threads and copied into a mapping
+    of the file by threads: what runs at n = 1e6, k = 512) on a small model: byte-identical to the one-thread writes;
+    init_gamma2 with its draws spread over threads as well"""
+    args = ["-file", graph_files["astroph"], "-n", "17903", "-k", "20", "-link-sampling", "-no-stop", "-max-iterations", "3"]
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = _run(args, str(tmp_path / "a"), env={"SVINET_WRITE_THREADS": "1", "SVINET_INIT_THREADS": "1"})
+    rb = _run(args, str(tmp_path / "b"), env={"SVINET_WRITE_THREADS": "5", "SVINET_INIT_THREADS": "6", "SVINET_INIT_CHUNK_LINKS": "2000"})
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    da, db = tmp_path / "a" / "n17903-k20-mmsb-linksampling", tmp_path / "b" / "n17903-k20-mmsb-linksampling"
+    for nme in ("gamma.txt", "groups.txt", "lambda.txt", "communities.txt", "validation-edges.txt"):
+        assert (da / nme).read_bytes() == (db / nme).read_bytes(), nme
+    assert (da / "gamma.txt").stat().st_size > 3_000_000

@@ -171,7 +171,7 @@ def test_native_step_sharded_full_window_is_a_sweep(graph_files, tmp_path, world
     states, (calls, _) = _run_ranks(tmp_path, path, n, k, steps, world, mode)
     ref = _oracle(path, n, k, steps)
     _check_node_block(states, ref, n, world, tags=False)
-    assert calls == steps * (2 + 3 * world) + 1
+    assert calls == steps * (2 + 3 * world) + world      # + the tag gather: one broadcast per block
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -182,3 +182,42 @@ def test_fixed_point_formatter_writes_printf_bytes():
     ])
     vals = np.ascontiguousarray(vals, dtype=np.float64)
     assert L.svih_fixed_format_mismatches(vals.ctypes.data, vals.size) == 0
+
+
+def test_mt19937_jump_ahead_equals_drawing():
+    """svinet_amd/host/mtjump.hh: the generator `pos` outputs after the seed by jump-ahead (characteristic polynomial by
+    Berlekamp-Massey, x^pos mod phi, Horner on the state) gives the same 3000 outputs as drawing `pos` values does -- block
+    boundaries, a -seed other than the default, positions beyond 2^28"""
+    import ctypes as C
+    from svinet_amd import host_api
+    L = host_api.load()
+    L.svih_mt_jump_check.argtypes = [C.c_ulong, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+    L.svih_mt_jump_check.restype = C.c_int
+    for seed, pos in ((0, 0), (0, 1), (0, 623), (0, 624), (0, 625), (0, 1247), (0, 1248), (7, 123457), (4357, 10 ** 7 + 3),
+                      (0, 3 * 10 ** 8 + 11)):
+        assert L.svih_mt_jump_check(seed, pos, 3000, None) == 0, (seed, pos)
+
+
+def test_init_gamma_threaded_draws_are_the_sequential_stream(graph_files):
+    """init_gamma2 with the draws spread over threads (every thread jumps to its chunks of the ONE gsl_rng stream): gamma
+    and the held-out pairs are bit-identical to the single-threaded loop, whatever the thread count and chunk size"""
+    import os
+    from svinet_amd.host_api import Setup
+
+    def run(env):
+        old = {k: os.environ.pop(k, None) for k in ("SVINET_INIT_THREADS", "SVINET_INIT_CHUNK_LINKS")}
+        os.environ.update(env)
+        try:
+            s = Setup(graph_files["astroph"], 17903, 20)
+            return np.array(s.gamma), np.array(s.validation_accept)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+            os.environ.update({k: v for k, v in old.items() if v is not None})
+
+    g0, v0 = run({"SVINET_INIT_THREADS": "1"})
+    for env in ({"SVINET_INIT_THREADS": "4", "SVINET_INIT_CHUNK_LINKS": "1000"},
+                {"SVINET_INIT_THREADS": "7", "SVINET_INIT_CHUNK_LINKS": "333"},      # ragged last round, idle threads
+                {"SVINET_INIT_THREADS": "16", "SVINET_INIT_CHUNK_LINKS": "12311"}):  # one round only
+        g, v = run(env)
+        assert np.array_equal(g, g0) and np.array_equal(v, v0), env
