@@ -603,6 +603,10 @@ def main():
                          "an error line and every rank exits")
     ap.add_argument("--extra-timeout", type=int, default=480,
                     help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
+    ap.add_argument("--record-timeout", type=int, default=200,
+                    help="N>1: seconds ONE side record may take; past it the record is marked as hung, the ones behind it as not run, "
+                         "the JSON line is printed with everything measured so far and every rank exits (a rank stuck in a collective "
+                         "cannot be brought back)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -828,6 +832,12 @@ def main():
             if cpu_rec is not None:
                 out["cpu_baseline"] = cpu_rec
                 out["speedup_vs_cpu_1core"] = out["value"] / cpu_rec["value"]
+            # N ranks must sit on N devices and RCCL must say so: otherwise `value` is not an N-GPU number and is withheld
+            rccl["devices_unique"] = rccl["distinct_devices"] == world and rccl["nranks"] == [world]
+            if not rccl["devices_unique"] and not args.test_one_gpu:
+                out["error"] = ("the %d ranks do not sit on %d distinct devices of one communicator (distinct PCI bus ids: %d, "
+                                "ncclCommCount: %s): value withheld" % (world, world, rccl["distinct_devices"], rccl["nranks"]))
+                out["value_withheld"], out["value"] = out["value"], None
         if exch is not None:
             out["exchange"] = {"ms_per_sweep": exch[0] / exch[1],
                                "note": "hipEvent time of the RCCL collectives on the engine stream (2 event brackets per sweep: rows + sum, "
@@ -876,11 +886,24 @@ def main():
             state["emitted"] = True
 
     finished = threading.Event()
+    current = {"name": None, "t0": 0.0, "todo": []}   # the side record in progress (per-record watchdog)
 
     def watchdog():
-        if not finished.wait(timeout=args.extra_timeout):
+        t_start = time.time()
+        while not finished.wait(timeout=1.0):
+            name = current["name"]
+            hung = name is not None and time.time() - current["t0"] > args.record_timeout
+            if not hung and time.time() - t_start <= args.extra_timeout:
+                continue
             if rank == 0:
-                out.setdefault("sharded_extra", {})["watchdog"] = "side records cut off after %d s" % args.extra_timeout
+                ex = out.setdefault("sharded_extra", {})
+                if hung:
+                    ex[name] = {"error": "did not finish within %d s (a collective or a kernel of this record blocked); the ranks left"
+                                         % args.record_timeout}
+                    for later in current["todo"]:
+                        ex.setdefault(later, {"error": "not run: the record %s before it hung" % name})
+                else:
+                    ex["watchdog"] = "side records cut off after %d s" % args.extra_timeout
             emit()
             sys.stderr.write("bench.py: rank %d left on the watchdog\n" % rank)
             sys.stderr.flush()
@@ -907,7 +930,12 @@ def main():
                                       ("config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _Sharded)):
             if args.extra_list and name not in args.extra_list.split(","):
                 continue
+            current["todo"] = [x for x in (args.extra_list.split(",") if args.extra_list else []) if x != name and x not in extra]
+            current["t0"], current["name"] = time.time(), name
             try:
+                if os.environ.get("BENCH_TEST_HANG_RECORD") == name:   # tests only: this record never comes back
+                    while True:
+                        time.sleep(1.0)
                 s2, p2, _, n2, k2, _ = _load_workload(wl)
                 r2 = cls(s2, rank, world, local_rank, dist)
                 r2.sweep(3)
@@ -932,6 +960,7 @@ def main():
                     os.unlink(p2)
             except Exception as exc:  # the main measurement must survive a failure here
                 extra[name] = {"error": repr(exc)[:300]}
+            current["name"] = None
     if path:
         os.unlink(path)
     if dist is not None:

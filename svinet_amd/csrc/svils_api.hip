@@ -61,6 +61,9 @@ struct svils_handle {
   // lane-per-link layout: the link classes on the device describe the sweep about to run (k_s3_lpl
   // refreshes them for the next sweep); cleared whenever flags / _iter / the window change under them
   bool cls_valid = false;
+  // three-launch sweeps hand work between workgroups INSIDE a launch (classification role blocks of the s3 launch): only
+  // where the device provably holds all of them at once -- decided when the graph is set (svils_set_graph)
+  bool fused3_ok = true;
   bool cflag_dirty = true;        // the host wrote converged flags (or nothing has yet): rebuild cflag[] before classifying
   bool derive_ok = true;          // SVILS_DERIVE_M=0 keeps the stored mean indicators everywhere (A/B knob)
   bool mphi_stale = false;        // whole sweeps (derive_m) left the stored mean indicators behind gamma: k_mphi_from_gamma on demand
@@ -298,7 +301,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   // Larger graphs keep four launches, where the two classification passes ride spin-free on the s3 and tail
   // launches with as many blocks as they need (n=1e6, K=20: s3 launch 1740 -> see profiles/r02h).
   // (a handle with a test set keeps four launches: the deferred stop rule would come too late for the test row)
-  d.fused3 = (d.fold && !prm.stoch && d.gacc0 && d.cls_ntiles <= 512u && !h->nt) ? 1 : 0;
+  d.fused3 = (d.fold && !prm.stoch && d.gacc0 && d.cls_ntiles <= 512u && !h->nt && h->fused3_ok) ? 1 : 0;
   if (d.fused3) {
     d.gacc = d.gacc0;
     d.nvb = lpl_validation_blocks(g, d.nv, g.K);
@@ -1475,6 +1478,15 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     guard(dalloc(h, &d.tbase, tiles_all));
     guard(dalloc(h, &d.tpoll, tiles_all));
     if (g.K <= 32) guard(dalloc(h, &d.gacc0, (size_t)g.n_alloc * g.ld));   // three-launch sweeps accumulate beside gamma
+    {
+      // co-residency of the in-launch hand-off: the s3 launch's 64 + 1 role blocks next to whatever s3 blocks are still
+      // running.  Not met on a partition of a few CUs; not knowable under a CU mask (the attribute still counts every
+      // CU): both keep the four-launch sweep, whose passes never wait for another workgroup.  SVILS_FUSED3=0 / 1 overrides.
+      const uint32_t res = lpl_s3_resident_blocks(g.K, h->cfg.device);
+      const bool masked = getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK");
+      h->fused3_ok = res >= 2u * 65u && !masked;
+      if (const char *e = getenv("SVILS_FUSED3")) h->fused3_ok = atoi(e) != 0;
+    }
     // ltot [2][8] u32 | shist [2][K] u64, cleared together before a stand-alone classification
     const size_t shist_bytes = ((2 * (size_t)g.K * sizeof(unsigned long long)) + 63) / 64 * 64;
     h->cls_zero_bytes = 64 + shist_bytes + 2 * 8 * 2 * 64 * sizeof(long long);   // ... | sumfx [2][8][hi|lo][64] i64

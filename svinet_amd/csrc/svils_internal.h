@@ -259,6 +259,7 @@ uint32_t lpl_finalize_waves(uint32_t K);
 int lpl_finalize_group(uint32_t K);
 uint32_t lpl_finalize_resident_blocks(uint32_t K, int device);
 uint32_t lpl_scatter_blocks(const DeviceState &d);
+uint32_t lpl_s3_resident_blocks(uint32_t K, int device);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
                           uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s);

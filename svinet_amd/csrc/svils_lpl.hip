@@ -1303,6 +1303,19 @@ void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &
   FIN_DISPATCH(g.K, FIN);
 #undef FIN
 }
+// blocks of k_s3_lpl the device holds at once.  The three-launch sweep needs its classification role blocks (<= 64, + 1)
+// co-resident: they hand tile counts to each other inside the launch.  A whole MI355X holds hundreds; a CPX partition
+// (32 CUs) or a masked device may not, and then the handle keeps the four-launch sweep (spin-free passes).
+uint32_t lpl_s3_resident_blocks(uint32_t K, int device) {
+  int per_cu = 0, cus = 0;
+#define CALL(KC_) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_s3_lpl<KC_>, s3_threads(KC_), 0)
+  LPL_DISPATCH(K, CALL);
+#undef CALL
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (const char *e = getenv("SVILS_ASSUME_CUS")) cus = atoi(e);   // tests: pretend to be a partition of this many CUs
+  if (per_cu <= 0 || cus <= 0) return 0;
+  return (uint32_t)per_cu * (uint32_t)cus;
+}
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
 #define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d) + (d.fused3 ? 1u : 0u)), dim3(s3_threads(KC_)), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);

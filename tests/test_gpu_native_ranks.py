@@ -454,3 +454,27 @@ def test_bench_multi_gpu_code_path_two_ranks(tmp_path):
     for name in ("config4_astroph_k200", "minibatch_steps_astroph_k20", "ksharded_config4_astroph_k200"):
         assert "error" not in ex[name], ex[name]
         assert ex[name]["value"] > 0
+
+
+def test_bench_side_record_that_hangs_does_not_cost_the_line(tmp_path):
+    """a side record that never comes back (here: a test hook; on a node: a collective that blocks) is caught by the
+    per-record watchdog: the JSON line still carries the headline value, the records measured before it, an error entry
+    for the hung one and "not run" for those behind it; every rank exits"""
+    import json
+    env = _env(tmp_path)
+    env["BENCH_TEST_HANG_RECORD"] = "minibatch_steps_astroph_k20"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--test-one-gpu",
+                        "--record-timeout", "20", "--no-cpu-baseline",
+                        "--extra-list", "config4_astroph_k200,minibatch_steps_astroph_k20,ksharded_config4_astroph_k200"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 2
+    ex = out["sharded_extra"]
+    assert ex["config4_astroph_k200"]["value"] > 0
+    assert "did not finish" in ex["minibatch_steps_astroph_k20"]["error"]
+    assert "not run" in ex["ksharded_config4_astroph_k200"]["error"]
+    assert out["load_balance"]["max_over_mean"] < 1.1 and out["rccl"]["devices_unique"] is False   # test mode: both ranks on GPU 0

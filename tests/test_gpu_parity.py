@@ -421,3 +421,33 @@ def test_in_launch_handoff_timeout_is_loud(graph_files, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "FAULT" in r.stdout and "NOFAULT" not in r.stdout, r.stdout
     assert "hand-off" in r.stdout
+
+
+def test_small_device_keeps_the_four_launch_sweep(graph_files, monkeypatch):
+    """The three-launch small-K sweep hands work between workgroups inside a launch, which needs its role blocks
+    co-resident.  Where the device cannot hold them (a CPX partition of 32 CUs; here: SVILS_ASSUME_CUS pretends), or a CU
+    mask hides how many CUs there are, the handle keeps the four-launch sweep (spin-free passes) instead of running into
+    the hand-off's time-out: same results, one k_tail launch per sweep."""
+    from svinet_amd.host_api import Setup
+    setup = Setup(graph_files["lfr"], 1000, 28)
+    a = setup.engine(use_validation_stop=False)
+    a.enable_timing(1 << 6)                  # tail
+    a.sweep(40)
+    a.synchronize()
+    assert a.timing()["tail"][1] <= 1        # three launches: the likelihood rides on the next phi launch
+    for env in ({"SVILS_ASSUME_CUS": "16"}, {"HSA_CU_MASK": "0:0-31"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        b = setup.engine(use_validation_stop=False)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        b.enable_timing(1 << 6)
+        b.sweep(40)
+        b.synchronize()
+        assert b.timing()["tail"][1] == 40
+        ga, la, ca = a.state()
+        gb, lb, cb = b.state()
+        np.testing.assert_allclose(gb, ga, rtol=1e-12)
+        np.testing.assert_allclose(lb, la, rtol=1e-12)
+        assert np.array_equal(ca, cb) and np.array_equal(a.communities(), b.communities())
+        np.testing.assert_allclose(b.rows()[:, 1:], a.rows()[:, 1:], rtol=1e-11, atol=1e-13)

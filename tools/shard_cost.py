@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import _load_workload
 from svinet_amd import _svils
-from svinet_amd.sharded import block_size, node_block
+from svinet_amd.sharded import balanced_bounds, equal_bounds
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "astroph-k200"
 Gs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 4, 8]
@@ -51,29 +51,43 @@ plain.close()
 print("# %s: n=%d k=%d links=%d held-out pairs=%d; plain engine on one GPU: %.3f ms per sweep" % (wl, n, k, L, V, t_plain))
 print("# layout      G   compute/rank (ms)  of which expand   bytes exchanged per sweep (total)         collectives  links (ms)  predicted ms/sweep  speed-up vs 1 GPU")
 for G in Gs:
-    # ---- node blocks: rank 0 of G
-    B = block_size(n, G)
-    e = setup.engine(use_validation_stop=False, node_block=node_block(n, G, 0), n_alloc=B * G)
-    def run_nb(s):
-        for _ in range(s):
-            for ph in (_svils.PHASE_A, _svils.PHASE_B, _svils.PHASE_EXPAND, _svils.PHASE_C, _svils.PHASE_D):
-                e.sweep_phase(ph)
-        e.synchronize()
-    t_nb = wall(run_nb, steps)
-    def run_exp(s):
-        for _ in range(s):
-            e.sweep_phase(_svils.PHASE_EXPAND)
-        e.synchronize()
-    t_exp = wall(run_exp, steps)
-    e.close()
-    rows_total = n * ld * 8 + n * 16            # gamma rows + packed flags (kw = ceil(k/64): 8 + 8 kw bytes)
+    # ---- node blocks, balanced by work (svils_balance_node_blocks): every rank of G on small state, ranks 0 and G-1 on large
+    bounds = balanced_bounds(setup.links, n, G)
+    deg = np.bincount(np.asarray(setup.links).ravel(), minlength=n)
+    ent = np.array([deg[int(bounds[r]):int(bounds[r + 1])].sum() for r in range(G)], dtype=np.float64)
+    eq = equal_bounds(n, G)
+    ent_eq = np.array([deg[int(eq[r]):int(eq[r + 1])].sum() for r in range(G)], dtype=np.float64)
+    ranks = list(range(G)) if n * k < 5e7 else [0, G - 1]
+    t_rank, t_exp = [], 0.0
+    for r in ranks:
+        e = setup.engine(use_validation_stop=False, node_block=(int(bounds[r]), int(bounds[r + 1])))
+        e.set_node_blocks(r, G, bounds)
+        def run_nb(s):
+            for _ in range(s):
+                for ph in (_svils.PHASE_A, _svils.PHASE_B_LIGHT, _svils.PHASE_EXPAND_ALL, _svils.PHASE_C, _svils.PHASE_D):
+                    e.sweep_phase(ph)
+            e.synchronize()
+        t_rank.append(wall(run_nb, steps))
+        if r == 0:
+            def run_exp(s):
+                for _ in range(s):
+                    e.sweep_phase(_svils.PHASE_EXPAND_ALL)
+                e.synchronize()
+            t_exp = wall(run_exp, steps)
+        e.close()
+    t_nb = max(t_rank)
+    bmax = int(np.max(np.diff(bounds.astype(np.int64))))
+    rows_total = G * bmax * ld * 8               # the staged rows, slices padded to the largest block
     kvec = 4 * k * 8
     recv = rows_total * (G - 1) / G + 2 * kvec * (G - 1) / G
-    t_link = link_time(recv, G, 3)
-    # the row exchange is pipelined against the expansion of the rows already there: what stays exposed is the longer of the two
-    t_pred = (t_nb - t_exp) + max(t_exp, link_time(rows_total * (G - 1) / G, G, 1)) + link_time(2 * kvec * (G - 1) / G, G, 2)
+    t_link = link_time(recv, G, 2)
+    # the row exchange is pipelined against the expansion of the rows already there (large payloads): what stays exposed is the longer of the two
+    t_pred = (t_nb - t_exp) + max(t_exp, link_time(rows_total * (G - 1) / G, G, 1)) + link_time(2 * kvec * (G - 1) / G, G, 1)
     print("node-block  %2d   %10.3f        %8.3f          %7.1f MB all-gather + %5.1f KB all-reduce   %6d    %8.3f    %10.3f        %6.2fx"
-          % (G, t_nb, t_exp, rows_total / 1e6, kvec / 1e3, 3, t_link, t_pred, t_plain / t_pred))
+          % (G, t_nb, t_exp, rows_total / 1e6, kvec / 1e3, 2, t_link, t_pred, t_plain / t_pred))
+    print("#   balance: CSR entries per rank / mean = %s (equal-count blocks: %s); compute per measured rank (ms): %s"
+          % (" ".join("%.2f" % x for x in ent / ent.mean()), " ".join("%.2f" % x for x in ent_eq / ent_eq.mean()),
+             " ".join("r%d %.3f" % (r, t) for r, t in zip(ranks, t_rank))))
     # ---- K-sharded: rank 0 of G
     k0, k1 = 0, k // G
     ks = _svils.Engine(n, k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, link_thresh=setup.link_thresh,
