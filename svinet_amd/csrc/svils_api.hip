@@ -64,6 +64,7 @@ struct svils_handle {
   // three-launch sweeps hand work between workgroups INSIDE a launch (classification role blocks of the s3 launch): only
   // where the device provably holds all of them at once -- decided when the graph is set (svils_set_graph)
   bool fused3_ok = true;
+  bool shard_fold_ok = true;      // SVILS_SHARD_FOLD=0: node-block sweeps keep the k_colreduce launches (A/B knob)
   bool cflag_dirty = true;        // the host wrote converged flags (or nothing has yet): rebuild cflag[] before classifying
   bool derive_ok = true;          // SVILS_DERIVE_M=0 keeps the stored mean indicators everywhere (A/B knob)
   bool mphi_stale = false;        // whole sweeps (derive_m) left the stored mean indicators behind gamma: k_mphi_from_gamma on demand
@@ -280,7 +281,7 @@ int classify_now(svils_handle *h, const Geometry &g, const DeviceState &d, const
 // (small K) consumers fold the producers' partial rows themselves and k_s3_lpl classifies the
 // links of the next sweep; otherwise the K-vectors are materialised for the caller's collectives.
 int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceState &d0, const Params &prm,
-              bool fused) {
+              bool fused, bool shard = false) {
   hipStream_t s = h->stream;
   DeviceState d = d0;
   // whole full sweeps keep the mean indicators in derived form (svils_internal.h: derive_m); anything else -- sweeps
@@ -293,6 +294,13 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   }
   if (d.derive_m && ph == SVILS_PHASE_B) h->mphi_stale = true;
   d.fold = (fused && d.lpl && g.K <= 32) ? 1 : 0;   // K = 33..64: K-vectors via k_colreduce (2K columns are too wide to fold)
+  // Node-block sweeps issued by this library (svils_sweep_sharded), K <= 32: the K-vectors the collectives need are left by
+  // the kernels themselves -- `sum` by the light finalise pass (block 0 adds the phi pass's per-XCD accumulators), s1 / s2 by
+  // and s3 by the last block of the s3 launch to arrive -- instead of by two k_colreduce launches; the tail reads the
+  // all-reduced vectors (no fold there).  The s3 launch then has at most 192 blocks (<= 192 partial rows for its last block).
+  const bool shard_fold = shard && d.lpl && g.K <= 32 && !prm.stoch && h->shard_fold_ok;
+  if (shard_fold && (ph == SVILS_PHASE_A || ph == SVILS_PHASE_B_LIGHT)) d.fold = 1;
+  d.shard_c = (shard_fold && ph == SVILS_PHASE_C) ? 1 : 0;   // (d.fold stays 0 there: the LAST block leaves s1, s2 and s3)
   // Three launches per sweep when this library drives whole full sweeps at K <= 32: the work of k_tail is
   // split between the last s3 block (lambda, loop control) and a role of the NEXT phi launch (likelihood,
   // stop rule), and the phi pass accumulates beside gamma so that it may run before the stop rule has spoken.
@@ -325,7 +333,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
     } break;
     case SVILS_PHASE_C: {
       { Timed t(h, SVILS_KERNEL_S3); launch_s3(g, d, prm, s); }
-      if (!d.fold) { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
+      if (!d.fold && !d.shard_c) { Timed t(h, SVILS_KERNEL_REDUCE_S); launch_reduce_c(g, d, s); }
     } break;
     case SVILS_PHASE_EXPAND: {
       launch_expand(g, d, prm, s);
@@ -375,7 +383,7 @@ int run_phase(svils_handle *h, svils_phase ph, const Geometry &g, const DeviceSt
   return 0;
 }
 
-int run_phase(svils_handle *h, svils_phase ph, bool fused) { return run_phase(h, ph, h->geo, h->d, h->prm, fused); }
+int run_phase(svils_handle *h, svils_phase ph, bool fused, bool shard = false) { return run_phase(h, ph, h->geo, h->d, h->prm, fused, shard); }
 
 void drop_graphs_of(svils_handle *h) {
   for (auto &g_ : h->sgexec) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
@@ -637,6 +645,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
     return fail(SVILS_ERR_DEVICE, "control block upload failed");
   }
   if (const char *e = getenv("SVILS_GRAPH_AFTER")) h->graph_after = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = getenv("SVILS_SHARD_FOLD")) h->shard_fold_ok = atoi(e) != 0;
   *out = h;
   return 0;
 }
@@ -819,7 +828,7 @@ int exchange_rows_and_expand(svils_handle *h) {
       NCCLCHK(g_rccl.AllGather(d.gown, d.gstage, (size_t)b.bmax * g.ld, ncclDouble, h->comm, h->stream));
       NCCLCHK(g_rccl.GroupEnd());
     }
-    return run_phase(h, SVILS_PHASE_EXPAND_ALL, false);
+    return run_phase(h, SVILS_PHASE_EXPAND_ALL, false, true);
   }
   if (!h->comm_stream) HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   if (!h->ev_ready) HIPCHK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
@@ -864,12 +873,12 @@ int exchange_rows_and_expand(svils_handle *h) {
 // one node-block sweep: two exchange points, whatever the annealing flag says (nothing here looks at the control block)
 int sharded_sweep_once(svils_handle *h) {
   int rc;
-  if ((rc = run_phase(h, SVILS_PHASE_A, false))) return rc;
-  if ((rc = run_phase(h, SVILS_PHASE_B_LIGHT, false))) return rc;
+  if ((rc = run_phase(h, SVILS_PHASE_A, false, true))) return rc;
+  if ((rc = run_phase(h, SVILS_PHASE_B_LIGHT, false, true))) return rc;
   if ((rc = exchange_rows_and_expand(h))) return rc;
-  if ((rc = run_phase(h, SVILS_PHASE_C, false))) return rc;
+  if ((rc = run_phase(h, SVILS_PHASE_C, false, true))) return rc;
   if ((rc = exchange_sum(h, h->d.kvec_c, 3 * (size_t)h->geo.K))) return rc;
-  return run_phase(h, SVILS_PHASE_D, false);
+  return run_phase(h, SVILS_PHASE_D, false, true);
 }
 
 // `nsweeps` node-block sweeps, collectives included, captured into an executable graph.  RCCL's collectives are

@@ -139,6 +139,7 @@ struct DeviceState {
   // chunked broadcasts) fills the other slices, k_expand_all turns every row into gamma / Elogpi / flags
   double *gstage, *gown;
   int light;            // 1: this launch of the finalise pass is the light one
+  int shard_c;          // 1 (node-block sweeps, K <= 32): the last s3 block materialises this rank's s3 in kvec_c (no k_colreduce)
   double *gacc;         // where the phi pass accumulates gammanext: == gamma for full sweeps, a separate
                         // [n_alloc][ld] buffer in mini-batch mode (the old gamma row is blended in)
   uint32_t *ncnt;       // [n_alloc] mini-batch mode: number of updates each node has received

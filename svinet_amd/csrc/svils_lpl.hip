@@ -751,6 +751,10 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     }
     if (first) {
       // everything the first node needs is in flight; now `sum`
+      if (LIGHT && d.fold && blockIdx.x == 0 && threadIdx.x < K) {
+        // node-block sweeps: this rank's share of `sum`, published for the all-reduce that follows the launch
+        d.kvec_a[threadIdx.x] = (c_cpar & 1u) ? fx_value(ah1, al1, d.fx_inv) + (double)sh1 : fx_value(ah0, al0, d.fx_inv) + (double)sh0;
+      }
       if (!LIGHT && threadIdx.x < 64) {
         double t = 1.0;
         if (d.fold) {
@@ -1079,7 +1083,7 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
   if (threadIdx.x < K && !fold_role) {
     double t = 0.0;
     for (int w = 0; w < NWV; ++w) t += red[w][threadIdx.x];
-    if (d.fused3) st_agent(&d.part_c[(size_t)blockIdx.x * K + threadIdx.x], t);   // read by the last block of THIS launch
+    if (d.fused3 || d.shard_c) st_agent(&d.part_c[(size_t)blockIdx.x * K + threadIdx.x], t);   // read by the last block of THIS launch
     else d.part_c[(size_t)blockIdx.x * K + threadIdx.x] = t;
   }
   STAMP(2, 2);
@@ -1093,6 +1097,49 @@ __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceS
         if (d.fused3) st_agent(&d.kvec_c[threadIdx.x], out64[threadIdx.x]);
         else d.kvec_c[threadIdx.x] = out64[threadIdx.x];
       }
+    }
+    if (d.shard_c) {
+      // ---- node-block sweeps: the last s3 block to arrive adds the blocks' partial rows in block order and leaves this
+      // rank's share of s3 next to s1, s2 (block 0, above) for the all-reduce that follows the launch
+      if (!last_block_arrives(d.s3_ctl, d.nb_c, &hflag)) return;
+      double *tmp = &lds[0][0];
+      {   // s1, s2: the finalise launch's partial rows (<= SVILS_FOLD_ROWS of 2K <= 64 columns), row groups of NTH / 64 in order
+        const uint32_t c = threadIdx.x & 63u, r0 = threadIdx.x >> 6;
+        double t = 0.0;
+        if (c < 2 * K)
+          for (uint32_t r = r0; r < d.nb_b; r += NTH / 64) t += d.part_b[(size_t)r * 2 * K + c];
+        tmp[r0 * 64 + c] = t;
+        __syncthreads();
+        if (threadIdx.x < 2 * K) {
+          double u = 0.0;
+#pragma unroll
+          for (uint32_t i = 0; i < NTH / 64; ++i) u += tmp[i * 64 + threadIdx.x];
+          d.kvec_c[threadIdx.x] = u;
+        }
+        __syncthreads();
+      }
+      {
+        constexpr uint32_t RG = NTH / 32, NL = 256 / RG;   // row groups x 32 columns; nb_c <= 192 rows
+        const uint32_t c = threadIdx.x & 31u, r0 = threadIdx.x >> 5;
+        double v[NL];
+#pragma unroll
+        for (uint32_t i = 0; i < NL; ++i) {
+          const uint32_t r = r0 + RG * i;
+          v[i] = (c < K && r < d.nb_c) ? ld_agent(&d.part_c[(size_t)r * K + c]) : 0.0;
+        }
+        double t = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < NL; ++i) t += v[i];
+        tmp[r0 * 32 + c] = t;
+      }
+      __syncthreads();
+      if (threadIdx.x < K) {
+        double t = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < NTH / 32; ++i) t += tmp[i * 32 + threadIdx.x];
+        d.kvec_c[2 * K + threadIdx.x] = t;
+      }
+      return;
     }
     if (d.fused3) {
       // ---- three-launch sweeps: the last s3 block to arrive closes the sweep -------------------------

@@ -45,6 +45,8 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
       rng_(env.seed ? (unsigned long)env.seed : 0ul),   // :70-75
       start_time_(time(0)) {
   const double t_ctor = now_s();
+  const bool trace_ctor = getenv("SVINET_TRACE_LOOP") != nullptr;
+  auto mark = [&](const char *what) { if (trace_ctor) fprintf(stderr, "[ctor] +%.3f s: %s\n", now_s() - t_ctor, what); };
   // `_n * (_n - 1) / 2` in 32-bit unsigned arithmetic (:36-37, quirk Q5)
   total_pairs_ = (double)((uint32_t)(n_ * (n_ - 1u)) / 2u);
   Env::plog("inference n", n_);
@@ -110,6 +112,7 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     }
   }
 
+  mark("held-out sets done");
   gamma_.assign((size_t)n_ * k_, 0.0);
   lambda_.assign(2 * (size_t)k_, 0.0);
   if (env_.model_load) {
@@ -122,6 +125,7 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     init_lambda();
   }
 
+  mark("gamma / lambda initialised");
   if (env_.write_files) {
     tf_ = open_or_die(Env::file_str("/test.txt"), "test");
     vf_ = open_or_die(Env::file_str("/validation.txt"), "validation");
@@ -145,8 +149,11 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     test_sorted_.push_back(network_.y(kv.first.first, kv.first.second) ? 1u : 0u);
   }
 
+  if (env_.write_files) rank_external_ids();
+  mark("sorted pair lists, id ranks");
   if (attach_device) {
     attach();
+    mark("device attached (handle, communicator, validation set, state upload)");
     if (!env_.accuracy && !val_sorted_.empty()) {
       // constructor-time validation_likelihood (:149-150): row "iter 0"
       if (svils_validation_row(h_, row0_)) die_svils("svils_validation_row");
@@ -481,9 +488,10 @@ void LinkSampling::init_gamma2() {
       if (p < q) { lp.push_back(p); lq.push_back(q); }   // all links, held-out ones included
   const size_t E = lp.size(), K = k_;
   unsigned T = std::thread::hardware_concurrency();
-  T = std::max(1u, std::min(T, 32u));
+  T = std::max(1u, std::min(T, 64u));
   if (E * K < (1u << 22)) T = 1;   // small problems: threads cost more than they save
-  size_t C = std::max<size_t>(256, ((size_t)32 << 20) / (K * sizeof(double)));   // links per chunk
+  // links per chunk: 32 MB of uniforms, 16 MB with more than 32 threads (two buffers per thread)
+  size_t C = std::max<size_t>(256, ((size_t)(T > 32 ? 16 : 32) << 20) / (K * sizeof(double)));
   // (tests reach the threaded paths on small graphs with these two)
   if (const char *e = getenv("SVINET_INIT_THREADS")) T = (unsigned)std::max(1, atoi(e));
   if (const char *e = getenv("SVINET_INIT_CHUNK_LINKS")) C = (size_t)std::max(1, atoi(e));
@@ -681,9 +689,16 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
     exit(-1);
   }
   unsigned T = std::thread::hardware_concurrency();
-  T = std::max(1u, std::min(T, 16u));
+  T = std::max(1u, std::min(T, 64u));   // formatting is the bound where the file system is memory-fast (measured: 14 GB/s of write())
   if ((uint64_t)n * k < (1u << 22)) T = 1;
   if (const char *e = getenv("SVINET_WRITE_THREADS")) T = (unsigned)std::max(1, atoi(e));   // (tests: the threaded path on small files)
+  // how a wave reaches the file: plain positional writes from this thread -- 14 GB/s on the memory-backed file system of
+  // the GPU box -- unless they turn out slow (0.2 GB/s on a disk-backed VM, where copies into a mapping from T threads
+  // reached 1.6 GB/s): then the rest of the file goes through mappings.  SVINET_WRITE_MMAP=0 / 1 fixes the choice.
+  int use_map = 0;   // 0 undecided (writes, timed), 1 mappings, -1 writes for good
+  if (const char *e = getenv("SVINET_WRITE_MMAP")) use_map = atoi(e) ? 1 : -1;
+  double write_s = 0.0;
+  uint64_t write_bytes = 0;
   const uint32_t B = (uint32_t)std::max<size_t>(16, ((size_t)8 << 20) / ((size_t)k * bytes_per_number + 24));   // ~8 MB of text per block
   std::vector<std::string> buf[2] = {std::vector<std::string>(T), std::vector<std::string>(T)};
   uint64_t off = 0;
@@ -694,7 +709,6 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
       p += w; len -= (size_t)w; at += (uint64_t)w;
     }
   };
-  bool can_map = T > 1;
   auto flush = [&](std::vector<std::string> &bs) {
     uint64_t total = 0;
     std::vector<uint64_t> at(bs.size());
@@ -702,11 +716,15 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
     if (!total) return;
     char *m = (char *)MAP_FAILED;
     const uint64_t a0 = off & ~(uint64_t)4095;
-    if (can_map && ftruncate(fd, (off_t)(off + total)) == 0)
+    if (use_map == 1 && T > 1 && ftruncate(fd, (off_t)(off + total)) == 0)
       m = (char *)mmap(nullptr, (size_t)(off + total - a0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
     if (m == (char *)MAP_FAILED) {
-      can_map = false;
+      if (use_map == 1) use_map = -1;          // this file system cannot map the file
+      const double t0 = now_s();
       for (size_t t = 0; t < bs.size(); ++t) write_all(bs[t].data(), bs[t].size(), at[t]);
+      write_s += now_s() - t0;
+      write_bytes += total;
+      if (use_map == 0 && write_bytes >= ((uint64_t)128 << 20)) use_map = (write_bytes / write_s < 1.0e9 && T > 1) ? 1 : -1;
     } else {
       std::vector<std::thread> th;
       for (size_t t = 0; t < bs.size(); ++t)
@@ -744,6 +762,7 @@ void LinkSampling::save_model() {                          // src/linksampling.c
   std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
   if (env_.kshard) fetch_state_ksharded(g, l);
   else if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
+  if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] state fetched at %.3f s\n", now_s());
   if (!dev_of_.empty()) {   // back to sequence-id order
     std::vector<double> t((size_t)n_ * k_);
     for (uint32_t i = 0; i < n_; ++i)
@@ -835,6 +854,9 @@ void LinkSampling::do_on_stop() {                          // src/linksampling.c
 }
 
 void LinkSampling::do_on_stop_impl() {
+  const double tf0 = now_s();
+  const bool trace = getenv("SVINET_TRACE_LOOP") != nullptr;
+  auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[final] +%.3f s: %s\n", now_s() - tf0, what); };
   // -gpus N: every rank takes part in the gather of the community bitmasks, rank 0 writes
   if (env_.kshard) {
     fetch_communities_ksharded();
@@ -846,8 +868,11 @@ void LinkSampling::do_on_stop_impl() {
   } else if (env_.sharded && svils_gather_communities(h_)) die_svils("svils_gather_communities");
   if (!env_.write_files) return;
   log_communities();
+  mark("communities.txt");
   save_model();
+  mark("gamma.txt, lambda.txt (state fetched from the device first)");
   write_groups();
+  mark("groups.txt");
 }
 
 // true when the batch reached a report (the reference's `_iter % reportfreq == 0` block, :777-785): new likelihood
@@ -909,19 +934,24 @@ void LinkSampling::send_graph() {
 }
 
 // communities.txt of a report (src/linksampling.cc:839-852,882-917) from tags already on the host
+// rank of every node in the order of the external ids (communities.txt lists members by ascending external id): once per
+// run, in the constructor when files are written -- not inside the first report of the sweep loop
+void LinkSampling::rank_external_ids() {
+  const std::vector<uint32_t> &s2i = network_.seq2id();
+  std::vector<uint32_t> order(n_);
+  for (uint32_t i = 0; i < n_; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s2i[a] < s2i[b]; });
+  ext_rank_.resize(n_);
+  for (uint32_t r = 0; r < n_; ++r) ext_rank_[order[r]] = r;
+}
+
 void LinkSampling::write_communities_file() {
   const std::vector<uint32_t> &s2i = network_.seq2id();
   // one pass over the (device row, community) pairs -- a node tags one or two communities, so this is O(n), not the
   // O(n k) of a pass over the tag matrix (n = 1e6, k = 512: 512 MB per report) -- then every community sorted by external id
   // ... visited in the order of the external ids (a counting sort of the pairs by the node's rank in that order, the ranks
   // computed once per run), so that every community's member list comes out sorted and no per-report sort is needed
-  if (ext_rank_.empty()) {
-    std::vector<uint32_t> order(n_);
-    for (uint32_t i = 0; i < n_; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s2i[a] < s2i[b]; });
-    ext_rank_.resize(n_);
-    for (uint32_t r = 0; r < n_; ++r) ext_rank_[order[r]] = r;
-  }
+  if (ext_rank_.empty()) rank_external_ids();
   const size_t nt = tags_.size() / 2;
   std::vector<uint32_t> start((size_t)n_ + 1, 0), slot(2 * nt);
   auto seq_of_tag = [&](size_t i) { return dev_of_.empty() ? tags_[2 * i] : seq_of_[tags_[2 * i]]; };   // device rows back to sequence ids
@@ -1022,17 +1052,20 @@ int LinkSampling::sweep_loop_pipelined() {
     }
   }
   timing_.sweeps_t0 = now_s();
-  for (;;) {
-    // ---- keep the device busy: up to SVILS_REPORT_SLOTS - 1 chunks ahead of the host
+  const bool trace = getenv("SVINET_TRACE_LOOP") != nullptr;
+  // ---- keep the device busy: up to SVILS_REPORT_SLOTS - 1 chunks ahead of the host
+  auto issue_more = [&]() {
     while (!quit_max && flight.size() + 1 < (size_t)SVILS_REPORT_SLOTS) {
       uint32_t batch = std::min<uint32_t>(chunk, (uint32_t)SVILS_REPORT_MAX_ROWS * rf);
       if (env_.max_iterations) {
-        if (issued_iter > env_.max_iterations) { quit_max = true; break; }      // :573-579, seen at issue time
+        if (issued_iter > env_.max_iterations) { quit_max = true; return; }      // :573-579, seen at issue time
         batch = std::min<uint32_t>(batch, env_.max_iterations + 1 - issued_iter);
       }
       printf("\riteration %d: processing %d links", issued_iter, (int)nlinks);
       fflush(stdout);
+      const double tr0 = trace ? now_s() : 0.0;
       if (svils_sweep(h_, batch)) die_svils("svils_sweep");
+      if (trace) fprintf(stderr, "[loop] +%.3f ms: issued %u sweeps from iter %u (host %.3f ms)\n", (now_s() - timing_.sweeps_t0) * 1e3, batch, issued_iter, (now_s() - tr0) * 1e3);
       // the device records a row for every sweep whose pre-increment _iter is a multiple of rf (k_tail; _iter starts at
       // 0, so sweep 0 records row 0): the multiples of rf in [iter, iter + batch)
       const uint32_t new_rows = (issued_iter + batch + rf - 1) / rf - (issued_iter + rf - 1) / rf;
@@ -1046,6 +1079,9 @@ int LinkSampling::sweep_loop_pipelined() {
       // sweeps (a report costs the host ~0.5 ms of file writing, a sweep the device tens of microseconds)
       if (!fixed_chunk && chunk < 16) chunk *= 2;
     }
+  };
+  for (;;) {
+    issue_more();
     if (flight.empty()) break;              // everything issued and reported: -max-iterations reached
     // ---- the oldest report: blocks until it has landed
     const Flight f = flight.front();
@@ -1064,7 +1100,12 @@ int LinkSampling::sweep_loop_pipelined() {
       tags_.resize(2 * (size_t)nt);
       if (svils_report_fetch_tags(h_, f.ticket, &c, rows.data(), &have, tags_.data(), nt, &nt)) die_svils("svils_report_fetch_tags");
     } else if (svils_report_fetch(h_, f.ticket, &c, rows.data(), &have, nullptr)) die_svils("svils_report_fetch");
+    // the slot is free again and the run goes on: the next chunk is enqueued BEFORE this report's files are written -- a
+    // report costs the host 0.3 - 1 ms of file work, the early chunks only tens of microseconds of device time, and a
+    // device that waits for the host to finish writing is what made the default run 1.7x the library sweep
+    if (!c.stopped) issue_more();
     const double t0 = now_s();
+    if (trace) fprintf(stderr, "[loop] +%.3f ms: report landed: iter %u rows %u stopped %d (%zu in flight)\n", (t0 - timing_.sweeps_t0) * 1e3, c.iter, have, c.stopped, flight.size());
     // (without a test set every report that does not end the run still gets its row of 0/0 ratios)
     if (!with_test) have_t = (c.stopped && have && rows_logged_ + have == c.rows) ? have - 1 : have;
     log_rows(rows.data(), have, c.why, c.max_h, with_test ? trows.data() : nullptr, have_t);
@@ -1082,6 +1123,7 @@ int LinkSampling::sweep_loop_pipelined() {
       // above is right) is read from the ring before the final files are written
       if (c.rows > rows_logged_) fetch_and_log_rows();
       timing_.sweeps_t1 = now_s();
+      if (trace) fprintf(stderr, "[loop] +%.3f ms: drained\n", (timing_.sweeps_t1 - timing_.sweeps_t0) * 1e3);
       timing_.sweeps = c.sweeps_done;
       do_on_stop();
       return 1;

@@ -101,6 +101,7 @@ class LinkSampling {
   // mini-batch mode: nodes are handed to the device under a random relabelling so that a window of
   // consecutive device ids is a uniform random subset; dev_of_[seq] / seq_of_[dev], empty otherwise
   std::vector<uint32_t> dev_of_, seq_of_;
+  void rank_external_ids();
   std::vector<uint32_t> blocks_;   // -gpus N (whole sweeps): bounds[N + 1] of the work-balanced node blocks, the same on every rank
   std::vector<uint32_t> ext_rank_;             // rank of a sequence id in the order of the external ids (communities.txt lists members by external id)
   Cover ground_truth_;                         // -nmi: the reference cover (external ids)

@@ -123,7 +123,11 @@ def test_native_rccl_driver_world1(graph_files):
         shard = HipShard(setup, 0, 1, 0, use_validation_stop=False)
         ShardedSweep(shard, _NoDist()).sweep(sweeps)
         c = shard.engine.state()
-        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+        # (the library's own driver leaves the K-vectors for its collectives from inside the kernels at K <= 32, the
+        #  caller-driven phases through k_colreduce: another fixed summation order)
+        np.testing.assert_allclose(a[0], c[0], rtol=1e-10)
+        np.testing.assert_allclose(a[1], c[1], rtol=1e-10)
+        assert np.array_equal(a[2], c[2])
         # ... and the same run replayed as hipGraphs with the REAL librccl's collectives captured inside (no timing
         # brackets: those keep the sweeps eager): bit-identical to the eager run
         geng = setup.engine(use_validation_stop=False, node_block=(0, n), n_alloc=n)

@@ -47,6 +47,9 @@ def main():
             print(r.stderr[-2000:])
             sys.exit(1)
         print("timing:", json.dumps(json.load(open(tf))), flush=True)
+        for line in r.stderr.split("\n"):       # SVINET_TRACE_LOOP=1: the binary's own marks
+            if line.startswith("[ctor]") or line.startswith("[final]"):
+                print("  " + line)
         outdir = [x for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
         for fn in sorted(os.listdir(os.path.join(d, outdir))):
             print("  %-28s %12.1f MB" % (fn, os.path.getsize(os.path.join(d, outdir, fn)) / 1e6))
