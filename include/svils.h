@@ -94,6 +94,12 @@ int svils_destroy(svils_handle *h);
  * derived from the list.  Builds the device CSR. */
 int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks);
 
+/* Optional: capture the hipGraphs svils_sweep replays (1, 4, 8, 16 ... sweeps, up to max_sweeps) during set-up instead of
+ * in the middle of the run (by itself svils_sweep launches eagerly until a handle has run 128 sweeps: a capture costs more
+ * than a short run).  After svils_set_graph / svils_set_validation / svils_set_state.  The drop-in binary calls it from the
+ * LinkSampling constructor, so that its default run -- 31 sweeps on ca-AstroPh -- replays graphs from the third chunk on. */
+int svils_prepare_graphs(svils_handle *h, uint32_t max_sweeps);
+
 /* Held-out pairs in std::map<Edge,bool> order (src/linksampling.cc:974-992):
  * [nv][3] = (p, q, y).  nv == 0 disables the likelihood/stop rule. */
 int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv);

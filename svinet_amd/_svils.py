@@ -32,7 +32,7 @@ EXPORTS = (
     "svils_report_enqueue", "svils_report_ready", "svils_report_fetch", "svils_report_test_rows",
     "svils_set_test", "svils_get_test_rows",
     "svils_report_tag_count", "svils_report_fetch_tags", "svils_get_community_tags",
-    "svils_set_node_blocks", "svils_balance_node_blocks",
+    "svils_set_node_blocks", "svils_balance_node_blocks", "svils_prepare_graphs",
 )
 
 
@@ -127,6 +127,7 @@ def load():
     L.svils_comm_unique_id.argtypes = [vp]
     L.svils_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.svils_set_node_blocks.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.svils_prepare_graphs.argtypes = [vp, C.c_uint32]
     L.svils_balance_node_blocks.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_double, vp]
     L.svils_sweep_sharded.argtypes = [vp, C.c_uint32]
     L.svils_gather_communities.argtypes = [vp]
@@ -298,6 +299,9 @@ class Engine:
 
     def sweep(self, nsweeps=1):
         _chk(load().svils_sweep(self._h, nsweeps))
+
+    def prepare_graphs(self, max_sweeps=16):
+        _chk(load().svils_prepare_graphs(self._h, max_sweeps))
 
     def set_stochastic(self, batch_nodes=0, tau0=1024.0, kappa=0.9, node_tau0=None, node_kappa=None, seed=0,
                        shard_block=0):

@@ -1799,6 +1799,33 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   return flush_validation(h);
 }
 
+// Capture the hipGraphs svils_sweep replays -- 1, 4, 8, 16 ... sweeps up to max_sweeps -- NOW, while the caller is still in
+// its set-up, instead of in the middle of the run once the handle has seen 128 sweeps.  A short run (the default ca-AstroPh
+// run stops after 31 sweeps) then replays graphs from its first chunk of >= 4 sweeps on: eager launches cost the device
+// ~20 us of gaps per three-launch sweep.  The graphs do not depend on the state, only on the buffers: call it after
+// svils_set_graph / svils_set_validation / svils_set_state.  Nothing runs except the stand-alone link classification.
+int svils_prepare_graphs(svils_handle *h, uint32_t max_sweeps) {
+  if (!h) return fail(SVILS_ERR_ARG, "svils_prepare_graphs: null handle");
+  if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_prepare_graphs: set graph and state first");
+  if (h->stoch || h->d.ksh || !h->graphs_ok) return 0;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int rc = ensure_classes(h);
+  if (rc) return rc;
+  const uint32_t saved = h->tmask;
+  h->tmask = 0;
+  if (!h->gexec1) h->gexec1 = capture_sweeps(h, 1);
+  if (h->gexec1 && !h->gexecN && max_sweeps >= svils_handle::kGraphSweeps) h->gexecN = capture_sweeps(h, svils_handle::kGraphSweeps);
+  if (!h->gexecN) h->gexecN = h->gexec1 ? capture_sweeps(h, svils_handle::kGraphSweeps) : nullptr;   // graph_sweeps expects both
+  for (int i = 2; i <= (int)svils_handle::kGraphMaxLog && h->gexec1; ++i) {
+    const uint32_t m = 1u << i;
+    if (m > max_sweeps || m == svils_handle::kGraphSweeps || h->gexecP[i]) continue;
+    h->gexecP[i] = capture_sweeps(h, m);
+  }
+  h->tmask = saved;
+  if (!h->gexec1 || !h->gexecN) { drop_graphs(h); h->graphs_ok = false; }
+  return 0;
+}
+
 int svils_set_timing_period(svils_handle *h, uint32_t period) {
   if (!h || period == 0) return fail(SVILS_ERR_ARG, "svils_set_timing_period: bad argument");
   h->tperiod = period;

@@ -18,13 +18,29 @@ inline void append_fixed(std::string &o, double v, char sep) {
     const double y = v * S, fl = std::floor(y), fr = y - fl;
     if (std::fabs(fr - 0.5) > 4e-6) {
       const uint64_t r = (uint64_t)fl + (fr > 0.5 ? 1u : 0u);
-      uint64_t q = r / P, fq = r % P;
+      uint64_t q = r / P;
+      uint32_t fq = (uint32_t)(r % P);
       char tmp[40];
       char *e = tmp + sizeof tmp, *b = e;
       *--b = sep;
-      for (int i = 0; i < D; ++i) { *--b = (char)('0' + fq % 10); fq /= 10; }
+      // the D fraction digits, two at a time from a table (D = 5: one single digit first)
+      static const char *const dd =
+          "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+          "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+      if (D == 5) {
+        const uint32_t lo = fq % 100, mid = (fq / 100) % 100, hi = fq / 10000;
+        b -= 2; b[0] = dd[2 * lo]; b[1] = dd[2 * lo + 1];
+        b -= 2; b[0] = dd[2 * mid]; b[1] = dd[2 * mid + 1];
+        *--b = (char)('0' + hi);
+      } else {
+        const uint32_t lo = fq % 100, hi = fq / 100;
+        b -= 2; b[0] = dd[2 * lo]; b[1] = dd[2 * lo + 1];
+        *--b = (char)('0' + hi);
+      }
       *--b = '.';
-      do { *--b = (char)('0' + q % 10); q /= 10; } while (q);
+      if (q < 10) *--b = (char)('0' + q);           // the common case: values below 10
+      else do { *--b = (char)('0' + q % 10); q /= 10; } while (q);
+      // (the caller reserves a block's worth of text: this append never reallocates inside a row)
       o.append(b, (size_t)(e - b));
       return;
     }

@@ -26,6 +26,9 @@ class FlatPairSet {
       if (tab_[i] == 0) { tab_[i] = key; ++size_; return true; }
     }
   }
+  void prefetch(uint64_t key) const {    // the slot a later insert / contains of `key` starts at
+    if (!tab_.empty()) __builtin_prefetch(&tab_[mix64(key) & (tab_.size() - 1)], 1, 1);
+  }
   bool contains(uint64_t key) const {
     if (tab_.empty()) return false;
     const size_t m = tab_.size() - 1;
@@ -61,6 +64,12 @@ class FlatIdMap {
       if (val_[i] == kFree) return false;
       if (key_[i] == id) { *seq = val_[i]; return true; }
     }
+  }
+  void prefetch(uint32_t id) const {
+    if (key_.empty()) return;
+    const size_t i = mix64(id) & (key_.size() - 1);
+    __builtin_prefetch(&val_[i], 0, 1);
+    __builtin_prefetch(&key_[i], 0, 1);
   }
   void emplace(uint32_t id, uint32_t seq) {   // id must be absent
     if (2 * (size_ + 1) > key_.size()) rehash(key_.empty() ? 1024 : 2 * key_.size());

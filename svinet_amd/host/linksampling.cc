@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
 #include <cerrno>
@@ -31,6 +32,28 @@ FILE *open_or_die(const std::string &path, const char *what) {
     exit(-1);
   }
   return f;
+}
+// CPUs this process may really use: the affinity mask and the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us), not the
+// machine's core count -- a container with a 16-CPU quota on a 256-core host gains nothing from 64 threads
+unsigned usable_cpus() {
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n ? n : 1u, (unsigned)CPU_COUNT(&set));
+  double quota = 0.0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64];
+    long per = 0;
+    if (fscanf(f, "%63s %ld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) quota = atof(a) / (double)per;
+    fclose(f);
+  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    long q = -1, per = 100000;
+    if (fscanf(g, "%ld", &q) != 1) q = -1;
+    fclose(g);
+    if (FILE *h2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h2, "%ld", &per) != 1) per = 100000; fclose(h2); }
+    if (q > 0 && per > 0) quota = (double)q / (double)per;
+  }
+  if (quota >= 1.0) n = std::min<unsigned>(n, (unsigned)(quota + 0.5));
+  return std::max(1u, n);
 }
 double now_s() {
   timespec ts;
@@ -287,6 +310,12 @@ void LinkSampling::attach() {
       std::copy(&gamma_[(size_t)i * k_], &gamma_[(size_t)(i + 1) * k_], &g[(size_t)dev_of_[i] * k_]);
     if (svils_set_state(h_, g.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
   }
+  // the pipelined loop issues chunks of 1, 2, 4, 8, 16, 16 ... sweeps: their graphs are captured here, in the set-up,
+  // not inside a run that may be over after 31 sweeps (svils.h: svils_prepare_graphs)
+  if (pipelined_reports() && !getenv("SVILS_GRAPH_AFTER")) {
+    send_graph();
+    if (svils_prepare_graphs(h_, env_.sweep_batch ? std::min<uint32_t>(env_.sweep_batch, 64) : 16)) die_svils("svils_prepare_graphs");
+  }
 }
 
 // ---------------------------------------------------------------- validation set
@@ -487,8 +516,7 @@ void LinkSampling::init_gamma2() {
     for (uint32_t q : network_.get_edges(p))
       if (p < q) { lp.push_back(p); lq.push_back(q); }   // all links, held-out ones included
   const size_t E = lp.size(), K = k_;
-  unsigned T = std::thread::hardware_concurrency();
-  T = std::max(1u, std::min(T, 64u));
+  unsigned T = std::min(usable_cpus(), 64u);
   if (E * K < (1u << 22)) T = 1;   // small problems: threads cost more than they save
   // links per chunk: 32 MB of uniforms, 16 MB with more than 32 threads (two buffers per thread)
   size_t C = std::max<size_t>(256, ((size_t)(T > 32 ? 16 : 32) << 20) / (K * sizeof(double)));
@@ -556,24 +584,71 @@ void LinkSampling::init_gamma2() {
           const size_t cnt = std::min(C, E - l0);
           double *v = bufs[(r & 1) * T + t].data();
           GslMt19937 g(st[t].data(), rng_.seed_state(), o0 + (uint64_t)K * l0);
-          g.fill_uniform(v, cnt * K);
-          normalise(v, 0, cnt);
+          for (size_t i = 0; i < cnt; ++i) {        // drawn and normalised while the row sits in L1: one pass over memory
+            g.fill_uniform(v + i * K, K);
+            normalise(v, i, i + 1);
+          }
         }
         stride.apply(st[t].data());
       };
-      auto gather = [&](size_t r, unsigned w) {
+      // Round r's vectors into gamma, keeping every row's additions in link order.  Row x receives its q-side
+      // additions (links (p' < x, x)) before its p-side ones (links (x, q)): all links with first endpoint below x come
+      // before those with first endpoint x.  So per round: first every q-side addition, rows split over the threads by
+      // node range (each scans the round's chunks in order); then the p-side ones, split by CHUNK -- links with the same p
+      // are consecutive, so thread t takes the runs of equal p that START in chunk t and follows a run into the next
+      // chunks if it straddles a boundary (adding by node range here would leave all p-side work of a round, whose links
+      // cover a few thousand consecutive nodes, to one or two threads: 4 of the 5 s this function took at n = 1e6).
+      auto chunk_of = [&](size_t r, unsigned t, size_t *l0, size_t *cnt) {
+        *l0 = r * W + (size_t)t * C;
+        *cnt = *l0 < E ? std::min(C, E - *l0) : 0;
+        return bufs[(r & 1) * T + t].data();
+      };
+      auto gather_q = [&](size_t r, unsigned w) {
         const uint32_t nb = (uint32_t)((uint64_t)n_ * w / T), ne = (uint32_t)((uint64_t)n_ * (w + 1) / T);
         for (unsigned t = 0; t < T; ++t) {
-          const size_t l0 = r * W + (size_t)t * C;
-          if (l0 >= E) break;
-          accumulate(bufs[(r & 1) * T + t].data(), l0, std::min(C, E - l0), nb, ne);
+          size_t l0, cnt;
+          const double *v = chunk_of(r, t, &l0, &cnt);
+          for (size_t i = 0; i < cnt; ++i) {
+            const uint32_t q = lq[l0 + i];
+            if (q >= nb && q < ne) { double *g = &gamma_[(size_t)q * K]; const double *u = v + i * K; for (size_t k = 0; k < K; ++k) g[k] += u[k]; }
+          }
         }
       };
-      for (size_t r = 0; r <= rounds; ++r) {
+      auto gather_p = [&](size_t r, unsigned t) {
+        size_t l0, cnt;
+        (void)chunk_of(r, t, &l0, &cnt);
+        if (!cnt) return;
+        const size_t round_end = std::min(E, (r + 1) * W);
+        size_t i = l0;
+        if (t > 0) {                                          // the run that came in from the chunk before belongs to its starter
+          const uint32_t pin = lp[l0 - 1];
+          while (i < l0 + cnt && lp[i] == pin) ++i;
+        }
+        const size_t own_end = l0 + cnt;
+        if (i >= own_end) return;                             // the whole chunk lies inside a run an earlier thread follows
+        while (i < round_end && (i < own_end || lp[i] == lp[own_end - 1])) {
+          const size_t tt = (i - r * W) / C;                  // the chunk this link sits in
+          const double *u = bufs[(r & 1) * T + tt].data() + (i - (r * W + tt * C)) * K;
+          double *g = &gamma_[(size_t)lp[i] * K];
+          for (size_t k = 0; k < K; ++k) g[k] += u[k];
+          ++i;
+        }
+      };
+      {   // prime the pipeline: round 0
         std::vector<std::thread> th;
-        if (r < rounds) for (unsigned t = 0; t < T; ++t) th.emplace_back(draw, r, t);
-        if (r > 0) for (unsigned w = 0; w < T; ++w) th.emplace_back(gather, r - 1, w);
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(draw, (size_t)0, t);
         for (auto &x : th) x.join();
+      }
+      for (size_t r = 0; r < rounds; ++r) {
+        std::vector<std::thread> drawing, th;
+        // round r + 1 is drawn into the other set of buffers (free since round r - 1 was added) while round r is added
+        if (r + 1 < rounds) for (unsigned t = 0; t < T; ++t) drawing.emplace_back(draw, r + 1, t);
+        for (unsigned w = 0; w < T; ++w) th.emplace_back(gather_q, r, w);
+        for (auto &x : th) x.join();
+        th.clear();
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(gather_p, r, t);
+        for (auto &x : th) x.join();
+        for (auto &x : drawing) x.join();
       }
       GslMt19937 after;
       if (!rng_.at(o0 + (uint64_t)E * K, &after)) { fprintf(stderr, "error: random stream jump failed\n"); exit(-1); }
@@ -688,10 +763,10 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
     printf("cannot open %s file:%s\n", what, strerror(errno));
     exit(-1);
   }
-  unsigned T = std::thread::hardware_concurrency();
-  T = std::max(1u, std::min(T, 64u));   // formatting is the bound where the file system is memory-fast (measured: 14 GB/s of write())
+  unsigned T = std::min(usable_cpus(), 64u);   // formatting is the bound where the file system is memory-fast (measured: 14 GB/s of write())
   if ((uint64_t)n * k < (1u << 22)) T = 1;
   if (const char *e = getenv("SVINET_WRITE_THREADS")) T = (unsigned)std::max(1, atoi(e));   // (tests: the threaded path on small files)
+  if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] %s: %u formatting threads (usable cpus %u)\n", what, T, usable_cpus());
   // how a wave reaches the file: plain positional writes from this thread -- 14 GB/s on the memory-backed file system of
   // the GPU box -- unless they turn out slow (0.2 GB/s on a disk-backed VM, where copies into a mapping from T threads
   // reached 1.6 GB/s): then the rest of the file goes through mappings.  SVINET_WRITE_MMAP=0 / 1 fixes the choice.
@@ -736,20 +811,27 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
     for (std::string &b : bs) b.clear();
   };
   int cur = 0;
+  double t_fmt = 0.0, t_wait = 0.0, t_flush = 0.0;
   for (uint32_t base = 0; base < n; base += T * B, cur ^= 1) {
     auto work = [&, base, cur](unsigned t) {
       std::string &o = buf[cur][t];
       const uint32_t b = (uint32_t)std::min<uint64_t>(n, (uint64_t)base + (uint64_t)t * B), e = (uint32_t)std::min<uint64_t>(n, (uint64_t)b + B);
+      if (e > b && o.capacity() == 0) o.reserve((size_t)(e - b) * ((size_t)k * bytes_per_number + 24));
       for (uint32_t i = b; i < e; ++i) row(i, o);
     };
     if (T == 1) { work(0); flush(buf[cur]); continue; }
     std::vector<std::thread> th;
+    const double w0 = now_s();
     for (unsigned t = 0; t < T; ++t) th.emplace_back(work, t);
     flush(buf[cur ^ 1]);                      // the previous wave goes to the file while this one is formatted
+    const double w1 = now_s();
     for (auto &x : th) x.join();
+    const double w2 = now_s();
+    t_flush += w1 - w0; t_wait += w2 - w1; t_fmt += w2 - w0;
   }
   flush(buf[cur ^ 1]);
   close(fd);
+  if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] %s: waves %.3f s, of which writing the previous wave %.3f s, then waiting for the formatters %.3f s\n", what, t_fmt, t_flush, t_wait);
 }
 inline void append_int(std::string &o, long v, char sep) {
   char tmp[32];
@@ -759,10 +841,17 @@ inline void append_int(std::string &o, long v, char sep) {
 }  // namespace
 
 void LinkSampling::save_model() {                          // src/linksampling.cc:804-837
-  std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
-  if (env_.kshard) fetch_state_ksharded(g, l);
+  // the state comes back into the host copies the constructor filled (n k doubles: allocating and zeroing a second 4 GB
+  // array at n = 1e6, k = 512 cost a second); only the layouts that have to be re-ordered take a scratch array
+  const bool direct = !env_.kshard && dev_of_.empty();
+  std::vector<double> g(direct ? 0 : (size_t)n_ * k_), l(2 * (size_t)k_);
+  const double tf = now_s();
+  if (direct) {
+    if (svils_get_state(h_, gamma_.data(), l.data(), nullptr)) die_svils("svils_get_state");
+    g.swap(gamma_);
+  } else if (env_.kshard) fetch_state_ksharded(g, l);
   else if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
-  if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] state fetched at %.3f s\n", now_s());
+  if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] state fetched in %.3f s\n", now_s() - tf);
   if (!dev_of_.empty()) {   // back to sequence-id order
     std::vector<double> t((size_t)n_ * k_);
     for (uint32_t i = 0; i < n_; ++i)

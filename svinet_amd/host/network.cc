@@ -1,6 +1,8 @@
 #include "network.hh"
 
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 #include <string>
 
 #include "env.hh"
@@ -88,12 +90,47 @@ int Network::read(const std::string &path) {
       c = t;
       return true;
     };
-    while (next_int(&a) && next_int(&b)) {
-      if (add_line((uint32_t)a, (uint32_t)b) && chat && ones() % 10000 == 0) {
+    // Pass 1: the numbers.  Pass 2: the reference's loop over the lines (Network::add / y(), src/network.hh:134-175), as
+    // a software pipeline -- every line costs three random probes into tables far larger than the caches (two ids, one
+    // pair key), so the slots of the lines ahead are prefetched while this one is processed: ids of line i + 16, pair
+    // key of line i + 8 (its ids are interned then, in line order: interning never depends on the pair set).  Pass 3:
+    // the neighbour lists, sized exactly and filled in link order (= the order the reference pushes them).
+    std::vector<int> vals;
+    vals.reserve(2 * lines + 2);
+    while (next_int(&a) && next_int(&b)) { vals.push_back(a); vals.push_back(b); }
+    { std::string().swap(buf); }
+    const size_t nl = vals.size() / 2;
+    constexpr size_t DA = 16, DB = 8;
+    struct Pending { uint32_t p, q; bool ok; };
+    Pending ring[DB];
+    auto intern_line = [&](size_t i) {
+      Pending x{0, 0, false};
+      if (i + DA < nl) { id2seq_.prefetch((uint32_t)vals[2 * (i + DA)]); id2seq_.prefetch((uint32_t)vals[2 * (i + DA) + 1]); }
+      // id1 stays interned even if id2 is refused (as in add_line)
+      if (intern((uint32_t)vals[2 * i], &x.p) && intern((uint32_t)vals[2 * i + 1], &x.q) && x.p != x.q) {
+        x.ok = true;
+        pair_set_.prefetch(pair_key(x.p, x.q));
+      }
+      return x;
+    };
+    for (size_t i = 0; i < std::min(nl, DB); ++i) ring[i] = intern_line(i);
+    std::vector<uint32_t> degree(declared_n_, 0);
+    for (size_t i = 0; i < nl; ++i) {
+      const Pending x = ring[i % DB];
+      if (i + DB < nl) ring[i % DB] = intern_line(i + DB);
+      if (!x.ok || !pair_set_.insert(pair_key(x.p, x.q))) continue;   // both directions listed / duplicates
+      edges_.push_back(x.p < x.q ? Edge(x.p, x.q) : Edge(x.q, x.p));
+      degree[x.p]++;
+      degree[x.q]++;
+      if (chat && ones() % 1000000 == 0) {
         printf("\r+ %d entries", ones());
         fflush(stdout);
       }
     }
+    // which endpoint came first on the line decides nothing here: adj[p] gets q and adj[q] gets p at the same moment, so
+    // walking the links in order and appending both ways reproduces the reference's lists
+    for (uint32_t v = 0; v < declared_n_; ++v) adj_[v].reserve(degree[v]);
+    for (const Edge &e : edges_) { adj_[e.first].push_back(e.second); adj_[e.second].push_back(e.first); }
   }
   fclose(f);
   if (env_.strid && env_.write_files) {

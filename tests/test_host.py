@@ -218,6 +218,7 @@ def test_init_gamma_threaded_draws_are_the_sequential_stream(graph_files):
     g0, v0 = run({"SVINET_INIT_THREADS": "1"})
     for env in ({"SVINET_INIT_THREADS": "4", "SVINET_INIT_CHUNK_LINKS": "1000"},
                 {"SVINET_INIT_THREADS": "7", "SVINET_INIT_CHUNK_LINKS": "333"},      # ragged last round, idle threads
+                {"SVINET_INIT_THREADS": "5", "SVINET_INIT_CHUNK_LINKS": "50"},       # a hub's run of 504 links spans ten chunks and two rounds
                 {"SVINET_INIT_THREADS": "16", "SVINET_INIT_CHUNK_LINKS": "12311"}):  # one round only
         g, v = run(env)
         assert np.array_equal(g, g0) and np.array_equal(v, v0), env

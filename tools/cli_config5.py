@@ -38,6 +38,20 @@ def main():
         print("graph: %d links, file %.0f MB, generated + written in %.1f s" % (pairs.shape[0], os.path.getsize(path) / 1e6, time.perf_counter() - t0), flush=True)
         tf = os.path.join(d, "timing.json")
         env = dict(os.environ, SVINET_TIMING_FILE=tf)
+        # CFG5_THREADS=16,32,64: the same run once per thread count of the host-side pools (init_gamma2, file writers)
+        for th in [x for x in os.environ.get("CFG5_THREADS", "").split(",") if x]:
+            e2 = dict(env, SVINET_INIT_THREADS=th, SVINET_WRITE_THREADS=th)
+            t1 = time.perf_counter()
+            r = subprocess.run([os.path.join(ROOT, "svinet_amd", "bin", "svinet"), "-file", path, "-n", str(n), "-k", str(k), "-link-sampling",
+                                "-no-stop", "-max-iterations", str(M), "-label", "t" + th], cwd=d, env=e2, capture_output=True, text=True, timeout=3000)
+            tm = json.load(open(tf))
+            print("threads %s: wall %.1f s read %.2f ctor %.2f sweeps %.2f final %.2f" % (th, time.perf_counter() - t1, tm["read_s"], tm["ctor_s"], tm["sweeps_s"], tm["final_files_s"]), flush=True)
+            for line in r.stderr.split("\n"):
+                if line.startswith("[final]") or line.startswith("[ctor]"):
+                    print("    " + line)
+            for x in os.listdir(d):
+                if os.path.isdir(os.path.join(d, x)):
+                    shutil.rmtree(os.path.join(d, x))
         t1 = time.perf_counter()
         r = subprocess.run([os.path.join(ROOT, "svinet_amd", "bin", "svinet"), "-file", path, "-n", str(n), "-k", str(k), "-link-sampling"]
                            + ([] if to_stop else ["-no-stop", "-max-iterations", str(M)]), cwd=d, env=env, capture_output=True, text=True, timeout=3000)
