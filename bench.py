@@ -647,6 +647,7 @@ def main():
     # If the communicator set-up or the timed sharded sweeps ever block, rank 0 still owes the driver a JSON
     # line: it says so (value null, the reason in "error") and every rank leaves instead of hanging the node.
     main_done = None
+    fallback = {}    # what the main watchdog can still print if the replayed window blocks (N > 1)
     if multi:
         import threading
         main_done = threading.Event()
@@ -654,11 +655,20 @@ def main():
         def main_watchdog():
             if not main_done.wait(timeout=args.main_timeout):
                 if rank == 0:
-                    print(json.dumps({"metric": "edge-updates/sec (link-sampling SVI step)", "value": None, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps,
-                                      "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
-                                      "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-                                      "error": "the sharded run did not finish within %d s (communicator set-up or a "
-                                               "collective blocked); nothing was measured" % args.main_timeout}), flush=True)
+                    line = {"metric": "edge-updates/sec (link-sampling SVI step)", "value": None, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps,
+                            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                            "error": "the sharded run did not finish within %d s (communicator set-up or a "
+                                     "collective blocked); nothing was measured" % args.main_timeout}
+                    if fallback.get("eager"):
+                        # the eager window (every launch and collective enqueued one by one) was timed before the
+                        # replayed one blocked: that number is a measurement of the same K sweeps and is what the line carries
+                        e = fallback["eager"]
+                        line.update({"value": e["value"], "ms_per_step": e["ms_per_step"], "data": fallback.get("data"),
+                                     "config": fallback.get("config"), "eager_window": e,
+                                     "error": "the hipGraph-replayed window did not finish within %d s; `value` is the EAGER window of the "
+                                              "same %d sweeps (SVILS_SHARDED_GRAPHS=0), timed before it" % (args.main_timeout, args.steps)})
+                    print(json.dumps(line), flush=True)
                 sys.stderr.write("bench.py: rank %d left on the main watchdog\n" % rank)
                 sys.stderr.flush()
                 os._exit(3)
@@ -687,13 +697,39 @@ def main():
     else:
         runner = _Sharded(setup, rank, world, local_rank, dist)
         eng = runner.eng
+    eager_window = None
+    sg_env = os.environ.get("SVILS_SHARDED_GRAPHS")
+    if multi and sg_env != "0":
+        # N > 1, first: the SAME window with every launch and collective enqueued one by one (no capture).  RCCL under
+        # hipGraph capture has never met more than one rank of this code; if the replayed window below blocks, the main
+        # watchdog prints the line with this number instead of nothing.  It also pins replay == eager on the real links.
+        os.environ["SVILS_SHARDED_GRAPHS"] = "0"
+        runner.sweep(args.warmup)
+        el_e = _timed(runner, eng, args.steps, dist, torch)
+        c_e = eng.control()
+        lam_e = eng.state()[1].copy()
+        eager_window = {"value": L * args.steps / el_e, "unit": "edge-updates/s", "ms_per_step": el_e / args.steps * 1e3,
+                        "what": "the same %d sweeps from the same re-seeded state, launched eagerly (SVILS_SHARDED_GRAPHS=0), "
+                                "timed before the replayed window" % args.steps}
+        fallback.update({"eager": eager_window, "data": data,
+                         "config": {"workload": "%s: n=%d k=%d links/sweep=%d, sweeps %d..%d of the seeded run, node blocks x%d"
+                                                % (args.workload, n, k, L, args.warmup, args.warmup + args.steps, world)}})
+        if sg_env is None:
+            del os.environ["SVILS_SHARDED_GRAPHS"]
+        else:
+            os.environ["SVILS_SHARDED_GRAPHS"] = sg_env
+        _reseed(eng, setup.gamma, setup.lam)
     runner.sweep(args.warmup)
     period = max(1, min(args.event_period, args.steps // 10))   # >= 10 timed launches whenever steps >= 10
     # The timed region carries no hipEvents: svils_sweep replays whole sweeps as hipGraphs (N = 1) / the sharded
-    # driver issues its phases and collectives back to back (N > 1).  Per-kernel timings come from event passes
+    # driver replays its phases with their collectives captured (N > 1).  Per-kernel timings come from event passes
     # of their own afterwards.
     elapsed = _timed(runner, eng, args.steps, dist, torch)
     ctrl = eng.control()
+    if eager_window is not None:
+        import numpy as np
+        same = (int(ctrl.iter), int(ctrl.links_dense), int(ctrl.links_shortcut)) == (int(c_e.iter), int(c_e.links_dense), int(c_e.links_shortcut))
+        eager_window["replayed_end_state_identical"] = bool(same and np.array_equal(lam_e, eng.state()[1]))
     if main_done is not None:
         main_done.set()
     assert ctrl.sweeps_done >= args.warmup + args.steps, "sweeps were skipped"
@@ -838,6 +874,8 @@ def main():
                 out["error"] = ("the %d ranks do not sit on %d distinct devices of one communicator (distinct PCI bus ids: %d, "
                                 "ncclCommCount: %s): value withheld" % (world, world, rccl["distinct_devices"], rccl["nranks"]))
                 out["value_withheld"], out["value"] = out["value"], None
+        if eager_window is not None:
+            out["eager_window"] = eager_window
         if exch is not None:
             out["exchange"] = {"ms_per_sweep": exch[0] / exch[1],
                                "note": "hipEvent time of the RCCL collectives on the engine stream (2 event brackets per sweep: rows + sum, "

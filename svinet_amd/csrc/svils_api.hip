@@ -922,7 +922,10 @@ int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
   // rule as svils_sweep: eager until the handle has run graph_after sweeps, timing brackets need eager launches.
   // SVILS_SHARDED_GRAPHS=0 keeps every sweep eager.  Every rank takes the same decisions (same arguments, same
   // history), so the ranks enqueue the same collectives in the same order whether they replay or launch.
-  static const bool graphs_wanted = !(getenv("SVILS_SHARDED_GRAPHS") && atoi(getenv("SVILS_SHARDED_GRAPHS")) == 0);
+  // (read at every call, not once per process: bench.py times an eager window first and a replayed one after it, so
+  // that a first contact with real multi-GPU RCCL that blocks under capture still leaves the eager number behind)
+  const char *sg_env = getenv("SVILS_SHARDED_GRAPHS");
+  const bool graphs_wanted = !(sg_env && atoi(sg_env) == 0);
   const bool warm = h->sgexec[0] != nullptr || h->sweeps_issued + nsweeps >= h->graph_after || nsweeps >= 64;
   uint32_t left = nsweeps;
   if (graphs_wanted && h->sgraphs_ok && h->tmask == 0 && nsweeps >= 4 && warm) {

@@ -18,6 +18,9 @@
 #   kscan        tools/k_scan.sh
 #   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations
 #   cli          bench.py's cli_end_to_end record alone
+#   forced       bench.py --force-sharded (real librccl, world of one) on ca-AstroPh K=20 and K=200: sharded driver vs plain engine
+#   cli5         tools/cli_config5.py (the binary at config-5 size): 4 sweeps with -no-stop, then the default flags
+#   benchN       bare `python bench.py --gpus 4|8 --test-one-gpu` (tests' transport)
 #   cliff        per-kernel times and sweep time on ca-AstroPh at K = 20 / 22 / 24 (the register cliff of the small-K kernels)
 #   ab-mid12     A/B of tools/build_variant.sh mid12 -DLPL_MID_KC=12 (K = 21..24 phi in the 4-wave block shape)
 TAG=$1; shift
@@ -77,6 +80,28 @@ for step in "$@"; do
          f=$(find $O/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/shard_rank0of8_kernel_stats_$t.csv
          rm -rf $O/prof_$t
        done) ;;
+    forced)   # the N > 1 driver of bench.py on the REAL librccl with a world of one (eager window, then hipGraph replay with the collectives captured)
+      for wl in astroph-k20 astroph-k200; do
+        timeout 600 python bench.py --force-sharded --workload $wl --no-cpu-baseline --no-extra > $O/bench_force_sharded_world1_$wl.json 2>> $O/bench_forced.err
+        python - $O/bench_force_sharded_world1_$wl.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+e = d.get("eager_window") or {}
+print(d["config"]["workload"][:40], "| sharded ms/sweep %.4f" % d["ms_per_step"], "| plain engine, same box %.4f" % d["n1_same_box"]["ms_per_step"],
+      "| ratio %.3f" % (d["ms_per_step"] / d["n1_same_box"]["ms_per_step"]), "| eager %.4f" % e.get("ms_per_step", float("nan")),
+      "| replay == eager:", e.get("replayed_end_state_identical"), "| rccl", d["rccl"]["rccl_version"], d["rccl"]["library"])
+PY
+      done 2>&1 | tee $O/force_sharded_world1.txt ;;
+    cli5)     # the drop-in binary at config-5 size: four sweeps with -no-stop, then the default flags to the stop rule
+      (export TMPDIR=/tmp; timeout 900 python tools/cli_config5.py 4 2>&1 | tee $O/cli_config5.txt
+       timeout 900 python tools/cli_config5.py stop 2>&1 | tee $O/cli_config5_to_stop.txt) ;;
+    benchN)   # bare `python bench.py --gpus 4 / 8` in one-GPU test mode (tests' transport; a code-path check, never a measurement)
+      python -c "import __graft_entry__ as g; g.build_test_transport()" >/dev/null 2>&1
+      for N in 4 8; do
+        SVILS_RCCL_LIBRARY=$R/tests/fakerccl/libfakerccl.so FAKERCCL_ASYNC=1 timeout 700 python bench.py --gpus $N --steps 10 --warmup 2 --test-one-gpu \
+          --extra-list ksharded_config4_astroph_k200 --no-cpu-baseline > $O/bench_gpus${N}_one_gpu_test_mode.json 2> $O/benchN_err$N.txt
+        echo "N=$N rc=$?"; tail -2 $O/benchN_err$N.txt; tail -c 600 $O/bench_gpus${N}_one_gpu_test_mode.json; echo
+      done ;;
     cli) python bench.py --cli-only > $O/bench_cli_end_to_end.json 2> $O/bench_cli.err; tail -c 1500 $O/bench_cli_end_to_end.json; echo ;;
     cliff) for k in 20 22 24; do python tools/kernel_times.py astroph-k$k 100 2>/dev/null | tail -1; python bench.py --workload astroph-k$k --steps 100 --warmup 5 --reps 20 --no-hbm-bound --no-config5 --no-cpu-baseline --no-cli 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('astroph-k$k graph-replayed sweep %.2f us' % (d['ms_per_step']*1e3))"; done | tee $O/k20_k24_cliff_kernel_times.txt ;;
     ab-mid12) WLS="astroph-k22 astroph-k24 astroph-k20 lfr-k28" bash tools/ab_libs.sh $O/ab_mid_kc12.txt libsvils.so libsvils_mid12.so ;;
