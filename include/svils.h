@@ -32,19 +32,31 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 6   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags;
+#define SVILS_ABI_VERSION 7   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags;
                                  6: work-balanced node blocks (svils_balance_node_blocks / svils_set_node_blocks), the node-block sweep
-                                    with ONE row exchange (SVILS_PHASE_B_LIGHT / SVILS_PHASE_EXPAND_ALL, SVILS_BUF_GSTAGE) */
+                                    with ONE row exchange (SVILS_PHASE_B_LIGHT / SVILS_PHASE_EXPAND_ALL, SVILS_BUF_GSTAGE);
+                                 7: k up to SVILS_MAX_K_TOTAL (column-tiled handles above SVILS_MAX_K; K-sharded k_total up to it),
+                                    getters that do not wait behind a stop the caller has seen ("After the stop") */
 
 typedef enum {
   SVILS_OK = 0,
   SVILS_ERR_ARG = -1,      /* bad argument / call order                     */
   SVILS_ERR_DEVICE = -2,   /* no HIP device, HIP runtime error              */
   SVILS_ERR_NOMEM = -3,    /* host or device allocation failed              */
-  SVILS_ERR_UNSUPPORTED = -4 /* e.g. k > SVILS_MAX_K                         */
+  SVILS_ERR_UNSUPPORTED = -4 /* e.g. k > SVILS_MAX_K_TOTAL                   */
 } svils_error;
 
-#define SVILS_MAX_K 2048
+#define SVILS_MAX_K 2048         /* columns ONE set of kernels holds: a whole-row handle up to here, a K-sharded slice up to here */
+/* k above SVILS_MAX_K (the reference has no limit short of its 16-bit community ids, src/linksampling.cc:635): svils_create
+ * builds a COLUMN-TILED handle -- ceil(k / SVILS_MAX_K) slices of every row on the one device, the K-sharded layout with all
+ * its "ranks" on one stream and their four exchanges summed in place.  Same results as a whole-row handle to rounding.  What
+ * such a handle offers: svils_set_graph / set_validation / set_state (graph before the first sweep or likelihood row) /
+ * sweep / synchronize / get_control / set_control / validation_row / get_rows / get_state / get_communities /
+ * get_community_tags / get_sweep_stats / destroy; everything else (reports, test set, mini-batch steps, node blocks,
+ * timing) answers SVILS_ERR_UNSUPPORTED.  Across GPUs the same k goes through K-sharded handles (k_total up to
+ * SVILS_MAX_K_TOTAL, at most SVILS_MAX_K columns per rank). */
+#define SVILS_MAX_K_TOTAL 65535
+#define SVILS_MAX_TILES 32
 
 typedef struct svils_handle svils_handle;
 
@@ -144,7 +156,11 @@ typedef struct {
                              count of the last sweep (:602,:726)                 */
 } svils_control;
 
-int svils_get_control(svils_handle *h, svils_control *out);   /* synchronises */
+/* After the stop: once a control block or a report that says `stopped` has reached the caller (svils_get_control,
+ * svils_report_fetch*), svils_get_control / get_state / get_rows / get_test_rows / get_communities / get_community_tags
+ * no longer wait for the stream: whatever a pipelined caller still has in flight behind the stopping sweep are launches
+ * that return at once, and the state they would wait for is already final. */
+int svils_get_control(svils_handle *h, svils_control *out);   /* synchronises (but see "After the stop") */
 /* only iter, annealing, write_comm, nh, prev_h, max_h are taken from `in` */
 int svils_set_control(svils_handle *h, const svils_control *in);
 

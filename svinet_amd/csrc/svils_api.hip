@@ -44,6 +44,11 @@ int fail(int code, const char *fmt, ...) {
                   "%s failed: %s", #expr, hipGetErrorString(e_));                        \
   } while (0)
 
+// column-tiled handles (k > SVILS_MAX_K, svils_handle::tiles)
+#define TILED(h) ((h) && !(h)->tiles.empty())
+#define NOT_TILED(h, name) \
+  do { if (TILED(h)) return fail(SVILS_ERR_UNSUPPORTED, name ": not available on a column-tiled handle (k > SVILS_MAX_K = %d)", SVILS_MAX_K); } while (0)
+
 struct EvPair {
   hipEvent_t a, b;
 };
@@ -68,6 +73,17 @@ struct svils_handle {
   bool cflag_dirty = true;        // the host wrote converged flags (or nothing has yet): rebuild cflag[] before classifying
   bool derive_ok = true;          // SVILS_DERIVE_M=0 keeps the stored mean indicators everywhere (A/B knob)
   bool mphi_stale = false;        // whole sweeps (derive_m) left the stored mean indicators behind gamma: k_mphi_from_gamma on demand
+  // The host has SEEN the stop (a fetched report or control block said `stopped`): every launch from the stopping sweep
+  // on returns at once without touching the state, so the getters below read it without waiting for the no-op sweeps a
+  // pipelined caller still has in flight behind the stop (two chunks of 16 sweeps in the drop-in binary: ~0.2 ms).
+  bool frozen = false;
+  // Column tiles (k > SVILS_MAX_K on ONE device): the handle the caller holds owns `tiles` K-sharded handles -- slices of
+  // at most SVILS_MAX_K columns of every row, the layout of a K-sharded multi-GPU run with all its "ranks" on this device
+  // and on one stream -- and drives their phases itself; the four exchanges of a K-sharded sweep become a sum over the
+  // tiles' buffers (k_tiles_combine).  Nothing else of this struct is used by such a handle.
+  std::vector<svils_handle *> tiles;
+  bool stream_shared = false;     // a tile: its stream is tile 0's
+  bool tiles_inited = false;      // the row sums / Elogpi of the tiles' state have been formed (needs graph and state)
   bool v_flush_needed = false;   // a three-launch sweep left its likelihood row / stop rule to the next launch
   bool v_flush_capture = false;  // ... and so do the sweeps captured in the hipGraphs
   void *cls_zero = nullptr;      // ltot + shist + scan descriptors, one contiguous block
@@ -465,6 +481,11 @@ int apply_s3_split(svils_handle *h) {
 
 }  // namespace
 
+namespace {
+int tiles_create(const svils_config *cfg, svils_handle **out);
+int tiles_try_init(svils_handle *h);
+}  // namespace
+
 extern "C" {
 
 const char *svils_last_error(void) { return g_err.c_str(); }
@@ -503,7 +524,11 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   if (!cfg || !out) return fail(SVILS_ERR_ARG, "svils_create: null argument");
   *out = nullptr;
   if (cfg->n == 0 || cfg->k == 0) return fail(SVILS_ERR_ARG, "svils_create: n and k must be > 0");
-  if (cfg->k > SVILS_MAX_K) return fail(SVILS_ERR_UNSUPPORTED, "k=%u exceeds SVILS_MAX_K=%d", cfg->k, SVILS_MAX_K);
+  if (cfg->k > SVILS_MAX_K_TOTAL || cfg->k_total > SVILS_MAX_K_TOTAL)
+    return fail(SVILS_ERR_UNSUPPORTED, "k=%u exceeds SVILS_MAX_K_TOTAL=%d (the reference's community ids are 16-bit, src/linksampling.cc:635)",
+                std::max(cfg->k, cfg->k_total), SVILS_MAX_K_TOTAL);
+  if (cfg->k > SVILS_MAX_K && cfg->k_total)
+    return fail(SVILS_ERR_UNSUPPORTED, "K-sharded handle: a slice of k=%u columns exceeds SVILS_MAX_K=%d (use more slices)", cfg->k, SVILS_MAX_K);
   if (cfg->reportfreq == 0) return fail(SVILS_ERR_ARG, "reportfreq must be >= 1");
   uint32_t nb = cfg->node_begin, ne = cfg->node_end ? cfg->node_end : cfg->n;
   if (nb > ne || ne > cfg->n) return fail(SVILS_ERR_ARG, "bad node block [%u,%u) for n=%u", nb, ne, cfg->n);
@@ -514,6 +539,7 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(SVILS_ERR_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
   HIPCHK(hipSetDevice(cfg->device));
+  if (cfg->k > SVILS_MAX_K) return tiles_create(cfg, out);   // column tiles on this device (svils_handle::tiles)
 
   svils_handle *h = new (std::nothrow) svils_handle();
   if (!h) return fail(SVILS_ERR_NOMEM, "out of host memory");
@@ -540,9 +566,9 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
   g.K0 = 0;
   g.Kt = cfg->k;
   if (cfg->k_total) {   // K-sharded handle: a column slice of every row
-    if ((uint64_t)cfg->k_begin + cfg->k > cfg->k_total || cfg->k_total > SVILS_MAX_K || nb != 0 || ne != cfg->n) {
+    if ((uint64_t)cfg->k_begin + cfg->k > cfg->k_total || cfg->k_total > SVILS_MAX_K_TOTAL || nb != 0 || ne != cfg->n) {
       delete h;
-      return fail(SVILS_ERR_ARG, "K-sharded handle: need k_begin + k <= k_total <= %d and the node block [0, n)", SVILS_MAX_K);
+      return fail(SVILS_ERR_ARG, "K-sharded handle: need k_begin + k <= k_total <= %d and the node block [0, n)", SVILS_MAX_K_TOTAL);
     }
     g.K0 = cfg->k_begin;
     g.Kt = cfg->k_total;
@@ -751,6 +777,7 @@ int svils_comm_unique_id(void *id128) {
 }
 
 int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
+  NOT_TILED(h, "svils_comm_init");
   if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SVILS_ERR_ARG, "svils_comm_init: bad argument");
   if (h->comm) return fail(SVILS_ERR_ARG, "svils_comm_init: communicator already initialised");
   int rc;
@@ -774,6 +801,7 @@ int svils_comm_init(svils_handle *h, const void *id128, int rank, int world) {
 }
 
 int svils_comm_query(svils_handle *h, svils_comm_info *out) {
+  NOT_TILED(h, "svils_comm_query");
   if (!h || !out) return fail(SVILS_ERR_ARG, "svils_comm_query: null argument");
   if (!h->comm) return fail(SVILS_ERR_ARG, "svils_comm_query: the handle has no communicator (svils_comm_init)");
   memset(out, 0, sizeof *out);
@@ -823,9 +851,23 @@ int exchange_rows_and_expand(svils_handle *h) {
   if (C <= 1) {
     if (h->comm) {
       Timed t(h, SVILS_KERNEL_EXCHANGE);
+      // The all-gather moves world * bmax rows.  Blocks balanced by WORK are far from equal in rows where the numbering
+      // puts the hubs first (ca-AstroPh on 8 ranks: 574 ... 6 775 nodes, world * bmax = 3.0 n): beyond 1.5 n the rows go
+      // as `world` in-place broadcasts with the exact counts in the same grouped launch (the form of the chunked
+      // exchange below) -- n rows on the links instead of world * bmax.
+      const bool padded = (uint64_t)b.bmax * b.world * 2 <= 3 * (uint64_t)g.n || getenv("SVILS_ALLGATHER_ROWS");
       NCCLCHK(g_rccl.GroupStart());
       NCCLCHK(g_rccl.AllReduce(d.kvec_a, d.kvec_a, g.K, ncclDouble, ncclSum, h->comm, h->stream));
-      NCCLCHK(g_rccl.AllGather(d.gown, d.gstage, (size_t)b.bmax * g.ld, ncclDouble, h->comm, h->stream));
+      if (padded) {
+        NCCLCHK(g_rccl.AllGather(d.gown, d.gstage, (size_t)b.bmax * g.ld, ncclDouble, h->comm, h->stream));
+      } else {
+        for (int r = 0; r < h->world; ++r) {
+          const size_t rows = b.bounds[r + 1] - b.bounds[r];
+          if (!rows) continue;
+          double *gp = d.gstage + (size_t)r * b.bmax * g.ld;
+          NCCLCHK(g_rccl.Broadcast(gp, gp, rows * g.ld, ncclDouble, r, h->comm, h->stream));
+        }
+      }
       NCCLCHK(g_rccl.GroupEnd());
     }
     return run_phase(h, SVILS_PHASE_EXPAND_ALL, false, true);
@@ -904,6 +946,7 @@ hipGraphExec_t capture_sharded(svils_handle *h, uint32_t nsweeps) {
 }  // namespace
 
 int svils_sweep_sharded(svils_handle *h, uint32_t nsweeps) {
+  NOT_TILED(h, "svils_sweep_sharded");
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: set graph and state first");
   if (!h->comm && h->world != 1) return fail(SVILS_ERR_ARG, "svils_sweep_sharded: call svils_comm_init first");
@@ -982,6 +1025,7 @@ int exchange_windows(svils_handle *h, uint32_t b, uint32_t e) {
 // Mini-batch (Robbins-Monro) steps over node-block shards with the exchanges issued here: the global step of
 // the north_star -- all-reduce of the K-vectors, the touched gamma (and mphi, flag) rows of every rank's window.
 int svils_step_sharded(svils_handle *h, uint32_t nsteps) {
+  NOT_TILED(h, "svils_step_sharded");
   if (!h) return fail(SVILS_ERR_ARG, "svils_step_sharded: null handle");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_sharded: call svils_set_stochastic first");
   if (!h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step_sharded: svils_set_stochastic needs shard_block (the node-block size)");
@@ -1015,6 +1059,7 @@ namespace {
 int open_step(svils_handle *h);
 }
 int svils_ksweep_phase(svils_handle *h, svils_kphase phase) {
+  NOT_TILED(h, "svils_ksweep_phase");
   if (!h) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: not a K-sharded handle (svils_config.k_total)");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_ksweep_phase: set graph and state first");
@@ -1049,6 +1094,7 @@ int svils_ksweep_phase(svils_handle *h, svils_kphase phase) {
 }
 
 int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, size_t *ndoubles) {
+  NOT_TILED(h, "svils_ksh_buffer_ptr");
   if (!h || !dptr || !ndoubles) return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: null argument");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_buffer_ptr: not a K-sharded handle");
   const DeviceState &d = h->d;
@@ -1077,6 +1123,7 @@ int svils_ksh_buffer_ptr(svils_handle *h, svils_ksh_buffer which, void **dptr, s
 }
 
 int svils_ksh_log_domain(svils_handle *h, int on) {
+  NOT_TILED(h, "svils_ksh_log_domain");
   if (!h) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: not a K-sharded handle");
   if (on < 0) return h->d.ksh_log;   // query
@@ -1099,6 +1146,7 @@ int ksh_sum(svils_handle *h, svils_ksh_buffer which) {
 }  // namespace
 
 int svils_ksh_init_state(svils_handle *h) {
+  NOT_TILED(h, "svils_ksh_init_state");
   int rc;
   if ((rc = svils_ksweep_phase(h, SVILS_KPHASE_INIT_ROWS))) return rc;
   if ((rc = ksh_sum(h, SVILS_KSH_ROWX))) return rc;
@@ -1106,6 +1154,7 @@ int svils_ksh_init_state(svils_handle *h) {
 }
 
 int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
+  NOT_TILED(h, "svils_sweep_ksharded");
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: not a K-sharded handle");
   if (!h->comm && h->geo.K != h->geo.Kt) return fail(SVILS_ERR_ARG, "svils_sweep_ksharded: call svils_comm_init first");
@@ -1135,6 +1184,7 @@ int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps) {
 // Mini-batch (Robbins-Monro) steps on the K-sharded layout: every rank steps through the SAME window of nodes on its own
 // column slice; the exchanges are those of a sweep, restricted to the window's share of the buffers.
 int svils_step_ksharded(svils_handle *h, uint32_t nsteps) {
+  NOT_TILED(h, "svils_step_ksharded");
   if (!h) return fail(SVILS_ERR_ARG, "svils_step_ksharded: null handle");
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_step_ksharded: not a K-sharded handle");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_ksharded: call svils_set_stochastic first");
@@ -1167,6 +1217,7 @@ namespace {
 // products of the own columns, summed over the ranks, then the log terms on the host in pair order
 // (the order of the reference's map walk).  rowx[3p] holds the full row sum of gamma[p] after
 // svils_ksh_init_state and after every sweep.  Collective.
+int ksh_validation_row_finish(svils_handle *h, double *row10);
 int ksh_validation_row(svils_handle *h, double *row10) {
   if (!h->have_graph) return fail(SVILS_ERR_ARG, "svils_validation_row: a K-sharded handle needs its graph and svils_ksh_init_state first");
   if (!h->comm && h->geo.K != h->geo.Kt) return fail(SVILS_ERR_ARG, "svils_validation_row: call svils_comm_init first");
@@ -1174,20 +1225,23 @@ int ksh_validation_row(svils_handle *h, double *row10) {
   HIPCHK(hipGetLastError());
   int rc = ksh_sum(h, SVILS_KSH_VDOT);
   if (rc) return rc;
+  return ksh_validation_row_finish(h, row10);
+}
+// the log terms of the summed dot products, on the host in pair order
+int ksh_validation_row_finish(svils_handle *h, double *row10) {
   const DeviceState &d = h->d;
-  std::vector<double> vdot(d.nv), rowx(3 * (size_t)h->geo.n);
+  std::vector<double> vdot(d.nv);
   std::vector<uint32_t> vp(3 * (size_t)d.nv);
   DevCtrl c;
   HIPCHK(hipMemcpyAsync(vdot.data(), d.vdot, vdot.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(rowx.data(), d.rowx, rowx.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(vp.data(), d.vpairs, vp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   double sz = 0.0, so = 0.0;
   uint32_t kz = 0, ko = 0;
   for (uint32_t i = 0; i < d.nv; ++i) {
-    const uint32_t p = vp[3 * (size_t)i], q = vp[3 * (size_t)i + 1], y = vp[3 * (size_t)i + 2];
-    const double pq = vdot[i] / (rowx[3 * (size_t)p] * rowx[3 * (size_t)q]);
+    const uint32_t y = vp[3 * (size_t)i + 2];
+    const double pq = vdot[i];   // (k_vdot_ksh works on the normalised rows)
     double sv = y ? pq : 1.0 - pq;
     if (sv < 1e-30) sv = 1e-30;
     if (y) { so += log(sv); ko++; } else { sz += log(sv); kz++; }
@@ -1200,7 +1254,202 @@ int ksh_validation_row(svils_handle *h, double *row10) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------- column tiles: k > SVILS_MAX_K on one device
+namespace {
+struct TilePtrs { double *p[SVILS_MAX_TILES]; int n; };
+// what an all-reduce over the "ranks" of a K-sharded run would leave: op 0 SUM (in tile order: reproducible), 1 MAX, 2 MIN
+__global__ __launch_bounds__(256) void k_tiles_combine(TilePtrs t, size_t count, int op) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    double v = t.p[0][i];
+    for (int g = 1; g < t.n; ++g) {
+      const double w = t.p[g][i];
+      v = op == 0 ? v + w : op == 1 ? fmax(v, w) : fmin(v, w);
+    }
+    for (int g = 0; g < t.n; ++g) t.p[g][i] = v;
+  }
+}
+
+int tiles_combine(svils_handle *h, svils_ksh_buffer which) {
+  TilePtrs t{};
+  t.n = (int)h->tiles.size();
+  size_t count = 0;
+  for (int i = 0; i < t.n; ++i) {
+    void *p = nullptr;
+    size_t n = 0;
+    int rc = svils_ksh_buffer_ptr(h->tiles[(size_t)i], which, &p, &n);
+    if (rc) return rc;
+    if (i && n != count) return fail(SVILS_ERR_ARG, "column tiles: exchange buffer %d has different sizes on the tiles", (int)which);
+    count = n;
+    t.p[i] = (double *)p;
+  }
+  if (!count) return 0;
+  const int op = which == SVILS_KSH_DMAX ? 1 : which == SVILS_KSH_EARG ? 2 : 0;
+  const uint32_t nb = (uint32_t)std::min<size_t>((count + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_tiles_combine, dim3(nb), dim3(256), 0, h->tiles[0]->stream, t, count, op);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int tiles_phase(svils_handle *h, svils_kphase ph) {
+  for (svils_handle *t : h->tiles) {
+    int rc = svils_ksweep_phase(t, ph);
+    if (rc) return rc;
+  }
+  return 0;
+}
+// row sums and Elogpi of a freshly set state (svils_ksh_init_state over the tiles); needs graph and state on every tile
+int tiles_try_init(svils_handle *h) {
+  if (h->tiles_inited || !h->have_graph || !h->have_state) return 0;
+  int rc;
+  if ((rc = tiles_phase(h, SVILS_KPHASE_INIT_ROWS))) return rc;
+  if ((rc = tiles_combine(h, SVILS_KSH_ROWX))) return rc;
+  if ((rc = tiles_phase(h, SVILS_KPHASE_INIT_EXPAND))) return rc;
+  h->tiles_inited = true;
+  return 0;
+}
+int tiles_need_init(svils_handle *h, const char *who) {
+  int rc = tiles_try_init(h);
+  if (rc) return rc;
+  if (!h->tiles_inited) return fail(SVILS_ERR_ARG, "%s: a column-tiled handle (k > SVILS_MAX_K) needs svils_set_graph and svils_set_state first", who);
+  return 0;
+}
+
+int tiles_create(const svils_config *cfg, svils_handle **out) {
+  if (cfg->k > SVILS_MAX_K_TOTAL) return fail(SVILS_ERR_UNSUPPORTED, "k=%u exceeds SVILS_MAX_K_TOTAL=%d (the reference's community ids are 16-bit, src/linksampling.cc:635)", cfg->k, SVILS_MAX_K_TOTAL);
+  const uint32_t ne = cfg->node_end ? cfg->node_end : cfg->n;
+  if (cfg->node_begin != 0 || ne != cfg->n || cfg->n_alloc > cfg->n)
+    return fail(SVILS_ERR_UNSUPPORTED, "k=%u > SVILS_MAX_K=%d runs as column tiles of the whole graph: node blocks are not available (shard the columns instead: svils_config.k_total)", cfg->k, SVILS_MAX_K);
+  const uint32_t G = (cfg->k + SVILS_MAX_K - 1) / SVILS_MAX_K;
+  svils_handle *h = new (std::nothrow) svils_handle();
+  if (!h) return fail(SVILS_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  h->geo.n = cfg->n;
+  h->geo.K = h->geo.Kt = cfg->k;
+  for (uint32_t r = 0; r < G; ++r) {
+    svils_config c = *cfg;
+    c.k_begin = (uint32_t)((uint64_t)cfg->k * r / G);
+    c.k = (uint32_t)((uint64_t)cfg->k * (r + 1) / G) - c.k_begin;
+    c.k_total = cfg->k;
+    svils_handle *t = nullptr;
+    int rc = svils_create(&c, &t);
+    if (rc) { svils_destroy(h); return rc; }
+    h->tiles.push_back(t);
+    if (r) {   // one stream for all tiles: their phases and the sums between them are one sequence
+      (void)hipStreamSynchronize(t->stream);
+      (void)hipStreamDestroy(t->stream);
+      t->stream = h->tiles[0]->stream;
+      t->stream_shared = true;
+    }
+  }
+  h->stream = h->tiles[0]->stream;
+  h->stream_shared = true;
+  *out = h;
+  return 0;
+}
+
+int tiles_set_state(svils_handle *h, const double *gamma, const double *lambda, const uint32_t *converged) {
+  const uint32_t n = h->cfg.n, K = h->cfg.k;
+  std::vector<double> slice;
+  for (svils_handle *t : h->tiles) {
+    const uint32_t k0 = t->cfg.k_begin, w = t->cfg.k;
+    slice.resize((size_t)n * w);
+    for (uint32_t i = 0; i < n; ++i) memcpy(&slice[(size_t)i * w], gamma + (size_t)i * K + k0, (size_t)w * sizeof(double));
+    int rc = svils_set_state(t, slice.data(), lambda + 2 * (size_t)k0, converged);
+    if (rc) return rc;
+  }
+  h->have_state = true;
+  h->tiles_inited = false;
+  h->frozen = false;
+  return tiles_try_init(h);
+}
+
+int tiles_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *converged) {
+  const uint32_t n = h->cfg.n, K = h->cfg.k;
+  std::vector<double> slice;
+  for (svils_handle *t : h->tiles) {
+    const uint32_t k0 = t->cfg.k_begin, w = t->cfg.k;
+    if (gamma) slice.resize((size_t)n * w);
+    int rc = svils_get_state(t, gamma ? slice.data() : nullptr, lambda ? lambda + 2 * (size_t)k0 : nullptr, t == h->tiles[0] ? converged : nullptr);
+    if (rc) return rc;
+    if (gamma)
+      for (uint32_t i = 0; i < n; ++i) memcpy(gamma + (size_t)i * K + k0, &slice[(size_t)i * w], (size_t)w * sizeof(double));
+  }
+  return 0;
+}
+
+// one sweep = the phases of a K-sharded sweep on every tile, the exchanges summed in place (svils_sweep_ksharded)
+int tiles_sweep(svils_handle *h, uint32_t nsweeps) {
+  int rc = tiles_need_init(h, "svils_sweep");
+  if (rc) return rc;
+  svils_handle *t0 = h->tiles[0];
+  if (nsweeps > (uint64_t)t0->d.rows_cap * t0->prm.reportfreq)
+    return fail(SVILS_ERR_ARG, "svils_sweep: at most %llu sweeps per call", (unsigned long long)t0->d.rows_cap * t0->prm.reportfreq);
+  for (uint32_t i = 0; i < nsweeps; ++i) {
+    if (t0->d.ksh_log) {
+      if ((rc = tiles_phase(h, SVILS_KPHASE_DENMAX))) return rc;
+      if ((rc = tiles_combine(h, SVILS_KSH_DMAX))) return rc;
+    }
+    if ((rc = tiles_phase(h, SVILS_KPHASE_DEN))) return rc;
+    if ((rc = tiles_combine(h, SVILS_KSH_DEN))) return rc;
+    if (t0->d.ksh_lowt && (rc = tiles_combine(h, SVILS_KSH_EARG))) return rc;
+    if ((rc = tiles_phase(h, SVILS_KPHASE_PHI))) return rc;
+    if ((rc = tiles_combine(h, SVILS_KSH_ROWX))) return rc;
+    if ((rc = tiles_phase(h, SVILS_KPHASE_FIN))) return rc;
+    if ((rc = tiles_combine(h, SVILS_KSH_Q2))) return rc;
+    if ((rc = tiles_phase(h, SVILS_KPHASE_LAMBDA))) return rc;
+    if ((rc = tiles_combine(h, SVILS_KSH_VDOT))) return rc;
+    if ((rc = tiles_phase(h, SVILS_KPHASE_STOP))) return rc;
+  }
+  return 0;
+}
+
+int ksh_validation_row_finish(svils_handle *h, double *row10);
+int tiles_validation_row(svils_handle *h, double *row10) {
+  int rc = tiles_need_init(h, "svils_validation_row");
+  if (rc) return rc;
+  for (svils_handle *t : h->tiles) {
+    launch_ksh_phase(t->geo, t->d, t->prm, 8, t->stream);   // k_vdot_ksh alone
+    HIPCHK(hipGetLastError());
+  }
+  if ((rc = tiles_combine(h, SVILS_KSH_VDOT))) return rc;
+  return ksh_validation_row_finish(h->tiles[0], row10);
+}
+
+int tiles_get_communities(svils_handle *h, uint8_t *member) {
+  const uint32_t n = h->cfg.n, K = h->cfg.k;
+  std::vector<uint8_t> slice;
+  for (svils_handle *t : h->tiles) {
+    const uint32_t k0 = t->cfg.k_begin, w = t->cfg.k;
+    slice.resize((size_t)n * w);
+    int rc = svils_get_communities(t, slice.data());
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; ++i) memcpy(member + (size_t)i * K + k0, &slice[(size_t)i * w], w);
+  }
+  return 0;
+}
+
+// (node, community) pairs, by node, the communities of a node ascending
+int tiles_get_community_tags(svils_handle *h, uint32_t *tags, uint64_t cap, uint64_t *ntags) {
+  std::vector<uint64_t> keys;   // node << 32 | community
+  std::vector<uint32_t> part;
+  for (svils_handle *t : h->tiles) {
+    uint64_t nt = 0;
+    int rc = svils_get_community_tags(t, nullptr, 0, &nt);
+    if (rc) return rc;
+    part.resize(2 * (size_t)nt);
+    if ((rc = svils_get_community_tags(t, part.data(), nt, &nt))) return rc;
+    for (uint64_t i = 0; i < nt; ++i) keys.push_back((uint64_t)part[2 * i] << 32 | (uint64_t)(part[2 * i + 1] + t->cfg.k_begin));
+  }
+  std::sort(keys.begin(), keys.end());
+  *ntags = keys.size();
+  if (!tags) return 0;
+  if (keys.size() > cap) return fail(SVILS_ERR_ARG, "svils_get_community_tags: %llu tags, room for %llu", (unsigned long long)keys.size(), (unsigned long long)cap);
+  for (size_t i = 0; i < keys.size(); ++i) { tags[2 * i] = (uint32_t)(keys[i] >> 32); tags[2 * i + 1] = (uint32_t)keys[i]; }
+  return 0;
+}
+}  // namespace
+
 int svils_comm_allgather_host(svils_handle *h, const void *send, void *recv, size_t bytes) {
+  NOT_TILED(h, "svils_comm_allgather_host");
   if (!h || !send || !recv) return fail(SVILS_ERR_ARG, "svils_comm_allgather_host: null argument");
   if (!h->comm) {
     if (h->world != 1) return fail(SVILS_ERR_ARG, "svils_comm_allgather_host: call svils_comm_init first");
@@ -1242,6 +1491,7 @@ int svils_comm_allgather_host(svils_handle *h, const void *send, void *recv, siz
 }
 
 int svils_gather_communities(svils_handle *h) {
+  NOT_TILED(h, "svils_gather_communities");
   if (!h) return fail(SVILS_ERR_ARG, "svils_gather_communities: null handle");
   if (!h->comm) return h->world == 1 ? 0 : fail(SVILS_ERR_ARG, "svils_gather_communities: call svils_comm_init first");
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1259,6 +1509,7 @@ int svils_gather_communities(svils_handle *h) {
 }
 
 int svils_set_node_blocks(svils_handle *h, int rank, int world, const uint32_t *bounds) {
+  NOT_TILED(h, "svils_set_node_blocks");
   if (!h) return fail(SVILS_ERR_ARG, "svils_set_node_blocks: null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   return apply_blocks(h, rank, world, bounds, bounds != nullptr);
@@ -1299,6 +1550,11 @@ int svils_balance_node_blocks(const uint32_t *links, uint64_t nlinks, uint32_t n
 int svils_destroy(svils_handle *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->cfg.device);
+  if (!h->tiles.empty()) {   // column tiles: tile 0 owns the stream, so it goes last
+    for (size_t i = h->tiles.size(); i-- > 0;) svils_destroy(h->tiles[i]);
+    delete h;
+    return 0;
+  }
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (int i = 0; i < SVILS_KERNEL_COUNT; ++i)
     for (auto &ev : h->pending[i]) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -1323,12 +1579,17 @@ int svils_destroy(svils_handle *h) {
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (void *p : h->allocs) (void)hipFree(p);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && !h->stream_shared) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
 
 int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
+  if (TILED(h)) {
+    for (svils_handle *t : h->tiles) { int rc_ = svils_set_graph(t, links, nlinks); if (rc_) return rc_; }
+    h->have_graph = true;
+    return tiles_try_init(h);
+  }
   if (!h || (!links && nlinks)) return fail(SVILS_ERR_ARG, "svils_set_graph: null argument");
   if (h->have_graph) return fail(SVILS_ERR_ARG, "svils_set_graph: graph already set");
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1551,6 +1812,10 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
 }
 
 int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) {
+  if (TILED(h)) {
+    for (svils_handle *t : h->tiles) { int rc_ = svils_set_validation(t, pairs_y, nv); if (rc_) return rc_; }
+    return 0;
+  }
   if (!h || (!pairs_y && nv)) return fail(SVILS_ERR_ARG, "svils_set_validation: null argument");
   // captured kernel arguments hold the old validation pointers: drop every graph
   (void)hipStreamSynchronize(h->stream);
@@ -1578,6 +1843,10 @@ int svils_set_validation(svils_handle *h, const uint32_t *pairs_y, uint64_t nv) 
 
 int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
                     const uint32_t *converged) {
+  if (TILED(h)) {
+    if (!gamma || !lambda) return fail(SVILS_ERR_ARG, "svils_set_state: null argument");
+    return tiles_set_state(h, gamma, lambda, converged);
+  }
   if (!h || !gamma || !lambda) return fail(SVILS_ERR_ARG, "svils_set_state: null argument");
   h->mphi_stale = false;   // the stored rows have nothing to do with the new gamma (nor has the reference's _mphi after load_model)
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -1604,12 +1873,14 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
 }
 
 int svils_get_control(svils_handle *h, svils_control *out) {
+  if (TILED(h)) return svils_get_control(h->tiles[0], out);   // the loop control is replicated on the tiles
   if (!h || !out) return fail(SVILS_ERR_ARG, "svils_get_control: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->frozen) HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
   if (c.fault) return fault_error(c.fault);
+  if (c.stopped) h->frozen = true;
   out->iter = c.iter; out->annealing = c.annealing; out->write_comm = c.write_comm; out->nh = c.nh;
   out->prev_h = c.prev_h; out->max_h = c.max_h; out->stopped = c.stopped; out->why = c.why;
   out->sweeps_done = c.sweeps_done; out->rows = c.rows;
@@ -1618,6 +1889,10 @@ int svils_get_control(svils_handle *h, svils_control *out) {
 }
 
 int svils_set_control(svils_handle *h, const svils_control *in) {
+  if (TILED(h)) {
+    for (svils_handle *t : h->tiles) { int rc_ = svils_set_control(t, in); if (rc_) return rc_; }
+    return 0;
+  }
   if (!h || !in) return fail(SVILS_ERR_ARG, "svils_set_control: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1632,6 +1907,7 @@ int svils_set_control(svils_handle *h, const svils_control *in) {
 }
 
 int svils_validation_row(svils_handle *h, double *row10) {
+  if (TILED(h)) return row10 ? tiles_validation_row(h, row10) : fail(SVILS_ERR_ARG, "svils_validation_row: null argument");
   if (!h || !row10) return fail(SVILS_ERR_ARG, "svils_validation_row: null argument");
   if (!h->have_state) return fail(SVILS_ERR_ARG, "svils_validation_row: call svils_set_state first");
   if (h->d.nv == 0) return fail(SVILS_ERR_ARG, "svils_validation_row: no validation set");
@@ -1646,6 +1922,7 @@ int svils_validation_row(svils_handle *h, double *row10) {
 }
 
 int svils_sweep_phase(svils_handle *h, svils_phase phase) {
+  NOT_TILED(h, "svils_sweep_phase");
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep_phase: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep_phase: set graph and state first");
   if (h->d.ksh) return fail(SVILS_ERR_ARG, "svils_sweep_phase: a K-sharded handle is driven by svils_ksweep_phase");
@@ -1764,6 +2041,7 @@ int graph_sweeps(svils_handle *h, uint32_t n) {
 }  // namespace
 
 int svils_sweep(svils_handle *h, uint32_t nsweeps) {
+  if (TILED(h)) return tiles_sweep(h, nsweeps);
   if (!h) return fail(SVILS_ERR_ARG, "svils_sweep: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_sweep: set graph and state first");
   if (h->stoch) return fail(SVILS_ERR_ARG, "svils_sweep: the handle is in mini-batch mode, use svils_step");
@@ -1782,7 +2060,9 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
   // eager until the handle has seen graph_after sweeps (128; SVILS_GRAPH_AFTER, read when the handle is created,
   // overrides; 0 = capture at the first call of >= 4 sweeps), unless a single call is itself long.  Results are identical either way (one code path per kernel).
   const bool warm = h->gexec1 != nullptr || h->sweeps_issued + nsweeps >= h->graph_after || nsweeps >= 64;
-  if (!h->graphs_ok || nsweeps < 4 || !warm) rc = eager_sweeps(h, nsweeps);   // short calls are not worth a capture
+  // (short calls are not worth a capture -- but once the single-sweep graph exists, svils_prepare_graphs, they replay it:
+  // an eager three-launch sweep leaves ~20 us of gaps, a graph launch ~4.5)
+  if (!h->graphs_ok || !warm || (nsweeps < 4 && !(h->gexec1 && h->gexecN && h->tmask == 0))) rc = eager_sweeps(h, nsweeps);
   else if (h->tmask == 0) rc = graph_sweeps(h, nsweeps);
   // Per-kernel hipEvent timing needs eager launches: events captured as graph nodes cannot be read
   // with hipEventElapsedTime on this runtime.  With a sampling period P > 1 only every P-th sweep is
@@ -1808,6 +2088,7 @@ int svils_sweep(svils_handle *h, uint32_t nsweeps) {
 // ~20 us of gaps per three-launch sweep.  The graphs do not depend on the state, only on the buffers: call it after
 // svils_set_graph / svils_set_validation / svils_set_state.  Nothing runs except the stand-alone link classification.
 int svils_prepare_graphs(svils_handle *h, uint32_t max_sweeps) {
+  if (TILED(h)) return 0;   // column tiles launch eagerly (tens of launches of milliseconds each per sweep)
   if (!h) return fail(SVILS_ERR_ARG, "svils_prepare_graphs: null handle");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_prepare_graphs: set graph and state first");
   if (h->stoch || h->d.ksh || !h->graphs_ok) return 0;
@@ -1830,6 +2111,7 @@ int svils_prepare_graphs(svils_handle *h, uint32_t max_sweeps) {
 }
 
 int svils_set_timing_period(svils_handle *h, uint32_t period) {
+  NOT_TILED(h, "svils_set_timing_period");
   if (!h || period == 0) return fail(SVILS_ERR_ARG, "svils_set_timing_period: bad argument");
   h->tperiod = period;
   return 0;
@@ -1853,6 +2135,7 @@ void svils_stochastic_default(svils_stochastic *cfg, uint32_t batch_nodes) {
 }
 
 int svils_set_stochastic(svils_handle *h, const svils_stochastic *cfg) {
+  NOT_TILED(h, "svils_set_stochastic");
   if (!h || !cfg) return fail(SVILS_ERR_ARG, "svils_set_stochastic: null argument");
   if (h->d.ksh && cfg->shard_block) return fail(SVILS_ERR_ARG, "svils_set_stochastic: a K-sharded handle holds every node (shard_block must be 0)");
   if (!(cfg->tau0 >= 1.0) || !(cfg->kappa >= 0.0) || cfg->kappa > 1.0 || !(cfg->node_tau0 >= 1.0) ||
@@ -1971,6 +2254,7 @@ int open_step(svils_handle *h) {
 }  // namespace
 
 int svils_step_window(svils_handle *h, uint32_t *begin, uint32_t *end) {
+  NOT_TILED(h, "svils_step_window");
   if (!h || !begin || !end) return fail(SVILS_ERR_ARG, "svils_step_window: null argument");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_window: call svils_set_stochastic first");
   if (h->step_open) { *begin = h->sw_begin; *end = h->sw_end; }
@@ -1986,6 +2270,7 @@ int svils_step_phase(svils_handle *h, svils_phase phase) { return step_phase_imp
 namespace {
 int step_phase_impl(svils_handle *h, svils_phase phase, bool fused) {
   if (!h) return fail(SVILS_ERR_ARG, "svils_step_phase: null handle");
+  NOT_TILED(h, "svils_step_phase");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step_phase: call svils_set_stochastic first");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_step_phase: set graph and state first");
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -2015,6 +2300,7 @@ int step_phase_impl(svils_handle *h, svils_phase phase, bool fused) {
 }  // namespace
 
 int svils_step(svils_handle *h, uint32_t nsteps) {
+  NOT_TILED(h, "svils_step");
   if (!h) return fail(SVILS_ERR_ARG, "svils_step: null handle");
   if (!h->stoch) return fail(SVILS_ERR_ARG, "svils_step: call svils_set_stochastic first");
   if (h->scfg.shard_block) return fail(SVILS_ERR_ARG, "svils_step: a node-block shard is driven with svils_step_phase");
@@ -2032,6 +2318,7 @@ int svils_step(svils_handle *h, uint32_t nsteps) {
 }
 
 int svils_synchronize(svils_handle *h) {
+  if (TILED(h)) return svils_synchronize(h->tiles[0]);   // one stream for all tiles
   if (!h) return fail(SVILS_ERR_ARG, "svils_synchronize: null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2042,9 +2329,10 @@ int svils_synchronize(svils_handle *h) {
 }
 
 int svils_get_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows) {
+  if (TILED(h)) return svils_get_rows(h->tiles[0], first, count, rows);
   if (!h || (!rows && count)) return fail(SVILS_ERR_ARG, "svils_get_rows: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->frozen) HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
   if (c.fault) return fault_error(c.fault);
@@ -2072,6 +2360,7 @@ void ctrl_out(const DevCtrl &c, svils_control *out) {
 }  // namespace
 
 int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count, int with_communities, int *ticket) {
+  NOT_TILED(h, "svils_report_enqueue");
   if (!h || !ticket) return fail(SVILS_ERR_ARG, "svils_report_enqueue: null argument");
   if (!h->have_graph || !h->have_state) return fail(SVILS_ERR_ARG, "svils_report_enqueue: set graph and state first");
   const Geometry &g = h->geo;
@@ -2115,6 +2404,7 @@ int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count
 }
 
 int svils_report_ready(svils_handle *h, int ticket) {
+  NOT_TILED(h, "svils_report_ready");
   if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_ready: bad ticket");
   const hipError_t e = hipEventQuery(h->rslot[ticket].landed);
   if (e == hipSuccess) return 1;
@@ -2123,6 +2413,7 @@ int svils_report_ready(svils_handle *h, int ticket) {
 }
 
 int svils_report_test_rows(svils_handle *h, int ticket, double *test_rows, uint32_t *ntest) {
+  NOT_TILED(h, "svils_report_test_rows");
   if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_test_rows: bad ticket");
   if (!h->nt) return fail(SVILS_ERR_ARG, "svils_report_test_rows: the handle has no test set (svils_set_test)");
   svils_handle::ReportSlot &rs = h->rslot[ticket];
@@ -2139,6 +2430,7 @@ int svils_report_test_rows(svils_handle *h, int ticket, double *test_rows, uint3
 }
 
 int svils_set_test(svils_handle *h, const uint32_t *pairs_y, uint64_t nt) {
+  NOT_TILED(h, "svils_set_test");
   if (!h || (!pairs_y && nt)) return fail(SVILS_ERR_ARG, "svils_set_test: null argument");
   if (h->d.ksh) return fail(SVILS_ERR_UNSUPPORTED, "svils_set_test: not for K-sharded handles");
   if (nt > 0xffffffffull) return fail(SVILS_ERR_ARG, "svils_set_test: too many pairs");
@@ -2171,10 +2463,11 @@ int svils_set_test(svils_handle *h, const uint32_t *pairs_y, uint64_t nt) {
 }
 
 int svils_get_test_rows(svils_handle *h, uint32_t first, uint32_t count, double *rows) {
+  NOT_TILED(h, "svils_get_test_rows");
   if (!h || (!rows && count)) return fail(SVILS_ERR_ARG, "svils_get_test_rows: null argument");
   if (!h->nt) return fail(SVILS_ERR_ARG, "svils_get_test_rows: the handle has no test set (svils_set_test)");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->frozen) HIPCHK(hipStreamSynchronize(h->stream));
   DevCtrl c;
   HIPCHK(hipMemcpy(&c, h->d.ctrl, sizeof c, hipMemcpyDeviceToHost));
   if (c.fault) return fault_error(c.fault);
@@ -2191,6 +2484,7 @@ int svils_get_test_rows(svils_handle *h, uint32_t first, uint32_t count, double 
 }
 
 int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows, uint8_t *member) {
+  NOT_TILED(h, "svils_report_fetch");
   if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_fetch: bad ticket");
   svils_handle::ReportSlot &rs = h->rslot[ticket];
   if (member && !rs.with_member) return fail(SVILS_ERR_ARG, "svils_report_fetch: this report was enqueued without communities");
@@ -2199,6 +2493,7 @@ int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double 
   DevCtrl c;
   memcpy(&c, rs.host, sizeof c);
   if (c.fault) return fault_error(c.fault);
+  if (c.stopped) h->frozen = true;   // (svils_handle::frozen: the getters need not wait for the no-op sweeps behind the stop)
   if (ctrl) ctrl_out(c, ctrl);
   const uint32_t have = c.rows > rs.row_first ? std::min(c.rows - rs.row_first, rs.row_count) : 0u;
   if (nrows) *nrows = have;
@@ -2242,6 +2537,7 @@ uint64_t tags_of_bits(const Geometry &g, const uint64_t *bits, uint32_t *tags, u
 }  // namespace
 
 int svils_report_tag_count(svils_handle *h, int ticket, uint64_t *ntags) {
+  NOT_TILED(h, "svils_report_tag_count");
   if (!h || !ntags || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_tag_count: bad ticket");
   svils_handle::ReportSlot &rs = h->rslot[ticket];
   if (!rs.with_member) return fail(SVILS_ERR_ARG, "svils_report_tag_count: this report was enqueued without communities");
@@ -2252,6 +2548,7 @@ int svils_report_tag_count(svils_handle *h, int ticket, uint64_t *ntags) {
 
 int svils_report_fetch_tags(svils_handle *h, int ticket, svils_control *ctrl, double *rows, uint32_t *nrows,
                             uint32_t *tags, uint64_t cap, uint64_t *ntags) {
+  NOT_TILED(h, "svils_report_fetch_tags");
   if (!h || !ntags || (!tags && cap)) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: null argument");
   if (ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: bad ticket");
   if (!h->rslot[ticket].with_member) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: this report was enqueued without communities");
@@ -2264,9 +2561,10 @@ int svils_report_fetch_tags(svils_handle *h, int ticket, svils_control *ctrl, do
 }
 
 int svils_get_community_tags(svils_handle *h, uint32_t *tags, uint64_t cap, uint64_t *ntags) {
+  if (TILED(h)) return ntags && (tags || !cap) ? tiles_get_community_tags(h, tags, cap, ntags) : fail(SVILS_ERR_ARG, "svils_get_community_tags: null argument");
   if (!h || !ntags || (!tags && cap)) return fail(SVILS_ERR_ARG, "svils_get_community_tags: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->frozen) HIPCHK(hipStreamSynchronize(h->stream));
   const Geometry &g = h->geo;
   std::vector<uint64_t> bits((size_t)g.n * g.kw);
   HIPCHK(hipMemcpy(bits.data(), h->d.member, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -2276,9 +2574,10 @@ int svils_get_community_tags(svils_handle *h, uint32_t *tags, uint64_t cap, uint
 }
 
 int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *converged) {
+  if (TILED(h)) return tiles_get_state(h, gamma, lambda, converged);
   if (!h) return fail(SVILS_ERR_ARG, "svils_get_state: null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->frozen) HIPCHK(hipStreamSynchronize(h->stream));
   const Geometry &g = h->geo;
   if (gamma)
     HIPCHK(hipMemcpy2D(gamma, g.K * sizeof(double), h->d.gamma, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
@@ -2293,9 +2592,10 @@ int svils_get_state(svils_handle *h, double *gamma, double *lambda, uint32_t *co
 }
 
 int svils_get_communities(svils_handle *h, uint8_t *member) {
+  if (TILED(h)) return member ? tiles_get_communities(h, member) : fail(SVILS_ERR_ARG, "svils_get_communities: null argument");
   if (!h || !member) return fail(SVILS_ERR_ARG, "svils_get_communities: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->frozen) HIPCHK(hipStreamSynchronize(h->stream));
   const Geometry &g = h->geo;
   std::vector<uint64_t> bits((size_t)g.n * g.kw);
   HIPCHK(hipMemcpy(bits.data(), h->d.member, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -2314,6 +2614,7 @@ int svils_get_communities(svils_handle *h, uint8_t *member) {
 }
 
 int svils_get_aux(svils_handle *h, int which, void *out) {
+  NOT_TILED(h, "svils_get_aux");
   if (!h || !out) return fail(SVILS_ERR_ARG, "svils_get_aux: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2351,6 +2652,7 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
 }
 
 int svils_debug_eval(svils_handle *h, int which, const double *in, double *out, uint32_t n) {
+  if (TILED(h)) return svils_debug_eval(h->tiles[0], which, in, out, n);
   if (!h || !in || !out || which < 0 || which > 3) return fail(SVILS_ERR_ARG, "svils_debug_eval: bad argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   double *din = nullptr, *dout = nullptr;
@@ -2369,6 +2671,7 @@ int svils_debug_eval(svils_handle *h, int which, const double *in, double *out, 
 }
 
 int svils_enable_timing(svils_handle *h, uint32_t kernel_mask) {
+  NOT_TILED(h, "svils_enable_timing");
   if (!h) return fail(SVILS_ERR_ARG, "svils_enable_timing: null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   int rc = drain_timing(h);
@@ -2380,6 +2683,7 @@ int svils_enable_timing(svils_handle *h, uint32_t kernel_mask) {
 }
 
 int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches) {
+  NOT_TILED(h, "svils_get_timing");
   if (!h || !ms || !launches) return fail(SVILS_ERR_ARG, "svils_get_timing: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2390,6 +2694,7 @@ int svils_get_timing(svils_handle *h, double *ms, uint64_t *launches) {
 }
 
 int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint64_t *out) {
+  if (TILED(h)) return svils_get_sweep_stats(h->tiles[0], first, count, out);
   if (!h || (!out && count)) return fail(SVILS_ERR_ARG, "svils_get_sweep_stats: null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2410,6 +2715,7 @@ int svils_get_sweep_stats(svils_handle *h, uint32_t first, uint32_t count, uint6
 }
 
 int svils_get_timed_links(svils_handle *h, uint64_t *out3) {
+  NOT_TILED(h, "svils_get_timed_links");
   if (!h || !out3) return fail(SVILS_ERR_ARG, "svils_get_timed_links: null argument");
   out3[0] = out3[1] = out3[2] = 0;
   for (uint32_t sw : h->timed_sweeps) {
@@ -2423,6 +2729,7 @@ int svils_get_timed_links(svils_handle *h, uint64_t *out3) {
 
 int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr, size_t *bytes,
                         size_t *row_bytes) {
+  NOT_TILED(h, "svils_device_buffer");
   if (!h || !dptr || !bytes || !row_bytes) return fail(SVILS_ERR_ARG, "svils_device_buffer: null argument");
   const Geometry &g = h->geo;
   const DeviceState &d = h->d;

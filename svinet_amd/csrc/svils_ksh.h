@@ -773,9 +773,12 @@ __global__ __launch_bounds__(256) void k_vdot_ksh(Geometry geo, DeviceState d) {
     double gp[V], gq[V];
     load_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gp);
     load_row<W, V>(d.gamma + (size_t)q * ld, lw, ld, gq);
+    // on normalised rows (the summed row sums are in rowx since the exchange behind the phi pass): the raw product
+    // overflows once gamma reaches 1e154, which the annealing scale does on tiny graphs with thousands of communities
+    const double rp = 1.0 / d.rowx[3 * (size_t)p], rq = 1.0 / d.rowx[3 * (size_t)q];
     double dot = 0.0;
 #pragma unroll
-    for (int v = 0; v < V; ++v) dot += gp[v] * gq[v] * beta[v];
+    for (int v = 0; v < V; ++v) dot += (gp[v] * rp) * (gq[v] * rq) * beta[v];
     dot = group_sum<W>(dot);
     if (lane == 0) d.vdot[i] = dot;
   }
@@ -792,8 +795,8 @@ __global__ __launch_bounds__(256) void k_vsum_ksh(Geometry geo, DeviceState d, P
   double sz = 0.0, so = 0.0, kz = 0.0;
   if (d.nv > 0 && (c->iter % prm.reportfreq == 0))
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < d.nv; i += gridDim.x * blockDim.x) {
-      const uint32_t p = d.vpairs[3 * (size_t)i], q = d.vpairs[3 * (size_t)i + 1], y = d.vpairs[3 * (size_t)i + 2];
-      const double pq = d.vdot[i] / (d.rowx[3 * (size_t)p] * d.rowx[3 * (size_t)q]);
+      const uint32_t y = d.vpairs[3 * (size_t)i + 2];
+      const double pq = d.vdot[i];   // (k_vdot_ksh: partial dot products of the normalised rows, summed over the ranks)
       double sv = y ? pq : 1.0 - pq;
       if (sv < 1e-30) sv = 1e-30;
       const double u = log(sv);

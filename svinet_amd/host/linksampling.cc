@@ -193,6 +193,7 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
 
 bool LinkSampling::pipelined_reports() const {
   if (env_.sharded || env_.kshard || env_.minibatch || env_.gpus > 1) return false;
+  if (k_ > SVILS_MAX_K) return false;   // a column-tiled handle (svils.h): no report slots, the synchronous loop
   const char *e = getenv("SVINET_SYNC_REPORTS");
   return !(e && atoi(e) != 0);
 }
@@ -280,7 +281,7 @@ void LinkSampling::attach() {
     if (env_.sharded) sc.shard_block = (n_ + (uint32_t)env_.gpus - 1) / (uint32_t)env_.gpus;   // every rank steps through its own block
     if (svils_set_stochastic(h_, &sc)) die_svils("svils_set_stochastic");
   }
-  if (env_.kshard) send_graph();   // the K-sharded initial state needs the link list (row sums cross ranks)
+  if (env_.kshard || k_ > SVILS_MAX_K) send_graph();   // the K-sharded (and column-tiled) initial state needs the link list (row sums cross slices)
   // with -accuracy validation_likelihood() returns at once (:969-970)
   if (!env_.accuracy && !val_sorted_.empty()) {
     std::vector<uint32_t> v(val_sorted_);
@@ -1203,11 +1204,9 @@ int LinkSampling::sweep_loop_pipelined() {
     timing_.reports++;
     timing_.report_host_s += now_s() - t0;
     if (c.stopped) {                                              // :1044-1048; the sweeps behind the stop were no-ops
-      for (const Flight &g : flight) {
-        svils_control cc;
-        uint32_t hv = 0;
-        if (svils_report_fetch(h_, g.ticket, &cc, rows.data(), &hv, nullptr)) die_svils("svils_report_fetch");
-      }
+      // The chunks still in flight behind the stop are launches that return at once (the state is frozen where the
+      // reference's do_on_stop() saves it) and their reports repeat this one: nobody waits for them -- the library's
+      // getters read a state whose stop the host has seen without synchronising with the stream (svils.h, "After the stop").
       // every recorded row reaches the files: whatever the landed reports did not carry (none, if the row bookkeeping
       // above is right) is read from the ring before the final files are written
       if (c.rows > rows_logged_) fetch_and_log_rows();

@@ -37,7 +37,7 @@ def main():
                 f.write("\n".join("%d\t%d" % (a, b) for a, b in blk.tolist()) + "\n")
         print("graph: %d links, file %.0f MB, generated + written in %.1f s" % (pairs.shape[0], os.path.getsize(path) / 1e6, time.perf_counter() - t0), flush=True)
         tf = os.path.join(d, "timing.json")
-        env = dict(os.environ, SVINET_TIMING_FILE=tf)
+        env = dict(os.environ, SVINET_TIMING_FILE=tf, SVINET_TRACE_LOOP="1")   # (the trace marks go to stderr: where the constructor and the writers spend their time)
         # CFG5_THREADS=16,32,64: the same run once per thread count of the host-side pools (init_gamma2, file writers)
         for th in [x for x in os.environ.get("CFG5_THREADS", "").split(",") if x]:
             e2 = dict(env, SVINET_INIT_THREADS=th, SVINET_WRITE_THREADS=th)

@@ -85,7 +85,7 @@ for step in "$@"; do
         timeout 600 python bench.py --force-sharded --workload $wl --no-cpu-baseline --no-extra > $O/bench_force_sharded_world1_$wl.json 2>> $O/bench_forced.err
         python - $O/bench_force_sharded_world1_$wl.json <<'PY'
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d = [json.loads(l) for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]   # (librccl prints a banner after the line)
 e = d.get("eager_window") or {}
 print(d["config"]["workload"][:40], "| sharded ms/sweep %.4f" % d["ms_per_step"], "| plain engine, same box %.4f" % d["n1_same_box"]["ms_per_step"],
       "| ratio %.3f" % (d["ms_per_step"] / d["n1_same_box"]["ms_per_step"]), "| eager %.4f" % e.get("ms_per_step", float("nan")),

@@ -77,7 +77,9 @@ for G in Gs:
         e.close()
     t_nb = max(t_rank)
     bmax = int(np.max(np.diff(bounds.astype(np.int64))))
-    rows_total = G * bmax * ld * 8               # the staged rows, slices padded to the largest block
+    # the staged rows: slices padded to the largest block (all-gather) while G * bmax <= 1.5 n, else the exact rows as G
+    # grouped broadcasts (exchange_rows_and_expand, svils_api.hip)
+    rows_total = (G * bmax if 2 * G * bmax <= 3 * n else n) * ld * 8
     kvec = 4 * k * 8
     recv = rows_total * (G - 1) / G + 2 * kvec * (G - 1) / G
     t_link = link_time(recv, G, 2)
