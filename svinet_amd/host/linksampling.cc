@@ -818,7 +818,8 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
       std::string &o = buf[cur][t];
       const uint32_t b = (uint32_t)std::min<uint64_t>(n, (uint64_t)base + (uint64_t)t * B), e = (uint32_t)std::min<uint64_t>(n, (uint64_t)b + B);
       if (e > b && o.capacity() == 0) o.reserve((size_t)(e - b) * ((size_t)k * bytes_per_number + 24));
-      for (uint32_t i = b; i < e; ++i) row(i, o);
+      RowOut out(o);                         // (fixedfmt.hh: the thread's own scratch in front of the block's string)
+      for (uint32_t i = b; i < e; ++i) row(i, out);
     };
     if (T == 1) { work(0); flush(buf[cur]); continue; }
     std::vector<std::thread> th;
@@ -833,11 +834,6 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
   flush(buf[cur ^ 1]);
   close(fd);
   if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] %s: waves %.3f s, of which writing the previous wave %.3f s, then waiting for the formatters %.3f s\n", what, t_fmt, t_flush, t_wait);
-}
-inline void append_int(std::string &o, long v, char sep) {
-  char tmp[32];
-  const int len = snprintf(tmp, sizeof tmp, "%ld%c", v, sep);
-  o.append(tmp, (size_t)len);
 }
 }  // namespace
 
@@ -860,11 +856,11 @@ void LinkSampling::save_model() {                          // src/linksampling.c
     g.swap(t);
   }
   const std::vector<uint32_t> &s2i = network_.seq2id();
-  write_rows(Env::file_str("/gamma.txt"), "gamma", n_, k_, 10, [&](uint32_t i, std::string &o) {     // "%d\t%d\t" then "%.5f\t" ... "%.5f\n"
-    append_int(o, (long)(int)i, '\t');
-    append_int(o, (long)(int)s2i[i], '\t');
+  write_rows(Env::file_str("/gamma.txt"), "gamma", n_, k_, 10, [&](uint32_t i, RowOut &o) {     // "%d\t%d\t" then "%.5f\t" ... "%.5f\n"
+    o.integer((long)(int)i, '\t');
+    o.integer((long)(int)s2i[i], '\t');
     const double *row = &g[(size_t)i * k_];
-    for (uint32_t k = 0; k < k_; ++k) append_fixed<5>(o, row[k], k == k_ - 1 ? '\n' : '\t');   // %.5f, byte for byte (fixedfmt.hh)
+    for (uint32_t k = 0; k < k_; ++k) o.fixed<5>(row[k], k == k_ - 1 ? '\n' : '\t');   // %.5f, byte for byte (fixedfmt.hh)
   });
   FILE *lf = open_or_die(Env::file_str("/lambda.txt"), "lambda");
   for (uint32_t k = 0; k < k_; ++k) fprintf(lf, "%d\t%.5f\t%.5f\n", k, l[2 * k], l[2 * k + 1]);
@@ -917,13 +913,13 @@ void LinkSampling::fetch_communities_ksharded() {
 
 void LinkSampling::write_groups() {                        // src/linksampling.cc:1452-1476
   const std::vector<uint32_t> &s2i = network_.seq2id();
-  write_rows(Env::file_str("/groups.txt"), "groups", n_, k_, 6, [&](uint32_t i, std::string &o) {
+  write_rows(Env::file_str("/groups.txt"), "groups", n_, k_, 6, [&](uint32_t i, RowOut &o) {
     const double *g = &gamma_[(size_t)i * k_];
     double s = .0;
     for (uint32_t k = 0; k < k_; ++k) s += g[k];
-    append_int(o, (long)(int)i, '\t');
-    append_int(o, (long)(int)s2i[i], '\t');
-    for (uint32_t k = 0; k < k_; ++k) append_fixed<3>(o, g[k] / s, k == k_ - 1 ? '\n' : '\t');   // %.3f
+    o.integer((long)(int)i, '\t');
+    o.integer((long)(int)s2i[i], '\t');
+    for (uint32_t k = 0; k < k_; ++k) o.fixed<3>(g[k] / s, k == k_ - 1 ? '\n' : '\t');   // %.3f
   });
 }
 

@@ -20,6 +20,7 @@ int main(int argc, char **argv) {
     });
     for (auto &x : th) x.join();
   }
+  for (int mode = 0; mode < 2; ++mode)
   for (unsigned T : {1u, 4u, 8u, 16u, 32u}) {
     const uint32_t B = (uint32_t)(((size_t)8 << 20) / ((size_t)k * 10 + 24));
     std::vector<std::string> buf[2] = {std::vector<std::string>(T), std::vector<std::string>(T)};
@@ -35,9 +36,17 @@ int main(int argc, char **argv) {
         o.clear();
         const uint32_t b = (uint32_t)std::min<uint64_t>(n, (uint64_t)base + (uint64_t)t * B), e = (uint32_t)std::min<uint64_t>(n, (uint64_t)b + B);
         if (e > b && o.capacity() == 0) o.reserve((size_t)(e - b) * ((size_t)k * 10 + 24));
-        for (uint32_t i = b; i < e; ++i) {
-          const double *row = &g[(size_t)i * k];
-          for (uint32_t c = 0; c < k; ++c) svinet::append_fixed<5>(o, row[c], c == k - 1 ? '\n' : '\t');
+        if (mode == 0) {
+          for (uint32_t i = b; i < e; ++i) {
+            const double *row = &g[(size_t)i * k];
+            for (uint32_t c = 0; c < k; ++c) svinet::append_fixed<5>(o, row[c], c == k - 1 ? '\n' : '\t');
+          }
+        } else {
+          svinet::RowOut out(o);
+          for (uint32_t i = b; i < e; ++i) {
+            const double *row = &g[(size_t)i * k];
+            for (uint32_t c = 0; c < k; ++c) out.fixed<5>(row[c], c == k - 1 ? '\n' : '\t');
+          }
         }
       });
       for (auto &x : th) x.join();
@@ -45,8 +54,8 @@ int main(int argc, char **argv) {
       if (wave == 1) first2 = now() - t0;
     }
     const double s = now() - t0;
-    printf("T=%2u: %.2f s for %.0f M numbers = %.1f ns per number per thread, %.2f GB/s of text (first two waves %.2f s: page faults of the buffers)\n",
-           T, s, (double)n * k / 1e6, s * T / ((double)n * k) * 1e9, bytes / s / 1e9, first2);
+    printf("%s T=%2u: %.2f s for %.0f M numbers = %.1f ns per number per thread, %.2f GB/s of text (first two waves %.2f s: page faults of the buffers)\n",
+           mode ? "RowOut (scratch per thread)  " : "append to the block's string", T, s, (double)n * k / 1e6, s * T / ((double)n * k) * 1e9, bytes / s / 1e9, first2);
   }
   return 0;
 }
