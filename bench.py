@@ -792,7 +792,7 @@ def main():
         runner.sweep(nev)
         eng.synchronize()
         if rank == 0:
-            exch = (eng.timing()["exchange"][0], nev)
+            exch = (eng.timing()["exchange"][0], nev, eng.timing()["exchange"][1])
             same_window = _phi_record(eng, k, "the %d sweeps after the timed region (sweeps %d..%d), this rank's node block"
                                       % (nev, args.warmup + args.steps, args.warmup + args.steps + nev))
         eng.enable_timing(0, 1)
@@ -834,10 +834,11 @@ def main():
             "config": {"workload": "%s: n=%d k=%d links/sweep=%d heldout_pairs=%d, sweeps %d..%d of the seeded run"
                                    % (args.workload, n, k, L, V, args.warmup, args.warmup + args.steps),
                        "parallelism": ("one chain, node blocks balanced by work x%d: per sweep ONE grouped launch {all-reduce of sum[k] (K doubles), "
-                                       "all-gather of the unscaled new rows (n*ld*8 B, slices padded to the largest block; above 128 MB in chunks on "
-                                       "a stream of their own, each expanded while the next travels)} and one all-reduce of s1,s2,s3 (3K doubles) -- two "
-                                       "exchange points in both phases of the run, flags recomputed not exchanged -- issued by the device library "
-                                       "between the phases and replayed with them as hipGraphs (svils_sweep_sharded)" % world) if world > 1 else "single GPU",
+                                       "the unscaled new rows (n*ld*8 B: an all-gather of slices padded to the largest block, or exact-count broadcasts "
+                                       "where the blocks are far from equal; above 128 MB in chunks on a stream of their own, each expanded while the "
+                                       "next travels)} and one all-reduce of s1,s2,s3 (3K doubles) -- two exchange points in both phases of the run; "
+                                       "flags recomputed not exchanged; issued by the device library between the phases and replayed with them as "
+                                       "hipGraphs (svils_sweep_sharded)" % world) if world > 1 else "single GPU",
                        "converged_nodes_at_end": int((conv > 0).sum()),
                        # how the last sweep's links were evaluated (src/linksampling.cc:622-719): full softmax,
                        # active-set path (_iter > 1000 only), O(1) shortcut of links with exactly one converged endpoint
@@ -891,10 +892,10 @@ def main():
         if eager_window is not None:
             out["eager_window"] = eager_window
         if exch is not None:
-            out["exchange"] = {"ms_per_sweep": exch[0] / exch[1],
-                               "note": "hipEvent time of the RCCL collectives on the engine stream (2 event brackets per sweep: rows + sum, "
-                                       "s1/s2/s3), measured in the event pass after the timed region (eager launches; the timed region "
-                                       "replays hipGraphs)"}
+            out["exchange"] = {"ms_per_sweep": exch[0] / exch[1], "exchange_points_per_sweep": exch[2] / exch[1],
+                               "note": "hipEvent time of the RCCL collectives on the engine stream, measured in the event pass after the "
+                                       "timed region (eager launches; the timed region replays hipGraphs).  Two exchange points per sweep: "
+                                       "{rows + sum[k]} and {s1,s2,s3}"}
             out["load_balance"] = runner.balance
         if not multi and n * k * 8 < 256e6:
             try:
