@@ -992,6 +992,8 @@ def main():
                 s2, p2, _, n2, k2, _ = _load_workload(wl)
                 r2 = cls(s2, rank, world, local_rank, dist)
                 r2.sweep(3)
+                if cls is not _ShardedSteps:
+                    r2.sweep(wsteps)    # rehearsal: the hipGraphs of this many sweeps (either layout) are captured here, not in the timed region
                 el2 = _timed(r2, r2.eng, wsteps, dist, torch)
                 r2.eng.enable_timing((1 << _svils.KERNEL_PHI) | (1 << _svils.KERNEL_EXCHANGE), 1)
                 nev2 = min(10, wsteps)
@@ -1007,6 +1009,20 @@ def main():
                                    "row_communicator": r2.eng.comm_query()["row_communicator"]}
                     if hasattr(r2, "balance"):
                         extra[name]["csr_entries_max_over_mean"] = r2.balance["max_over_mean"]
+                    if cls is not _ShardedSteps:
+                        # the same sweeps on rank 0's GPU alone (plain engine, hipGraph replay): what one GPU of THIS box does with
+                        # this workload -- the other ranks wait at the barrier below
+                        try:
+                            e1 = s2.engine(use_validation_stop=False, device=local_rank)
+                            e1.sweep(3)
+                            e1.sweep(wsteps)
+                            t1 = _timed(e1, e1, wsteps, None, torch)
+                            e1.close()
+                            extra[name]["n1_same_box_ms_per_step"] = t1 / wsteps * 1e3
+                            extra[name]["speedup_vs_n1_same_box"] = t1 / el2
+                        except Exception as exc1:   # (the barrier below must be reached whatever happens here)
+                            extra[name]["n1_same_box_error"] = repr(exc1)[:200]
+                dist.barrier()
                 r2.eng.close()
                 s2.close()
                 if p2:
