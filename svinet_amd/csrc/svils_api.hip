@@ -1668,6 +1668,11 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
   uint64_t lpl_max_entries = 1ull << 27;
   if (const char *e = getenv("SVILS_LPL_MAX_ENTRIES")) lpl_max_entries = std::min<uint64_t>(lpl_max_entries, strtoull(e, nullptr, 10));
   d.lpl = (use_lpl(g.K) && !d.ksh && 2 * nlinks < lpl_max_entries) ? 1 : 0;
+  {
+    const size_t state_bytes = (size_t)g.n_alloc * g.ld * sizeof(double);
+    d.wt = (d.lpl && state_bytes >= ((size_t)1 << 20) && state_bytes <= ((size_t)8 << 20)) ? 1 : 0;    // svils_internal.h: DeviceState::wt
+    if (const char *e = getenv("SVILS_WT")) d.wt = (d.lpl && atoi(e) != 0) ? 1 : 0;                    // A/B knob
+  }
   d.nlinks = nlinks;
   d.ent_begin = rowptr[g.node_begin];
   d.ent_end = rowptr[g.node_end];

@@ -139,6 +139,14 @@ struct DeviceState {
   // chunked broadcasts) fills the other slices, k_expand_all turns every row into gamma / Elogpi / flags
   double *gstage, *gown;
   int light;            // 1: this launch of the finalise pass is the light one
+  // Lane-per-link layout: the row stores of the finalise pass and the piece stores of the phi pass go out write-through
+  // (agent-scope relaxed atomic stores = `global_store_dwordx2 ... sc1`) when the n-by-k state is between 1 and 8 MB:
+  // what a launch leaves DIRTY in the XCD L2s is written back at its end before the next launch may read it from
+  // another XCD (~0.6 us per MB); written through, the lines are clean by then.  Measured per sweep, one box, three
+  // alternating repetitions (profiles/r05r_ab_write_through_gated.txt): ca-AstroPh K=8 / 20 / 32 (1.1 / 2.9 / 4.6 MB per
+  // array) -3.3 / -3.3 / -3.0 %; LFR K=28 (0.2 MB) +0.4 %; n=1e5 K=20 (16 MB) +0.3 %, n=4e5 K=20 (64 MB) +1.1 %: hence
+  // the two bounds.  Same values stored either way: results are bit-identical.
+  int wt;
   int shard_c;          // 1 (node-block sweeps, K <= 32): the last s3 block materialises this rank's s3 in kvec_c (no k_colreduce)
   double *gacc;         // where the phi pass accumulates gammanext: == gamma for full sweeps, a separate
                         // [n_alloc][ld] buffer in mini-batch mode (the old gamma row is blended in)

@@ -28,6 +28,12 @@
 
 namespace svils {
 
+// a row element to global memory, write-through when DeviceState::wt says so (uniform per launch)
+__device__ __forceinline__ void row_store(double *p, double v, bool wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
 // LDS row stride in doubles: an odd number of 16-byte chunks, so the 8-lane groups
 // of ds_write_b128 hit distinct slots
 template <int KC>
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ?
       if ((vmask >> a) & 1ull) {                                                            \
         const uint32_t cur = __builtin_amdgcn_readlane(p, a);                               \
         double *dst = (DST);                                                                \
-        dst[lane] = acc;                                                                    \
+        row_store(&dst[lane], acc, d.wt != 0);                                              \
         csum += acc;                                                                        \
         if (any_tag) {                                                                      \
           const unsigned long long runmask = (((B) >= 63) ? ~0ull : ((2ull << (B)) - 1ull)) & ~((1ull << a) - 1ull); \
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
           if (kv[j]) gn[j] = (1.0 - rho) * gold[j] + rho * gn[j];
           if (kv[j] && ok) { s1[j] -= sold[j]; s2[j] -= sold[j] * sold[j]; }
         }
-        if ((STOCH || !d.derive_m) && ST(j)) d.mphi[rowoff + j * FW] = m[j];
+        if ((STOCH || !d.derive_m) && ST(j)) row_store(&d.mphi[rowoff + j * FW], m[j], d.wt != 0);
       }
     } else {
       // no training link: gammanext stays alpha, mphi row stays stale (:532-533)
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     double rsl = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      if (ST(j)) d.gamma[rowoff + j * FW] = gn[j];   // padding columns stay 0
+      if (ST(j)) row_store(&d.gamma[rowoff + j * FW], gn[j], d.wt != 0);   // padding columns stay 0
       rsl += gn[j];
     }
     const double rs = group_sum<FW>(rsl);
@@ -852,7 +858,7 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
     unsigned long long bits = 0ull;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      if (ST(j)) d.elogpi[rowoff + j * FW] = kv[j] ? ps[j] - psi_rs : 0.0;
+      if (ST(j)) row_store(&d.elogpi[rowoff + j * FW], kv[j] ? ps[j] - psi_rs : 0.0, d.wt != 0);
       // prune / check_and_set_converged, src/linksampling.cc:455-475
       bits |= ((__ballot(kv[j] && (gn[j] - prm.alpha >= 1.0)) >> (g * FW)) & group_mask<FW>()) << (j * FW);
     }
