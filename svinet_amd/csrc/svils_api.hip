@@ -1971,6 +1971,9 @@ hipGraphExec_t capture_sweeps(svils_handle *h, uint32_t nsweeps) {
   if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
   if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
   (void)hipGraphDestroy(graph);
+  // the first launch of an executable graph otherwise pays for its upload (measured in the drop-in binary's trace: 130 - 250 us
+  // in front of the first chunk of every size): done here, where svils_prepare_graphs has the caller still in its set-up
+  if (exec && hipGraphUpload(exec, h->stream) != hipSuccess) (void)hipGetLastError();
   return exec;
 }
 
@@ -2364,6 +2367,19 @@ void ctrl_out(const DevCtrl &c, svils_control *out) {
 }
 }  // namespace
 
+namespace {
+// wait for a report's event: polled for a while (the caller is a host thread that has nothing else to do and the report is
+// usually microseconds away; a blocking wait costs a wake-up of tens of microseconds), then the blocking form
+hipError_t wait_landed(hipEvent_t ev) {
+  for (int i = 0; i < 20000; ++i) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+  }
+  return hipEventSynchronize(ev);
+}
+}  // namespace
+
 int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count, int with_communities, int *ticket) {
   NOT_TILED(h, "svils_report_enqueue");
   if (!h || !ticket) return fail(SVILS_ERR_ARG, "svils_report_enqueue: null argument");
@@ -2393,13 +2409,23 @@ int svils_report_enqueue(svils_handle *h, uint32_t row_first, uint32_t row_count
     HIPCHK(hipEventCreateWithFlags(&rs.packed, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&rs.landed, hipEventDisableTiming));
   }
+  // A small snapshot (up to 1 MB: ca-AstroPh's is 143 KB) is packed straight into the pinned host slot -- the pack launch's
+  // stores cross PCIe themselves and the report has landed when that launch has: no second stream, no event hand-over, no
+  // SDMA start-up (together ~200 us per report in the drop-in binary's trace, which is what its short default run is made
+  // of).  Large ones (config 5: a 64 MB bitmask) keep the device staging + copy stream: the sweeps go on while the copy runs.
+  const size_t rbytes = with_communities ? h->rlay.bytes : h->rlay.off_member;
+  const bool direct = rbytes <= ((size_t)1 << 20) && !getenv("SVILS_REPORT_STAGED");
   launch_report_pack(h->d.ctrl, sizeof(DevCtrl), h->d.rows, h->nt ? h->t_rows : nullptr, h->d.rows_cap, row_first, row_count,
-                     with_communities ? h->d.member : nullptr, with_communities ? nwords : 0, rs.dev, h->rlay, h->stream);
+                     with_communities ? h->d.member : nullptr, with_communities ? nwords : 0, direct ? rs.host : rs.dev, h->rlay, h->stream);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(rs.packed, h->stream));
-  HIPCHK(hipStreamWaitEvent(h->copy_stream, rs.packed, 0));
-  HIPCHK(hipMemcpyAsync(rs.host, rs.dev, with_communities ? h->rlay.bytes : h->rlay.off_member, hipMemcpyDeviceToHost, h->copy_stream));
-  HIPCHK(hipEventRecord(rs.landed, h->copy_stream));
+  if (direct) {
+    HIPCHK(hipEventRecord(rs.landed, h->stream));
+  } else {
+    HIPCHK(hipEventRecord(rs.packed, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, rs.packed, 0));
+    HIPCHK(hipMemcpyAsync(rs.host, rs.dev, rbytes, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipEventRecord(rs.landed, h->copy_stream));
+  }
   rs.busy = true;
   rs.with_member = with_communities != 0;
   rs.row_first = row_first;
@@ -2422,7 +2448,7 @@ int svils_report_test_rows(svils_handle *h, int ticket, double *test_rows, uint3
   if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_test_rows: bad ticket");
   if (!h->nt) return fail(SVILS_ERR_ARG, "svils_report_test_rows: the handle has no test set (svils_set_test)");
   svils_handle::ReportSlot &rs = h->rslot[ticket];
-  HIPCHK(hipEventSynchronize(rs.landed));
+  HIPCHK(wait_landed(rs.landed));
   DevCtrl c;
   memcpy(&c, rs.host, sizeof c);
   if (c.fault) return fault_error(c.fault);
@@ -2493,7 +2519,7 @@ int svils_report_fetch(svils_handle *h, int ticket, svils_control *ctrl, double 
   if (!h || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_fetch: bad ticket");
   svils_handle::ReportSlot &rs = h->rslot[ticket];
   if (member && !rs.with_member) return fail(SVILS_ERR_ARG, "svils_report_fetch: this report was enqueued without communities");
-  HIPCHK(hipEventSynchronize(rs.landed));
+  HIPCHK(wait_landed(rs.landed));
   rs.busy = false;
   DevCtrl c;
   memcpy(&c, rs.host, sizeof c);
@@ -2546,7 +2572,7 @@ int svils_report_tag_count(svils_handle *h, int ticket, uint64_t *ntags) {
   if (!h || !ntags || ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_tag_count: bad ticket");
   svils_handle::ReportSlot &rs = h->rslot[ticket];
   if (!rs.with_member) return fail(SVILS_ERR_ARG, "svils_report_tag_count: this report was enqueued without communities");
-  HIPCHK(hipEventSynchronize(rs.landed));
+  HIPCHK(wait_landed(rs.landed));
   *ntags = tags_of_bits(h->geo, (const uint64_t *)(rs.host + h->rlay.off_member), nullptr, 0);
   return 0;
 }
@@ -2557,7 +2583,7 @@ int svils_report_fetch_tags(svils_handle *h, int ticket, svils_control *ctrl, do
   if (!h || !ntags || (!tags && cap)) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: null argument");
   if (ticket < 0 || ticket >= SVILS_REPORT_SLOTS || !h->rslot[ticket].busy) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: bad ticket");
   if (!h->rslot[ticket].with_member) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: this report was enqueued without communities");
-  HIPCHK(hipEventSynchronize(h->rslot[ticket].landed));
+  HIPCHK(wait_landed(h->rslot[ticket].landed));
   const uint64_t cnt = tags_of_bits(h->geo, (const uint64_t *)(h->rslot[ticket].host + h->rlay.off_member), tags, cap);
   *ntags = cnt;
   if (cnt > cap) return fail(SVILS_ERR_ARG, "svils_report_fetch_tags: %llu tags, room for %llu (svils_report_tag_count says how many); the slot is kept",
