@@ -558,8 +558,14 @@ def _spawn_ranks(n):
             live.discard(r)
             if code != 0 and rc == 0:
                 rc = code
-                sys.stderr.write("bench.py: rank %d exited with %d; ending the other ranks\n" % (r, code))
-                for q in sorted(live):
+                # the others usually leave by themselves for the same reason (and say why): a few seconds for that, then the end
+                t_end = time.time() + 5.0
+                while time.time() < t_end and any(procs[q].poll() is None for q in live):
+                    time.sleep(0.05)
+                still = [q for q in sorted(live) if procs[q].poll() is None]
+                if still:
+                    sys.stderr.write("bench.py: rank %d exited with %d; ending the other ranks\n" % (r, code))
+                for q in still:
                     procs[q].terminate()
         time.sleep(0.05)
     return rc
