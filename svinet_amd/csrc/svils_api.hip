@@ -855,7 +855,9 @@ int exchange_rows_and_expand(svils_handle *h) {
       // puts the hubs first (ca-AstroPh on 8 ranks: 574 ... 6 775 nodes, world * bmax = 3.0 n): beyond 1.5 n the rows go
       // as `world` in-place broadcasts with the exact counts in the same grouped launch (the form of the chunked
       // exchange below) -- n rows on the links instead of world * bmax.
-      const bool padded = (uint64_t)b.bmax * b.world * 2 <= 3 * (uint64_t)g.n || getenv("SVILS_ALLGATHER_ROWS");
+      // (SVILS_ALLGATHER_ROWS / SVILS_EXACT_ROWS force one form: A/B on real links, and the tests' way to put the grouped
+      //  {all-reduce, broadcasts} launch through the real librccl on a world of one)
+      const bool padded = !getenv("SVILS_EXACT_ROWS") && ((uint64_t)b.bmax * b.world * 2 <= 3 * (uint64_t)g.n || getenv("SVILS_ALLGATHER_ROWS"));
       NCCLCHK(g_rccl.GroupStart());
       NCCLCHK(g_rccl.AllReduce(d.kvec_a, d.kvec_a, g.K, ncclDouble, ncclSum, h->comm, h->stream));
       if (padded) {

@@ -61,6 +61,39 @@ def test_pipelined_row_exchange_second_communicator_and_graphs(graph_files, monk
         eng.close()
 
 
+@pytest.mark.parametrize("key,n,k,sweeps", [("lfr", 1000, 28, 40), ("astroph", 17903, 200, 6)])
+def test_grouped_allreduce_and_exact_count_broadcasts(graph_files, monkeypatch, key, n, k, sweeps):
+    """the row exchange of work-balanced blocks that are far from equal: ONE grouped launch of {all-reduce of sum[k], an
+    in-place broadcast per block with its exact row count} (SVILS_EXACT_ROWS forces that form on the single block of a world
+    of one) -- accepted by the real librccl eagerly and under hipGraph capture, equal to the plain engine"""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    monkeypatch.setenv("SVILS_EXACT_ROWS", "1")
+    setup = Setup(graph_files[key], n, k)
+    plain = setup.engine(use_validation_stop=False)
+    plain.sweep(sweeps)
+    first = None
+    for timed in (True, False):       # eager (timing brackets keep it so) / graph replay
+        eng = setup.engine(use_validation_stop=False, node_block=(0, n))
+        eng.comm_init(_svils.comm_unique_id(), 0, 1)
+        if timed:
+            eng.enable_timing(1 << _svils.KERNEL_EXCHANGE)
+        eng.sweep_sharded(sweeps)
+        eng.synchronize()
+        _real_rccl(eng)
+        a, b = eng.state(), plain.state()
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-10)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-10)
+        assert np.array_equal(a[2], b[2])
+        np.testing.assert_allclose(eng.rows(), plain.rows(), rtol=1e-10)
+        if timed:
+            assert eng.timing()["exchange"][1] == 2 * sweeps
+            first = a
+        else:
+            assert np.array_equal(a[0], first[0]) and np.array_equal(a[1], first[1])     # replay == eager, bit for bit
+        eng.close()
+
+
 @pytest.mark.parametrize("mode", ["sum", "log", "lowt"])
 def test_ksharded_reductions(graph_files, mode):
     """svils_sweep_ksharded's all-reduces with the real library: SUM (product form), + MAX (log-domain denominators),
