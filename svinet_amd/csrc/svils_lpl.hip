@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256) void k_validate_lpl(Geometry geo, DeviceState 
 #ifndef LPL_MID_OCC
 #define LPL_MID_OCC 2
 #endif
+// K = 21..24 (KC = 12) takes the same shape since round 5: as an 8-wave block it sat on the 128-register cap and spilled 24
+// VGPRs (profiles/r06a_ab_kc12.txt: ca-AstroPh K=22 phi 35.0 -> 29.1 us, K=24 31.7 -> 28.7)
 #ifndef LPL_MID_KC   // smallest KC that takes the LPL_MID_* shape
-#define LPL_MID_KC 14
+#define LPL_MID_KC 12
 #endif
 template <int KC, int NW, bool PIPE>
 __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ? LPL_MID_OCC : 4)) void k_phi_lpl(Geometry geo, DeviceState d, Params prm) {
@@ -910,7 +912,12 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
 // the scatter pass follows on the tail launch.
 // threads per block of k_s3_lpl: up to K = 20 the KR accumulators fit the 128 registers of a 16-wave
 // block; beyond that 8 waves (two per SIMD) share the register file
-constexpr int s3_threads(int kc) { return kc >= 12 ? 512 : 1024; }
+// ... except KC = 12 (K = 21..24): its 168 registers fit THREE waves per SIMD, i.e. 12-wave blocks (768 threads; one block
+// per CU either way: the launch is kept co-resident) -- 1.3 links per lane instead of 2 at 2 waves per SIMD
+#ifndef LPL_S3_KC12_THREADS
+#define LPL_S3_KC12_THREADS 768
+#endif
+constexpr int s3_threads(int kc) { return kc > 12 ? 512 : kc == 12 ? LPL_S3_KC12_THREADS : 1024; }
 
 template <int KC>
 __global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
@@ -1281,7 +1288,7 @@ void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, h
   hipLaunchKernelGGL(k_cls_count, dim3(nb), dim3(1024), 0, s, g, d, p);
   hipLaunchKernelGGL(k_cls_scatter, dim3(nb), dim3(1024), 0, s, g, d);
 }
-uint32_t lpl_s3_threads(uint32_t K) { return K > 20 ? 512u : 1024u; }
+uint32_t lpl_s3_threads(uint32_t K) { return K > 24 ? 512u : K > 20 ? (uint32_t)LPL_S3_KC12_THREADS : 1024u; }
 // validation-role blocks: two pairs per group and pass, at most 64 blocks (the last one adds the
 // partials serially)
 uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K) {
