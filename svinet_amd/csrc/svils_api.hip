@@ -1712,7 +1712,7 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     const uint32_t fnodes = lpl_finalize_waves(g.K) * (64u / (uint32_t)lpl_finalize_group(g.K));
     d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fnodes - 1) / fnodes,
                  std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_finalize_resident_blocks(g.K, h->cfg.device)));
-    d.s3_threads = lpl_s3_threads(g.K);
+    d.s3_threads = lpl_s3_threads(g.K, d.link_end - d.link_begin);
     d.nb_c = cap((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, 192);   // + up to 64 classification blocks
   }
 

@@ -263,7 +263,7 @@ uint32_t tail_blocks(const Geometry &g, uint32_t nv);
 uint32_t lpl_cls_blocks(const DeviceState &d);
 void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K);
-uint32_t lpl_s3_threads(uint32_t K);
+uint32_t lpl_s3_threads(uint32_t K, uint64_t nlinks);   // threads per block of the s3 launch for this many links
 uint32_t lpl_finalize_waves(uint32_t K);
 int lpl_finalize_group(uint32_t K);
 uint32_t lpl_finalize_resident_blocks(uint32_t K, int device);

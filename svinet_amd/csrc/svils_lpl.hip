@@ -912,18 +912,18 @@ __global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize
 // the scatter pass follows on the tail launch.
 // threads per block of k_s3_lpl: up to K = 20 the KR accumulators fit the 128 registers of a 16-wave
 // block; beyond that 8 waves (two per SIMD) share the register file
-// ... except KC = 12 (K = 21..24): its 168 registers fit THREE waves per SIMD, i.e. 12-wave blocks (768 threads; one block
-// per CU either way: the launch is kept co-resident) -- 1.3 links per lane instead of 2 at 2 waves per SIMD
-#ifndef LPL_S3_KC12_THREADS
-#define LPL_S3_KC12_THREADS 768
-#endif
-constexpr int s3_threads(int kc) { return kc > 12 ? 512 : kc == 12 ? LPL_S3_KC12_THREADS : 1024; }
+// ... K = 21..32 (KC = 12, 14, 16) have a second shape, 12-wave blocks (768 threads, 168 VGPRs = three waves per SIMD; one block per
+// CU either way: the launch is kept co-resident).  KC = 12 fits it without a spill, KC = 14 / 16 spill 8 / 44 VGPRs there.  It pays
+// where the 8-wave shape needs two links per lane, i.e. beyond 192 x 512 links, and costs a small graph 1.5 - 3 us otherwise:
+// ca-AstroPh K=22 s3 28.8 -> 21.4 us, K=28 29.2 -> 22.9, K=32 29.6 -> 26.0; LFR K=28 13.7 -> 16.7, n=1000 K=24 13.4 -> 15.0
+// (profiles/r06a_*, r06b_*, r06c_*) -- lpl_s3_threads decides by the link count.
+constexpr int s3_threads(int kc) { return kc >= 12 ? 512 : 1024; }
 
-template <int KC>
-__global__ __launch_bounds__(s3_threads(KC)) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
+template <int KC, int NTH = s3_threads(KC)>
+__global__ __launch_bounds__(NTH) void k_s3_lpl(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   constexpr int KR = LplCfg<KC>::KR, SROW = LplCfg<KC>::SROW;
-  constexpr int NTH = s3_threads(KC), NWV = NTH / 64, NWORK = NTH / 256;
+  constexpr int NWV = NTH / 64, NWORK = NTH / 256;
   constexpr bool PEEL = KC >= 12 && KC <= 20;   // see below
   if constexpr (!PEEL) {
     if (ctrl->stopped) return;   // (the instantiations without the first-link form keep the order of accesses they had)
@@ -1288,7 +1288,10 @@ void launch_classify(const Geometry &g, const DeviceState &d, const Params &p, h
   hipLaunchKernelGGL(k_cls_count, dim3(nb), dim3(1024), 0, s, g, d, p);
   hipLaunchKernelGGL(k_cls_scatter, dim3(nb), dim3(1024), 0, s, g, d);
 }
-uint32_t lpl_s3_threads(uint32_t K) { return K > 24 ? 512u : K > 20 ? (uint32_t)LPL_S3_KC12_THREADS : 1024u; }
+uint32_t lpl_s3_threads(uint32_t K, uint64_t nlinks) {
+  if (K <= 20) return 1024u;
+  return (K <= 32 && nlinks > 192ull * 512ull) ? 768u : 512u;   // (see s3_threads)
+}
 // validation-role blocks: two pairs per group and pass, at most 64 blocks (the last one adds the
 // partials serially)
 uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K) {
@@ -1377,7 +1380,14 @@ uint32_t lpl_s3_resident_blocks(uint32_t K, int device) {
   return (uint32_t)per_cu * (uint32_t)cus;
 }
 void launch_s3_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
-#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), dim3(d.nb_c + lpl_cls_blocks(d) + (d.fused3 ? 1u : 0u)), dim3(s3_threads(KC_)), 0, s, g, d, p)
+  const dim3 grid(d.nb_c + lpl_cls_blocks(d) + (d.fused3 ? 1u : 0u));
+  if (d.s3_threads == 768u && g.K > 20 && g.K <= 32) {   // the 12-wave shape of KC = 12 / 14 / 16 (lpl_s3_threads)
+    if (g.K <= 24) hipLaunchKernelGGL((k_s3_lpl<12, 768>), grid, dim3(768), 0, s, g, d, p);
+    else if (g.K <= 28) hipLaunchKernelGGL((k_s3_lpl<14, 768>), grid, dim3(768), 0, s, g, d, p);
+    else hipLaunchKernelGGL((k_s3_lpl<16, 768>), grid, dim3(768), 0, s, g, d, p);
+    return;
+  }
+#define CALL(KC_) hipLaunchKernelGGL((k_s3_lpl<KC_>), grid, dim3(s3_threads(KC_)), 0, s, g, d, p)
   LPL_DISPATCH(g.K, CALL);
 #undef CALL
 }
