@@ -111,7 +111,9 @@ def test_lfr_stop_rule(graph_files):
     assert np.array_equal(eng.communities(), ref.communities())
 
 
-@pytest.mark.parametrize("k,sweeps", [(20, 6), (20, 31), (200, 4), (64, 4), (100, 3)])
+@pytest.mark.parametrize("k,sweeps", [(20, 6), (20, 31), (200, 4), (64, 4), (100, 3),
+                                      # K = 21..32 on a graph of more than 192 x 512 links: the 12-wave s3 shape (k_s3_lpl<12 / 14 / 16, 768>)
+                                      (24, 4), (28, 3), (32, 3)])
 def test_astroph(graph_files, k, sweeps):
     """configs 3 and 4: ca-AstroPh n=17903, k=20 / k=200 (max degree 504 => split rows)."""
     net = O.Network(graph_files["astroph"], 17903)
