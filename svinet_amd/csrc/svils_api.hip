@@ -1709,7 +1709,12 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     d.nb_a = cap((phi_items + nw - 1) / nw, std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_phi_resident_blocks(g.K, h->cfg.device)));
     // finalise pass: 12-wave blocks of 64 / lpl_finalize_group(K) nodes per wavefront, as many as the device holds at
     // once (one per CU at its register budget); larger graphs loop inside the blocks
-    const uint32_t fnodes = lpl_finalize_waves(g.K) * (64u / (uint32_t)lpl_finalize_group(g.K));
+    {
+      int cus = 0;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+      d.fin_waves = lpl_finalize_waves(g.K, g.node_end - g.node_begin, cus > 0 ? (uint32_t)cus : 256u);
+    }
+    const uint32_t fnodes = d.fin_waves * (64u / (uint32_t)lpl_finalize_group(g.K));
     d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + fnodes - 1) / fnodes,
                  std::min<uint32_t>(SVILS_FOLD_ROWS, lpl_finalize_resident_blocks(g.K, h->cfg.device)));
     d.s3_threads = lpl_s3_threads(g.K, d.link_end - d.link_begin);
@@ -2236,7 +2241,7 @@ int open_step(svils_handle *h) {
       const int nw = lpl_phi_waves(g.K);
       const uint64_t items = ((d.ent_end - d.ent_begin + 63) >> 6) + 1;
       d.nb_a = fit((items + nw - 1) / nw, h->d.nb_a);
-      const uint32_t fnodes = lpl_finalize_waves(g.K) * (64u / (uint32_t)lpl_finalize_group(g.K));
+      const uint32_t fnodes = d.fin_waves * (64u / (uint32_t)lpl_finalize_group(g.K));
       d.nb_b = fit(((uint64_t)(e - b) + fnodes - 1) / fnodes, h->d.nb_b);
       d.nb_c = fit((d.link_end - d.link_begin + d.s3_threads - 1) / d.s3_threads, h->d.nb_c);
     } else {

@@ -147,6 +147,7 @@ struct DeviceState {
   // array) -3.3 / -3.3 / -3.0 %; LFR K=28 (0.2 MB) +0.4 %; n=1e5 K=20 (16 MB) +0.3 %, n=4e5 K=20 (64 MB) +1.1 %: hence
   // the two bounds.  Same values stored either way: results are bit-identical.
   int wt;
+  uint32_t fin_waves;   // lane-per-link finalise launch: waves per block (lpl_finalize_waves: 12 selects the 768-thread variant at NC = 4)
   int shard_c;          // 1 (node-block sweeps, K <= 32): the last s3 block materialises this rank's s3 in kvec_c (no k_colreduce)
   double *gacc;         // where the phi pass accumulates gammanext: == gamma for full sweeps, a separate
                         // [n_alloc][ld] buffer in mini-batch mode (the old gamma row is blended in)
@@ -264,7 +265,7 @@ uint32_t lpl_cls_blocks(const DeviceState &d);
 void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s);
 uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K);
 uint32_t lpl_s3_threads(uint32_t K, uint64_t nlinks);   // threads per block of the s3 launch for this many links
-uint32_t lpl_finalize_waves(uint32_t K);
+uint32_t lpl_finalize_waves(uint32_t K, uint64_t nodes, uint32_t cus);   // waves per block of the finalise launch (8 or 12)
 int lpl_finalize_group(uint32_t K);
 uint32_t lpl_finalize_resident_blocks(uint32_t K, int device);
 uint32_t lpl_scatter_blocks(const DeviceState &d);

@@ -558,6 +558,10 @@ __device__ __forceinline__ unsigned long long group_mask() { return W == 64 ? ~0
 
 // 12-wave blocks at three waves per SIMD (<= 168 VGPRs); four communities per lane (K = 25..32, 49..56) need a few more
 // than that: 8-wave blocks at two per SIMD
+// ... which is one block per CU of 64 nodes (K <= 32): a graph of more than 64 x CUs nodes then needs a second round of
+// blocks.  The four-community variants therefore ALSO exist as 12-wave blocks (96 nodes; 9 VGPRs spilled): ca-AstroPh
+// (17 903 nodes) K=28 finalise 22.0 -> 18.3 us, K=32 21.7 -> 18.2, K=56 25.6 -> 23.9; on a small graph the spill costs
+// (LFR K=28 13.5 -> 15.3) -- lpl_finalize_waves picks by the node count (profiles/r06e_ab_fin768.txt).
 constexpr int fin_threads(int nc) { return nc >= 4 ? 512 : 768; }
 
 struct FinIdx {
@@ -575,14 +579,14 @@ __device__ __forceinline__ FinIdx fin_load_idx(const DeviceState &d, uint32_t p,
 
 // LIGHT: the node-block form (see k_finalize in svils_device.hip): mean indicators, s1 / s2, tags and the unscaled row into
 // the exchange staging; scale, Elogpi and prune() follow in k_expand_all behind the exchange.
-template <int FW, int NC, bool STOCH, bool LIGHT = false>
-__global__ __launch_bounds__(fin_threads(NC), (NC >= 4 ? 2 : 3)) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
+template <int FW, int NC, bool STOCH, bool LIGHT = false, int NTH = fin_threads(NC)>
+__global__ __launch_bounds__(NTH, (NTH >= 768 ? 3 : 2)) void k_finalize_lpl(Geometry geo, DeviceState d, Params prm) {
   STAMP(1, 0);
   DevCtrl *ctrl = d.ctrl;
   constexpr int G = 64 / FW;
   __shared__ double2 logtab[128];
   __shared__ double ksum[64];
-  constexpr int FIN_WAVES = fin_threads(NC) / 64;
+  constexpr int FIN_WAVES = NTH / 64;
   __shared__ double s12l[FIN_WAVES][FW][2 * NC];
   __shared__ uint32_t shh[FIN_WAVES][G * FW * NC];   // per-group histogram of shortcut columns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1303,7 +1307,13 @@ uint32_t lpl_validation_blocks(const Geometry &g, uint32_t nv, uint32_t K) {
 void launch_validate_lpl(const Geometry &g, const DeviceState &d, const Params &p, hipStream_t s) {
   hipLaunchKernelGGL(k_validate_lpl, dim3(d.nvb ? d.nvb : 1u), dim3(256), 0, s, g, d, p);
 }
-uint32_t lpl_finalize_waves(uint32_t K) { return (uint32_t)fin_threads((K > 24 && K <= 32) || K > 48 ? 4 : 3) / 64u; }
+uint32_t lpl_finalize_waves(uint32_t K, uint64_t nodes, uint32_t cus) {
+  const int nc = (K > 24 && K <= 32) || K > 48 ? 4 : 3;
+  const uint32_t w = (uint32_t)fin_threads(nc) / 64u;
+  // four communities per lane: 12-wave blocks when 8-wave ones would not hold the graph in one round (see fin_threads)
+  if (nc == 4 && nodes > (uint64_t)w * (64u / (uint32_t)lpl_finalize_group(K)) * cus) return 12u;
+  return w;
+}
 // classification blocks riding on the s3 launch (one worker per 256 threads, ideally one tile each)
 uint32_t lpl_cls_blocks(const DeviceState &d) {
   if (!d.cls_next) return 0;
@@ -1360,7 +1370,11 @@ void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &
 #define FIN(W_, NC_)                                                                                \
   do {                                                                                              \
     if (p.stoch) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, true>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p); \
+    else if (d.light && NC_ == 4 && d.fin_waves == 12u)                                             \
+      hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false, true, (NC_ == 4 ? 768 : fin_threads(NC_))>), dim3(d.nb_b), dim3(768), 0, s, g, d, p); \
     else if (d.light) hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false, true>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p); \
+    else if (NC_ == 4 && d.fin_waves == 12u)                                                        \
+      hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false, false, (NC_ == 4 ? 768 : fin_threads(NC_))>), dim3(d.nb_b), dim3(768), 0, s, g, d, p); \
     else hipLaunchKernelGGL((k_finalize_lpl<W_, NC_, false>), dim3(d.nb_b), dim3(fin_threads(NC_)), 0, s, g, d, p);  \
   } while (0)
   FIN_DISPATCH(g.K, FIN);
