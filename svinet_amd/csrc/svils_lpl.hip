@@ -556,13 +556,19 @@ __global__ __launch_bounds__(64 * NW, (PIPE || KC >= 18 ? 2 : KC >= LPL_MID_KC ?
 template <int W>
 __device__ __forceinline__ unsigned long long group_mask() { return W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull); }
 
-// 12-wave blocks at three waves per SIMD (<= 168 VGPRs); four communities per lane (K = 25..32, 49..56) need a few more
+// blocks at three waves per SIMD (<= 168 VGPRs); four communities per lane (K = 25..32, 49..56) need a few more
 // than that: 8-wave blocks at two per SIMD
 // ... which is one block per CU of 64 nodes (K <= 32): a graph of more than 64 x CUs nodes then needs a second round of
 // blocks.  The four-community variants therefore ALSO exist as 12-wave blocks (96 nodes; 9 VGPRs spilled): ca-AstroPh
 // (17 903 nodes) K=28 finalise 22.0 -> 18.3 us, K=32 21.7 -> 18.2, K=56 25.6 -> 23.9; on a small graph the spill costs
 // (LFR K=28 13.5 -> 15.3) -- lpl_finalize_waves picks by the node count (profiles/r06e_ab_fin768.txt).
-constexpr int fin_threads(int nc) { return nc >= 4 ? 512 : 768; }
+// Up to three communities per lane (K <= 24, 33..48): 9-wave blocks (72 nodes at K <= 32): ca-AstroPh's 17 903 nodes then make 249
+// blocks, one per CU in one round on 249 of the 256 CUs; as 12-wave blocks (96 nodes) they made 187 -- the same round on fewer
+// CUs with more waves each (K=20 51.0 -> 50.5 us per sweep, profiles/r06h_ab_fin3.txt; 10 waves: 50.8; LFR unchanged)
+#ifndef LPL_FIN3_THREADS
+#define LPL_FIN3_THREADS 576
+#endif
+constexpr int fin_threads(int nc) { return nc >= 4 ? 512 : LPL_FIN3_THREADS; }
 
 struct FinIdx {
   uint32_t r[3][2];   // npos[l][p], npos[l][p + 1]
