@@ -513,6 +513,50 @@ class _KSharded:
         self.eng.sweep_ksharded(n)
 
 
+# N > 1 side records, in the order they run: (name, workload, timed sweeps, layout).  BASELINE config 5 in the layout built for
+# it comes FIRST -- it is the one configuration the design expects to scale, so it must not sit behind
+# six other records under the global cut-off on the first real node; the two config-5 records share one host set-up (~25 s).
+SIDE_RECORDS = (
+    ("ksharded_config5_mmsb_n1m_k512", "mmsb:1000000:512:24", 5, "kshard"),
+    ("config5_mmsb_n1m_k512", "mmsb:1000000:512:24", 5, "nodeblock"),
+    ("config4_astroph_k200", "astroph-k200", 50, "nodeblock"),
+    ("ksharded_config4_astroph_k200", "astroph-k200", 50, "kshard"),
+    ("hbm_bound_n200k_k512", "synthetic:200000:512:24", 10, "nodeblock"),
+    ("ksharded_hbm_bound_n200k_k512", "synthetic:200000:512:24", 10, "kshard"),
+    # mini-batch steps on the headline graph: 8 windows per node block, 80 steps = 10 passes
+    ("minibatch_steps_astroph_k20", "astroph-k20", 80, "steps"),
+)
+# seconds a record may need on top of the sweeps themselves (host set-up of its workload on every rank at once, graph capture,
+# the one-GPU run beside it): what --extra-timeout scales with
+SIDE_RECORD_BUDGET_S = {"mmsb:1000000:512:24": 150, "synthetic:200000:512:24": 45, "astroph-k200": 25, "astroph-k20": 20}
+
+
+def side_record_plan(extra_list=""):
+    """the records a run will take, in order, and the global cut-off that goes with them"""
+    want = [x for x in extra_list.split(",") if x] if extra_list else None
+    plan = [r for r in SIDE_RECORDS if want is None or r[0] in want]
+    seen, budget = set(), 60
+    for _, wl, _, _ in plan:
+        budget += SIDE_RECORD_BUDGET_S[wl] // (2 if wl in seen else 1)    # a workload already set up costs the sweeps only
+        seen.add(wl)
+    return plan, budget
+
+
+def model_prediction(workload, layout, world):
+    """What tools/shard_cost.py PREDICTS for this record -- per-rank compute measured on ONE GPU + the stated link model --
+    so that the first measured N > 1 number is read against it in the same line.  -> dict or None (no model row)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "shard_cost_model.json")) as f:
+            m = json.load(f)
+        row = m["rows"]["%s|%s|%d" % (workload, layout, world)]
+    except Exception:
+        return None
+    out = dict(row)
+    out["link_model"] = m.get("link_model")
+    out["source"] = m.get("source")
+    return out
+
+
 def _timed(runner, eng, steps, dist, torch):
     """barrier + device sync on both sides of exactly `steps` sweeps; MAX over ranks"""
     eng.synchronize(); torch.cuda.synchronize()
@@ -619,13 +663,17 @@ def main():
     ap.add_argument("--main-timeout", type=int, default=420,
                     help="N>1: seconds the communicator set-up + warm-up + timed sweeps may take before rank 0 prints "
                          "an error line and every rank exits")
-    ap.add_argument("--extra-timeout", type=int, default=480,
-                    help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits")
-    ap.add_argument("--record-timeout", type=int, default=200,
+    ap.add_argument("--extra-timeout", type=int, default=0,
+                    help="N>1: seconds after the main measurement before a watchdog prints the JSON line and exits "
+                         "(0: scaled with the side records requested -- side_record_plan)")
+    ap.add_argument("--record-timeout", type=int, default=0,
                     help="N>1: seconds ONE side record may take; past it the record is marked as hung, the ones behind it as not run, "
                          "the JSON line is printed with everything measured so far and every rank exits (a rank stuck in a collective "
-                         "cannot be brought back)")
+                         "cannot be brought back).  0: 200 s, or twice the record's set-up budget where that is more (config 5: eight "
+                         "concurrent 25 s host set-ups under a 16-core quota)")
     args = ap.parse_args()
+    if args.extra_timeout <= 0:
+        args.extra_timeout = side_record_plan(args.extra_list)[1]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # bare `python bench.py --gpus N`: be the launcher (before anything touches HIP in this process)
@@ -685,7 +733,7 @@ def main():
                         line.update({"value": e["value"], "ms_per_step": e["ms_per_step"], "data": fallback.get("data"),
                                      "config": fallback.get("config"), "eager_window": e,
                                      "error": "the hipGraph-replayed window did not finish within %d s; `value` is the EAGER window of the "
-                                              "same %d sweeps (SVILS_SHARDED_GRAPHS=0), timed before it" % (args.main_timeout, args.steps)})
+                                              "same %d sweeps (option sharded_graphs = 0), timed before it" % (args.main_timeout, args.steps)})
                     print(json.dumps(line), flush=True)
                 sys.stderr.write("bench.py: rank %d left on the main watchdog\n" % rank)
                 sys.stderr.flush()
@@ -716,26 +764,23 @@ def main():
         runner = _Sharded(setup, rank, world, local_rank, dist)
         eng = runner.eng
     eager_window = None
-    sg_env = os.environ.get("SVILS_SHARDED_GRAPHS")
-    if multi and sg_env != "0":
+    graphs_on = eng.get_option("sharded_graphs") != 0
+    if multi and graphs_on:
         # N > 1, first: the SAME window with every launch and collective enqueued one by one (no capture).  RCCL under
         # hipGraph capture has never met more than one rank of this code; if the replayed window below blocks, the main
         # watchdog prints the line with this number instead of nothing.  It also pins replay == eager on the real links.
-        os.environ["SVILS_SHARDED_GRAPHS"] = "0"
+        eng.set_option("sharded_graphs", 0)
         runner.sweep(args.warmup)
         el_e = _timed(runner, eng, args.steps, dist, torch)
         c_e = eng.control()
         lam_e = eng.state()[1].copy()
         eager_window = {"value": L * args.steps / el_e, "unit": "edge-updates/s", "ms_per_step": el_e / args.steps * 1e3,
-                        "what": "the same %d sweeps from the same re-seeded state, launched eagerly (SVILS_SHARDED_GRAPHS=0), "
+                        "what": "the same %d sweeps from the same re-seeded state, launched eagerly (option sharded_graphs = 0), "
                                 "timed before the replayed window" % args.steps}
         fallback.update({"eager": eager_window, "data": data,
                          "config": {"workload": "%s: n=%d k=%d links/sweep=%d, sweeps %d..%d of the seeded run, node blocks x%d"
                                                 % (args.workload, n, k, L, args.warmup, args.warmup + args.steps, world)}})
-        if sg_env is None:
-            del os.environ["SVILS_SHARDED_GRAPHS"]
-        else:
-            os.environ["SVILS_SHARDED_GRAPHS"] = sg_env
+        eng.set_option("sharded_graphs", 1)
         _reseed(eng, setup.gamma, setup.lam)
     runner.sweep(args.warmup)
     period = max(1, min(args.event_period, args.steps // 10))   # >= 10 timed launches whenever steps >= 10
@@ -914,6 +959,12 @@ def main():
                                        "timed region (eager launches; the timed region replays hipGraphs).  Two exchange points per sweep: "
                                        "{rows + sum[k]} and {s1,s2,s3}"}
             out["load_balance"] = runner.balance
+            mp = model_prediction(args.workload, "nodeblock", world)
+            if mp is not None:
+                out["model"] = mp
+                out["model_ms_per_step"] = mp.get("predicted_ms_per_step")
+                if mp.get("predicted_ms_per_step"):
+                    out["measured_over_model"] = out["ms_per_step"] / mp["predicted_ms_per_step"]
         if not multi and n * k * 8 < 256e6:
             try:
                 out["roofline_dense_only"] = dense_only_window(setup, k, local_rank)
@@ -956,20 +1007,20 @@ def main():
             state["emitted"] = True
 
     finished = threading.Event()
-    current = {"name": None, "t0": 0.0, "todo": []}   # the side record in progress (per-record watchdog)
+    current = {"name": None, "t0": 0.0, "todo": [], "limit": args.record_timeout or 200}   # the side record in progress (per-record watchdog)
 
     def watchdog():
         t_start = time.time()
         while not finished.wait(timeout=1.0):
             name = current["name"]
-            hung = name is not None and time.time() - current["t0"] > args.record_timeout
+            hung = name is not None and time.time() - current["t0"] > current["limit"]
             if not hung and time.time() - t_start <= args.extra_timeout:
                 continue
             if rank == 0:
                 ex = out.setdefault("sharded_extra", {})
                 if hung:
                     ex[name] = {"error": "did not finish within %d s (a collective or a kernel of this record blocked); the ranks left"
-                                         % args.record_timeout}
+                                         % current["limit"]}
                     for later in current["todo"]:
                         ex.setdefault(later, {"error": "not run: the record %s before it hung" % name})
                 else:
@@ -988,25 +1039,26 @@ def main():
         extra = {}
         if rank == 0:
             out["sharded_extra"] = extra   # filled as the records complete: the watchdog prints what is there
-        for name, wl, wsteps, cls in (("config4_astroph_k200", "astroph-k200", 50, _Sharded),
-                                      ("hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _Sharded),
-                                      # mini-batch steps on the headline graph: 8 windows per node block, 80 steps = 10 passes
-                                      ("minibatch_steps_astroph_k20", "astroph-k20", 80, _ShardedSteps),
-                                      # the same two workloads with the columns sharded instead of the nodes
-                                      ("ksharded_config4_astroph_k200", "astroph-k200", 50, _KSharded),
-                                      ("ksharded_hbm_bound_n200k_k512", HBM_BOUND_WORKLOAD, 10, _KSharded),
-                                      # BASELINE config 5 at full size (~25 s of host set-up each): the layout built for it, then node blocks
-                                      ("ksharded_config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _KSharded),
-                                      ("config5_mmsb_n1m_k512", CONFIG5_WORKLOAD, 5, _Sharded)):
-            if args.extra_list and name not in args.extra_list.split(","):
-                continue
-            current["todo"] = [x for x in (args.extra_list.split(",") if args.extra_list else []) if x != name and x not in extra]
+        plan, _ = side_record_plan(args.extra_list)
+        setups = {}          # workload -> (setup, path, n, k): the two config-5 records share one host set-up
+        for name, wl, wsteps, layout in plan:
+            cls = {"kshard": _KSharded, "nodeblock": _Sharded, "steps": _ShardedSteps}[layout]
+            current["todo"] = [r[0] for r in plan if r[0] != name and r[0] not in extra]
+            current["limit"] = args.record_timeout or max(200, 2 * SIDE_RECORD_BUDGET_S[wl])
             current["t0"], current["name"] = time.time(), name
             try:
                 if os.environ.get("BENCH_TEST_HANG_RECORD") == name:   # tests only: this record never comes back
                     while True:
                         time.sleep(1.0)
-                s2, p2, _, n2, k2, _ = _load_workload(wl)
+                if wl not in setups:
+                    for old in list(setups):             # one workload resident at a time (4.1 GB of host state at config 5)
+                        so, po = setups.pop(old)[:2]
+                        so.close()
+                        if po:
+                            os.unlink(po)
+                    s2, p2, _, n2, k2, _ = _load_workload(wl)
+                    setups[wl] = (s2, p2, n2, k2)
+                s2, p2, n2, k2 = setups[wl]
                 r2 = cls(s2, rank, world, local_rank, dist)
                 r2.sweep(3)
                 if cls is not _ShardedSteps:
@@ -1026,6 +1078,12 @@ def main():
                                    "row_communicator": r2.eng.comm_query()["row_communicator"]}
                     if hasattr(r2, "balance"):
                         extra[name]["csr_entries_max_over_mean"] = r2.balance["max_over_mean"]
+                    mp = model_prediction(wl, layout, world)
+                    if mp is not None:
+                        extra[name]["model"] = mp
+                        extra[name]["model_ms_per_step"] = mp.get("predicted_ms_per_step")
+                        if mp.get("predicted_ms_per_step"):
+                            extra[name]["measured_over_model"] = extra[name]["ms_per_step"] / mp["predicted_ms_per_step"]
                     if cls is not _ShardedSteps:
                         # the same sweeps on rank 0's GPU alone (plain engine, hipGraph replay): what one GPU of THIS box does with
                         # this workload -- the other ranks wait at the barrier below
@@ -1041,12 +1099,13 @@ def main():
                             extra[name]["n1_same_box_error"] = repr(exc1)[:200]
                 dist.barrier()
                 r2.eng.close()
-                s2.close()
-                if p2:
-                    os.unlink(p2)
             except Exception as exc:  # the main measurement must survive a failure here
                 extra[name] = {"error": repr(exc)[:300]}
             current["name"] = None
+        for so, po, _, _ in setups.values():
+            so.close()
+            if po:
+                os.unlink(po)
     if path:
         os.unlink(path)
     if dist is not None:

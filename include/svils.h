@@ -32,11 +32,13 @@
 extern "C" {
 #endif
 
-#define SVILS_ABI_VERSION 7   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags;
+#define SVILS_ABI_VERSION 8   /* 3: svils_config gained k_begin / k_total (K-sharded handles); 4: svils_comm_info; 5: community tags;
                                  6: work-balanced node blocks (svils_balance_node_blocks / svils_set_node_blocks), the node-block sweep
                                     with ONE row exchange (SVILS_PHASE_B_LIGHT / SVILS_PHASE_EXPAND_ALL, SVILS_BUF_GSTAGE);
                                  7: k up to SVILS_MAX_K_TOTAL (column-tiled handles above SVILS_MAX_K; K-sharded k_total up to it),
-                                    getters that do not wait behind a stop the caller has seen ("After the stop") */
+                                    getters that do not wait behind a stop the caller has seen ("After the stop");
+                                 8: svils_set_option / svils_get_option / svils_option_table (every tunable in one documented table; nothing
+                                    on a sweep path reads the environment); svils_gather_communities ends the no-wait window of "After the stop" */
 
 typedef enum {
   SVILS_OK = 0,
@@ -370,7 +372,7 @@ int svils_stream(svils_handle *h, void **stream);
  *   row) -> s3 pass -> all-reduce(s1,s2,s3) -> tail (replicated):
  * two exchange points per sweep in both phases of a run, nothing on the host looks at the control block, and runs of
  * sweeps -- collectives included -- replay as hipGraphs under svils_sweep's rule (eager until the handle has run 128
- * sweeps; SVILS_SHARDED_GRAPHS=0 keeps them eager; a capture that fails once leaves the handle eager).
+ * sweeps; option sharded_graphs = 0 keeps them eager; a capture that fails once leaves the handle eager).
  * The K-vector all-reduces run on the handle's stream.  When the n-by-k payload is large enough to be pipelined
  * (chunks on a communication stream of their own, each expanded while the next one travels) the row chunks use a
  * SECOND communicator, formed by the same ranks the first time it is needed (rank 0 draws another unique id and
@@ -445,6 +447,19 @@ int svils_sweep_ksharded(svils_handle *h, uint32_t nsweeps);   /* collective, as
  * in this mode: the entries of the window's rows are one contiguous range) and of SVILS_KSH_ROWX.  With your own
  * collectives: svils_ksweep_phase in the order of a sweep; the first phase opens the step, SVILS_KPHASE_STOP closes it. */
 int svils_step_ksharded(svils_handle *h, uint32_t nsteps);      /* collective, asynchronous */
+
+/* ---- options -------------------------------------------------------------------------------------------------------
+ * Every tunable of the library is a row of ONE table: key, the SVILS_* environment variable that sets its default, the
+ * built-in default, until when it may be changed on a handle, and what it does -- svils_option_table() returns it as
+ * tab-separated text (one row per line, a header line first; DESIGN.md section 9 prints it).  The environment is read
+ * when svils_create runs and at no other time (SVILS_RCCL_LIBRARY: at the first svils_comm_init of the process);
+ * svils_set_option changes one option of one handle afterwards -- options consumed by svils_create ("environment only")
+ * or by svils_set_graph ("before svils_set_graph") answer SVILS_ERR_ARG once it is too late.  Values are decimal
+ * integers as text.  The reference has one knob of this kind, its command line (src/env.hh:13-110); none of these changes
+ * a result beyond rounding (tests/test_gpu_parity.py runs the A/B forms against the oracle). */
+int svils_set_option(svils_handle *h, const char *key, const char *value);
+int svils_get_option(svils_handle *h, const char *key, char *value, size_t cap);
+const char *svils_option_table(void);
 
 const char *svils_last_error(void);
 int svils_abi_version(void);

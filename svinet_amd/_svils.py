@@ -33,6 +33,7 @@ EXPORTS = (
     "svils_set_test", "svils_get_test_rows",
     "svils_report_tag_count", "svils_report_fetch_tags", "svils_get_community_tags",
     "svils_set_node_blocks", "svils_balance_node_blocks", "svils_prepare_graphs",
+    "svils_set_option", "svils_get_option", "svils_option_table",
 )
 
 
@@ -144,9 +145,12 @@ def load():
     L.svils_report_fetch_tags.argtypes = [vp, C.c_int, C.POINTER(Control), vp, C.POINTER(C.c_uint32), vp, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
     L.svils_get_community_tags.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svils_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.svils_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.svils_option_table.restype = C.c_char_p
     for name in EXPORTS:
         f = getattr(L, name)
-        if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default"):
+        if name not in ("svils_last_error", "svils_kernel_name", "svils_abi_version", "svils_stochastic_default", "svils_option_table"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -186,9 +190,10 @@ class Engine:
 
     def __init__(self, n, k, ones, ones_prob, eta=(1.0, 1.0), link_thresh=0.5, lt_min_deg=0,
                  reportfreq=1, use_validation_stop=True, device=0, node_block=None, n_alloc=0,
-                 sparse_after_iter=1000, k_slice=None):
+                 sparse_after_iter=1000, k_slice=None, options=None):
         """k_slice = (k_begin, k_end): a K-sharded handle holding those columns of the `k` communities
-        (gamma / lambda go in and out as that slice; alpha stays 1/k)."""
+        (gamma / lambda go in and out as that slice; alpha stays 1/k).
+        options = {key: value}: rows of the library's option table set on the new handle (svils_set_option)."""
         L = load()
         cfg = Config()
         _chk(L.svils_config_default(C.byref(cfg), n, k))
@@ -213,6 +218,8 @@ class Engine:
         self.n, self.k = n, k
         self._h = C.c_void_p()
         _chk(L.svils_create(C.byref(cfg), C.byref(self._h)))
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -463,6 +470,15 @@ class Engine:
     def sweep_sharded(self, nsweeps=1):
         _chk(load().svils_sweep_sharded(self._h, nsweeps))
 
+    def set_option(self, key, value):
+        """one row of the library's option table for this handle (include/svils.h: svils_set_option)"""
+        _chk(load().svils_set_option(self._h, key.encode(), str(int(value)).encode()))
+
+    def get_option(self, key):
+        buf = C.create_string_buffer(64)
+        _chk(load().svils_get_option(self._h, key.encode(), buf, 64))
+        return int(buf.value.decode())
+
     def gather_communities(self):
         _chk(load().svils_gather_communities(self._h))
 
@@ -485,3 +501,10 @@ class Engine:
         s = C.c_void_p()
         _chk(load().svils_stream(self._h, C.byref(s)))
         return s.value
+
+
+def option_table():
+    """the library's option table as a list of dicts (key, environment, default, settable, meaning)"""
+    rows = load().svils_option_table().decode().strip().split("\n")
+    head = rows[0].split("\t")
+    return [dict(zip(head, r.split("\t"))) for r in rows[1:]]

@@ -37,22 +37,52 @@ def _glob(d, exts):
     return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts)) if os.path.isdir(d) else []
 
 
-def build_svils(force=False):
+def _svils_sources():
+    return _glob(CSRC, (".hip",))
+
+
+def _compile_objects(srcs, objdir, flags, deps_common, force):
+    """one object per translation unit, stale ones compiled in parallel (svils_lpl.hip / svils_device.hip are minutes of
+    hipcc each; the host-only units are seconds)"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + deps_common):
+            jobs.append([HIPCC] + flags + ["-c", "-o", obj, src])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+    return objs
+
+
+def _build_svils_variant(name, extra_flags, force=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    out = os.path.join(LIBDIR, "libsvils.so")
-    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip", "svils_report.hip")]
-    deps = srcs + _glob(CSRC, (".h",)) + [os.path.join(ROOT, "include", "svils.h")]
-    if force or _stale(out, deps):
-        _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out] + srcs)
+    out = os.path.join(LIBDIR, name + ".so")
+    srcs = _svils_sources()
+    deps_common = _glob(CSRC, (".h",)) + [os.path.join(ROOT, "include", "svils.h")]
+    objs = _compile_objects(srcs, os.path.join(LIBDIR, "obj_" + name), HIP_FLAGS + extra_flags, deps_common, force)
+    if force or _stale(out, objs):
+        _run([HIPCC] + HIP_FLAGS + ["-shared", "-o", out] + objs)
     return out
+
+
+def build_svils(force=False):
+    return _build_svils_variant("libsvils", [], force)
 
 
 def build_stamps():
     """libsvils_stamps.so: the same kernels with wall-clock stamps at phase boundaries (tools/stamps.py)"""
-    out = os.path.join(LIBDIR, "libsvils_stamps.so")
-    srcs = [os.path.join(CSRC, f) for f in ("svils_api.hip", "svils_device.hip", "svils_lpl.hip", "svils_report.hip")]
-    _run([HIPCC] + HIP_FLAGS + ["-DSVILS_STAMPS", "-shared", "-o", out] + srcs)
-    return out
+    return _build_svils_variant("libsvils_stamps", ["-DSVILS_STAMPS"])
+
+
+def build_testing(force=False):
+    """libsvils_testing.so: the product sources + the two hooks that exist for the tests alone (-DSVILS_TESTING: fault
+    injection into an in-launch hand-off, a pretended CU count; svils_options.h).  TEST INFRASTRUCTURE: tests select it
+    with SVILS_LIB; the product library does not contain the hooks."""
+    return _build_svils_variant("libsvils_testing", ["-DSVILS_TESTING"], force)
 
 
 def build_host(force=False):
@@ -84,5 +114,7 @@ def build_all(force=False):
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         build_stamps()
+    elif "--testing" in sys.argv:
+        build_testing("--force" in sys.argv)
     else:
         build_all("--force" in sys.argv)

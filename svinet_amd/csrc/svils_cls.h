@@ -421,7 +421,12 @@ __device__ __forceinline__ void cls_classify_in_launch(const Geometry &geo, cons
     const uint32_t tile = rw + t * nrw;
     // (inject_fault: tile 0 is never published, so every worker above it runs into the bound of its wait -- the test
     //  of the time-out path: the run freezes and surfaces as SVILS_ERR_DEVICE)
-    if (tile < d.cls_ntiles && tid == 0 && !(d.inject_fault && tile == 0u))
+#ifdef SVILS_TESTING
+    const bool withheld = d.inject_fault && tile == 0u;
+#else
+    constexpr bool withheld = false;
+#endif
+    if (tile < d.cls_ntiles && tid == 0 && !withheld)
       st_agent(&d.tpoll[tile], ((unsigned long long)epoch << 32) | (unsigned long long)ttot);   // n0 | n1 << 16, <= 1024 each
   }
 #pragma unroll

@@ -100,7 +100,7 @@ struct DeviceState {
   // otherwise the lists, totals and shortcut histogram of the current sweep simply stay current (cls_par does not flip).
   // Late in a run few sweeps change a flag; at n = 1e6, k = 20 the two passes are ~0.5 ms of a 2.8 ms sweep.
   uint32_t *cls_epoch;            // [1]
-  int inject_fault;               // test hook (SVILS_FAULT_INJECT=cls_handoff): one worker never publishes its tile
+  int inject_fault;               // test hook (libsvils_testing.so, option fault_inject): one worker never publishes its tile
   uint32_t *ltot;                 // [2][8] per cls_par: entries of class 0,1,2; entries with q > p of class 0,1,2
   unsigned long long *shist;      // [2][K] per cls_par: class-2 entries per community column
   // `sum[k]` of whole sweeps driven by this library (fold): per-XCD fixed-point accumulators, [2][8][64] per cls_par.
@@ -269,7 +269,7 @@ uint32_t lpl_finalize_waves(uint32_t K, uint64_t nodes, uint32_t cus);   // wave
 int lpl_finalize_group(uint32_t K);
 uint32_t lpl_finalize_resident_blocks(uint32_t K, int device);
 uint32_t lpl_scatter_blocks(const DeviceState &d);
-uint32_t lpl_s3_resident_blocks(uint32_t K, int device);
+uint32_t lpl_s3_resident_blocks(uint32_t K, int device, uint32_t threads, int assume_cus);
 void launch_carry_flags(const Geometry &g, const DeviceState &d, hipStream_t s);
 void launch_expand_window(const Geometry &g, const DeviceState &d, const Params &p, uint32_t wb, uint32_t we,
                           uint32_t block, uint32_t my_rank, uint32_t world, hipStream_t s);

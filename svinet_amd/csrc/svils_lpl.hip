@@ -1389,13 +1389,19 @@ void launch_finalize_lpl(const Geometry &g, const DeviceState &d, const Params &
 // blocks of k_s3_lpl the device holds at once.  The three-launch sweep needs its classification role blocks (<= 64, + 1)
 // co-resident: they hand tile counts to each other inside the launch.  A whole MI355X holds hundreds; a CPX partition
 // (32 CUs) or a masked device may not, and then the handle keeps the four-launch sweep (spin-free passes).
-uint32_t lpl_s3_resident_blocks(uint32_t K, int device) {
+uint32_t lpl_s3_resident_blocks(uint32_t K, int device, uint32_t threads, int assume_cus) {
   int per_cu = 0, cus = 0;
+  if (threads == 768u && K > 20 && K <= 32) {   // the 12-wave shape launch_s3_lpl takes for this graph (lpl_s3_threads)
+    if (K <= 24) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_s3_lpl<12, 768>, 768, 0);
+    else if (K <= 28) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_s3_lpl<14, 768>, 768, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_s3_lpl<16, 768>, 768, 0);
+  } else {
 #define CALL(KC_) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_s3_lpl<KC_>, s3_threads(KC_), 0)
-  LPL_DISPATCH(K, CALL);
+    LPL_DISPATCH(K, CALL);
 #undef CALL
+  }
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  if (const char *e = getenv("SVILS_ASSUME_CUS")) cus = atoi(e);   // tests: pretend to be a partition of this many CUs
+  if (assume_cus > 0) cus = assume_cus;   // (libsvils_testing.so: pretend to be a partition of this many CUs)
   if (per_cu <= 0 || cus <= 0) return 0;
   return (uint32_t)per_cu * (uint32_t)cus;
 }

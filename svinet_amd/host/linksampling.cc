@@ -792,7 +792,9 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
     if (!total) return;
     char *m = (char *)MAP_FAILED;
     const uint64_t a0 = off & ~(uint64_t)4095;
-    if (use_map == 1 && T > 1 && ftruncate(fd, (off_t)(off + total)) == 0)
+    // (posix_fallocate, not ftruncate: a full disk or a quota must surface HERE as an error code -- stores into a mapping of
+    //  a sparse range would turn it into SIGBUS; a file system without fallocate falls back to positional writes)
+    if (use_map == 1 && T > 1 && posix_fallocate(fd, (off_t)off, (off_t)total) == 0)
       m = (char *)mmap(nullptr, (size_t)(off + total - a0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
     if (m == (char *)MAP_FAILED) {
       if (use_map == 1) use_map = -1;          // this file system cannot map the file
@@ -832,7 +834,10 @@ void write_rows(const std::string &path, const char *what, uint32_t n, uint32_t 
     t_flush += w1 - w0; t_wait += w2 - w1; t_fmt += w2 - w0;
   }
   flush(buf[cur ^ 1]);
-  close(fd);
+  // a deferred write error (mapped pages, delayed allocation, NFS) is reported at fsync / close: the reference's fclose
+  // would have lost it too, but a silently short gamma.txt is the one thing this writer must not leave behind
+  if (fsync(fd) != 0 && errno != EINVAL && errno != EROFS) { printf("cannot write %s file:%s\n", what, strerror(errno)); exit(-1); }
+  if (close(fd) != 0) { printf("cannot write %s file:%s\n", what, strerror(errno)); exit(-1); }
   if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] %s: waves %.3f s, of which writing the previous wave %.3f s, then waiting for the formatters %.3f s\n", what, t_fmt, t_flush, t_wait);
 }
 }  // namespace

@@ -12,6 +12,7 @@
 // polynomial of any output bit sequence (it is irreducible of degree 19937), found once per process by Berlekamp-Massey
 // over GF(2) on 2 x 19937 bits.  x^J mod phi: square-and-multiply on 312-word bit vectors.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <mutex>

@@ -6,7 +6,9 @@ torch.distributed here: the ranks only share the 128-byte communicator id, which
 
 argv: path n k count out rank world mode
 mode: sweep | step:<windows per block>:<kappa> | kshard | kshard-log | kshard-lowt (link_thresh = 0.3) |
-      kstep:<windows>:<kappa> (mini-batch steps on the K-sharded layout)
+      kstep:<windows>:<kappa> (mini-batch steps on the K-sharded layout) |
+      sweep-stop (node blocks with the validation stop rule ON: the sequence of the CLI's do_on_stop -- the host SEES the
+      stop, gathers the tags, reads them at once)
 """
 import os
 import sys
@@ -78,7 +80,7 @@ def main():
             eng = setup.engine(device=0, node_block=node_block(n, world, rank), n_alloc=B * world, use_validation_stop=False)
         else:                                                   # whole sweeps: the work-balanced blocks, declared before the communicator
             bounds = balanced_bounds(setup.links, n, world)
-            eng = setup.engine(device=0, node_block=(int(bounds[rank]), int(bounds[rank + 1])), use_validation_stop=False)
+            eng = setup.engine(device=0, node_block=(int(bounds[rank]), int(bounds[rank + 1])), use_validation_stop=(mode == "sweep-stop"))
             eng.set_node_blocks(rank, world, bounds)
             extra_bounds = bounds
         eng.comm_init(comm_id(out, rank), rank, world)
@@ -91,8 +93,17 @@ def main():
             eng.step_sharded(count)
         else:
             eng.sweep_sharded(count)
-        eng.gather_communities()
-        extra = dict(mphi=eng.aux(2))
+        early = {}
+        if mode == "sweep-stop":
+            # svinet -gpus N at its stop (host/linksampling.cc: the control block says `stopped` -> do_on_stop: gather, then the
+            # files): the getters may skip their wait once the stop has been SEEN, but not for the gather enqueued since
+            c = eng.control()
+            assert c.stopped == 1, "the run was meant to reach its stop rule"
+            eng.gather_communities()
+            early = dict(member_early=eng.communities())      # no synchronize() in between: the getter itself must wait
+        else:
+            eng.gather_communities()
+        extra = dict(mphi=eng.aux(2), **early)
     eng.synchronize()
     ci = eng.comm_query()
     assert ci["rank"] == rank and ci["nranks"] == world and ci["hip_device"] == 0

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), "libsvils.so does not export %s" % n
     assert sorted(_svils.EXPORTS) == names
-    assert lib.svils_abi_version() == 7
+    assert lib.svils_abi_version() == 8
 
 
 def test_kernel_names():
@@ -66,3 +66,40 @@ def test_product_does_not_touch_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|svinet_oracle|orc_ls_|orc_net_", txt, flags=re.M):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_option_table_is_the_only_reader_of_the_environment():
+    """every tunable is a row of ONE table (svils_option_table), DESIGN.md prints it, nothing on a sweep
+    path reads the environment, and the tests' two hooks are not in the product library."""
+    from svinet_amd import _svils
+    rows = _svils.option_table()
+    keys = [r["key"] for r in rows if r["key"] != "-"]
+    assert len(keys) == len(set(keys)) >= 14 and "sharded_graphs" in keys and "xchunks" in keys
+    assert "fault_inject" not in keys and "assume_cus" not in keys            # -DSVILS_TESTING builds only
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for r in rows:
+        assert r["environment"] in design, "DESIGN.md does not list %s" % r["environment"]
+        assert r["key"] == "-" or ("`%s`" % r["key"]) in design, "DESIGN.md does not list option %s" % r["key"]
+    # getenv in the library's sources: the option table, the RCCL library name (first svils_comm_init of the process) and
+    # the runtime's own CU-mask variables (once per svils_set_graph) -- nowhere else
+    csrc = os.path.join(ROOT, "svinet_amd", "csrc")
+    hits = {}
+    for f in sorted(os.listdir(csrc)):
+        n = len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read()))
+        if n:
+            hits[f] = n
+    assert set(hits) == {"svils_options.hip", "svils_comm.hip", "svils_api.hip"}, hits
+    assert hits["svils_comm.hip"] == 1 and hits["svils_api.hip"] == 2
+    blob = open(os.path.join(ROOT, "svinet_amd", "lib", "libsvils.so"), "rb").read()
+    assert b"SVILS_FAULT_INJECT" not in blob and b"SVILS_ASSUME_CUS" not in blob
+    testing = os.path.join(ROOT, "svinet_amd", "lib", "libsvils_testing.so")
+    if os.path.exists(testing):
+        tb = open(testing, "rb").read()
+        assert b"SVILS_FAULT_INJECT" in tb and b"SVILS_ASSUME_CUS" in tb
+
+
+def test_set_option_argument_checks():
+    from svinet_amd import _svils
+    lib = _svils.load()
+    assert lib.svils_set_option(None, b"xchunks", b"2") == -1
+    assert b"key\tenvironment\tdefault" in lib.svils_option_table()

@@ -65,3 +65,36 @@ def test_bare_gpus_n_spawns_ranks_and_fails_loudly_without_a_gpu(tmp_path):
     # both ranks were started and said why they left (the launcher gives the second one a few seconds to do so before it ends it)
     assert 1 <= r.stderr.count("needs a GPU (no CPU fallback)") <= 2
     assert "torch.distributed.run" not in r.stderr
+
+
+def test_side_records_config5_ksharded_first_and_timeouts_scale():
+    """on the first real node the record of the one layout expected to scale (config 5, K-sharded) must not
+    sit behind six others under a global cut-off: it runs FIRST, shares its host set-up with the node-block record of the
+    same workload, and the cut-off scales with the records requested."""
+    import bench
+    plan, budget = bench.side_record_plan("")
+    names = [r[0] for r in plan]
+    assert names[0] == "ksharded_config5_mmsb_n1m_k512" and names[1] == "config5_mmsb_n1m_k512" and len(names) == 7
+    assert plan[0][1] == plan[1][1] == bench.CONFIG5_WORKLOAD                      # adjacent: one set-up serves both
+    assert budget >= 400
+    one, b1 = bench.side_record_plan("config4_astroph_k200")
+    assert [r[0] for r in one] == ["config4_astroph_k200"] and b1 < 120
+    # an --extra-list keeps the canonical order whatever order it names them in
+    two, _ = bench.side_record_plan("config4_astroph_k200,ksharded_config5_mmsb_n1m_k512")
+    assert [r[0] for r in two] == ["ksharded_config5_mmsb_n1m_k512", "config4_astroph_k200"]
+
+
+def test_model_prediction_rows_cover_every_n_gt_1_record():
+    """the cost model's number travels in the same JSON line as the record it will be compared with: profiles/shard_cost_model.json
+    (tools/shard_cost.py --json, measured on one GPU) has a row for the headline workload and for every side record at 2, 4, 8"""
+    import bench
+    m = json.load(open(os.path.join(ROOT, "profiles", "shard_cost_model.json")))
+    assert m["link_model"]["eff_GBps"] > 0 and "lat_us" in m["link_model"]
+    for world in (2, 4, 8):
+        assert bench.model_prediction("astroph-k20", "nodeblock", world)["predicted_ms_per_step"] > 0
+        for name, wl, _, layout in bench.SIDE_RECORDS:
+            if layout == "steps":
+                continue
+            mp = bench.model_prediction(wl, layout, world)
+            assert mp is not None and mp["predicted_ms_per_step"] > 0 and mp["compute_ms_per_rank"] > 0, (name, world)
+            assert mp["source"].startswith("tools/shard_cost.py")

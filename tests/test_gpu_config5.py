@@ -105,6 +105,105 @@ def test_config5_full_size_against_oracle_digest(config5):
     eng.close()
 
 
+def _eight_kshards(s, world=8, state=None, control=None):
+    """BASELINE config 5 as its 8-GPU run executes it: EIGHT K-sharded handles of 64 columns each (k_phi_ksh16,
+    k_fin1/2_ksh<16,4>, k_s3_ksh16), here as virtual ranks on the one GPU with the four exchanges summed in rank order"""
+    from svinet_amd.ksharded import KShard, init_virtual
+    shards = [KShard(s, r, world, 0, use_validation_stop=False) for r in range(world)]
+    if state is not None:
+        g0, lam0, conv0 = state
+        for sh in shards:
+            sh.engine.set_state(np.ascontiguousarray(g0[:, sh.k0:sh.k1]), np.ascontiguousarray(lam0[sh.k0:sh.k1]), conv0)
+    if control is not None:
+        for sh in shards:
+            sh.engine.set_control(**control)
+    init_virtual(shards)
+    return shards
+
+
+def _kshard_state(shards):
+    states = [sh.engine.state() for sh in shards]
+    for st in states[1:]:
+        assert np.array_equal(st[2], states[0][2])       # flags are replicated
+    return np.concatenate([st[0] for st in states], 1), np.concatenate([st[1] for st in states], 0), states[0][2]
+
+
+def test_config5_full_size_eight_kshards_against_oracle_digest(config5):
+    """BASELINE config 5 at FULL size in the layout built for its 8-GPU run -- eight column slices of 64 -- against the
+    same oracle digest as the plain engine (two sweeps from the seeded state): lambda, gamma column sums, 64 gamma rows
+    to 1e-9, flags / active counts / link-branch counts of every sweep exactly, likelihood rows to 1e-9
+    (src/linksampling.cc:605-761; the layout: DESIGN.md section 6)."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5")
+    meta = json.load(open(os.path.join(d, "digest.json")))
+    dg = np.load(os.path.join(d, "digest.npz"))
+    n, k, _, _, s = config5
+    from svinet_amd.ksharded import sweep_virtual
+    shards = _eight_kshards(s)
+    assert [sh.k1 - sh.k0 for sh in shards] == [64] * 8 and not shards[0].log_domain
+    sweep_virtual(shards, meta["sweeps"])
+    g, lam, conv = _kshard_state(shards)
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))
+    assert rel(lam, dg["lam"]) < 1e-9
+    assert rel(g.sum(0), dg["gamma_colsum"]) < 1e-9
+    assert rel(g[dg["rows_idx"]], dg["gamma_rows"]) < 1e-9
+    rs = g.sum(1)
+    np.testing.assert_allclose([rs.min(), rs.max()], dg["gamma_rowsum_minmax"], rtol=1e-9)
+    del g
+    assert np.array_equal(np.flatnonzero(conv).astype(np.uint32), dg["converged_idx"])
+    assert np.array_equal(conv[conv > 0], dg["converged_val"])
+    want = dg["likelihood_rows"]
+    for sh in (shards[0], shards[7]):                    # replicated on every rank: first and last
+        e = sh.engine
+        assert np.array_equal(np.bincount(e.aux(3), minlength=k + 1), dg["active_hist"])
+        assert np.array_equal(e.sweep_stats(0, meta["sweeps"]).astype(np.int64), dg["link_counts"])
+        np.testing.assert_allclose(e.rows()[:, 1:], want[1:, 1:], rtol=1e-9, atol=1e-13)
+        assert list(e.rows()[:, 0]) == list(want[1:, 0])
+    for sh in shards:
+        sh.engine.close()
+
+
+def test_config5_full_size_planted_state_eight_kshards_against_oracle_digest(config5):
+    """... and from the planted near-converged state at _iter = 999 (four sweeps: O(1) shortcuts for 44 % of the links, s3's
+    quirk Q2 across slice edges -- q2v --, the active-set branch past _iter = 1000 on bitmasks of one word per node):
+    link-branch counts of every sweep and every flag exactly, lambda / gamma to 1e-9."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = os.path.join(here, "golden", "config5")
+    meta = json.load(open(os.path.join(d, "digest_planted.json")))
+    dg = np.load(os.path.join(d, "digest_planted.npz"))
+    spec = importlib.util.spec_from_file_location("make_config5_digest", os.path.join(os.path.dirname(here), "tools", "make_config5_digest.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    n, k, pairs, truth, s = config5
+    from svinet_amd.ksharded import sweep_virtual
+    state = tool.planted_state(pairs, truth, n, k)
+    shards = _eight_kshards(s, state=state, control=dict(iter=meta["iter0"], annealing=0))
+    del state
+    nsw = meta["sweeps"]
+    sweep_virtual(shards, nsw)
+    g, lam, conv = _kshard_state(shards)
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))
+    assert rel(lam, dg["lam"]) < 1e-9
+    assert rel(g.sum(0), dg["gamma_colsum"]) < 1e-9
+    assert rel(g[dg["rows_idx"]], dg["gamma_rows"]) < 1e-9
+    del g
+    assert np.array_equal(np.flatnonzero(conv).astype(np.uint32), dg["converged_idx"]) and dg["converged_idx"].size > 100_000
+    assert np.array_equal(conv[conv > 0], dg["converged_val"])
+    want = dg["likelihood_rows"]
+    for sh in (shards[0], shards[7]):
+        e = sh.engine
+        st = e.sweep_stats(0, nsw).astype(np.int64)
+        assert np.array_equal(st, dg["link_counts"]), (st, dg["link_counts"])
+        assert np.array_equal(np.bincount(e.aux(3), minlength=k + 1), dg["active_hist"])
+        np.testing.assert_allclose(e.rows()[:, 1:], want[1:, 1:], rtol=1e-9, atol=1e-10)   # (atol: see the plain-engine test)
+    for sh in shards:
+        sh.engine.close()
+
+
 def test_config5_full_size_planted_state_against_oracle_digest(config5):
     """The same full-size graph in the regime a long run ends in, which two sweeps from the seeded state never reach:
     started from tools/make_config5_digest.py::planted_state (gamma = alpha + degree x planted membership, every third node
@@ -158,23 +257,31 @@ def test_config5_full_size_planted_state_against_oracle_digest(config5):
     eng.close()
 
 
-def test_hbm_bound_sweep_against_oracle():
-    """three sweeps at n = 1e5, k = 512 on the planted MMSB graph against the oracle RUNNING LIVE (0.41 GB per n-by-k
-    array: outside the 256 MB Infinity Cache; the full-size runs above compare with committed digests): gamma / lambda
-    within 1e-5 relative (the north-star bar; observed ~1e-13), flags, counters and the likelihood row equal.
-    (n = 2e5 until round 4: 107 s of the suite for the oracle's three sweeps, now that the full size itself is covered.)"""
+@pytest.fixture(scope="module")
+def hbm_bound():
+    """n = 1e5, k = 512 on the planted MMSB graph (0.41 GB per n-by-k array: outside the 256 MB Infinity Cache), the oracle
+    run LIVE for three sweeps -- once, for the plain engine and for the eight node blocks below (~50 s of CPU)."""
     from oracle import oracle as O
     from svinet_amd import mmsbgen_sparse as G
     from svinet_amd.host_api import Setup
-    n, k = 100_000, 512
+    n, k, nsweeps = 100_000, 512, 3     # flags set by prune() in one sweep steer the branches of the next (shortcut links, s3's quirk Q2)
     pairs = G.generate(n, k, 24)
     s = Setup(n=n, k=k, pairs=pairs)
     ref = O.LinkSampling(O.Network(n=n, pairs=pairs), k, use_validation_stop=False)
     assert np.array_equal(ref.links, s.links) and np.array_equal(ref.validation_sorted, s.validation_sorted)
-    eng = s.engine(use_validation_stop=False)
-    nsweeps = 3     # flags set by prune() in one sweep steer the branches of the next (shortcut links, s3's quirk Q2)
     for _ in range(nsweeps):
         ref.sweep()
+    yield n, k, nsweeps, pairs, s, ref
+    s.close()
+
+
+def test_hbm_bound_sweep_against_oracle(hbm_bound):
+    """three sweeps at n = 1e5, k = 512 on the planted MMSB graph against the oracle RUNNING LIVE (the full-size runs
+    above compare with committed digests): gamma / lambda within 1e-5 relative (the north-star bar; observed ~1e-13),
+    flags, counters and the likelihood row equal.
+    (n = 2e5 until round 4: 107 s of the suite for the oracle's three sweeps, now that the full size itself is covered.)"""
+    n, k, nsweeps, pairs, s, ref = hbm_bound
+    eng = s.engine(use_validation_stop=False)
     eng.sweep(nsweeps)
     g, lam, conv = eng.state()
     rg, rl = ref.gamma, ref.lam
@@ -186,6 +293,32 @@ def test_hbm_bound_sweep_against_oracle():
     c = eng.control()
     assert (c.links_dense, c.links_sparse, c.links_shortcut) == ref.link_counts()
     np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-9, atol=1e-13)
+    eng.close()
+
+
+def test_hbm_bound_eight_node_blocks_chunked_exchange_against_oracle(hbm_bound, tmp_path):
+    """The node-block form of an HBM-bound K = 512 run as eight GPUs execute it: EIGHT native ranks (processes on this one
+    GPU over the tests' transport) on work-balanced blocks, the row exchange FORCED into its pipelined form (option xchunks:
+    chunks of every block on the communication stream and a second communicator, each expanded while the next travels --
+    the form config 5's 4.1 GB payload takes by itself) -- every rank's replicated state against the live oracle."""
+    import test_gpu_native_ranks as T
+    n, k, nsweeps, pairs, s, ref = hbm_bound
+    path = str(tmp_path / "mmsb_n100k.txt")
+    with open(path, "w") as f:
+        f.write("".join("%d\t%d\n" % (a, b) for a, b in np.asarray(pairs).tolist()))
+    world, chunks = 8, 3
+    states, (calls, ncomm) = T._run_ranks(tmp_path, path, n, k, nsweeps, world, "sweep", {"SVILS_XCHUNKS": str(chunks)})
+    for st in states:
+        assert np.max(np.abs(st["gamma"] - ref.gamma) / ref.gamma) < 1e-9
+        assert np.max(np.abs(st["lam"] - ref.lam) / np.abs(ref.lam)) < 1e-9
+        assert np.array_equal(st["conv"], ref.converged)
+        np.testing.assert_allclose(st["rows"][:, 1:], ref.rows[1:, 1:], rtol=1e-9, atol=1e-13)
+        assert bool(st["row_comm"]) and int(st["comm_nranks"]) == world
+    for st in states[1:]:
+        assert np.array_equal(st["gamma"], states[0]["gamma"]) and np.array_equal(st["lam"], states[0]["lam"])
+    assert np.array_equal(states[0]["member"], ref.communities())
+    # per sweep: all-reduce(sum) + chunks x world broadcasts + all-reduce(s1,s2,s3); + the tag gather and the second communicator's id
+    assert ncomm == 2 and calls == (2 + chunks * world) * nsweeps + world + 1
 
 
 @pytest.mark.parametrize("k", [20, 28])

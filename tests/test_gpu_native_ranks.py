@@ -126,7 +126,10 @@ def _check_node_block(states, ref, n, world, tags=True):
                                                                # the world sizes the driver's scaling run uses (2, 4, 8): four and
                                                                # eight node blocks, the headline graph at its own K on eight
                                                                ("lfr", 4, 28, 35, 1, False), ("lfr", 8, 28, 35, 3, False),
-                                                               ("astroph", 8, 20, 6, 1, False), ("astroph", 4, 200, 3, 2, False)])
+                                                               ("astroph", 8, 20, 6, 1, False), ("astroph", 4, 200, 3, 2, False),
+                                                               # BASELINE config 4 as its 8-GPU run executes it: ca-AstroPh K = 200 on
+                                                               # eight balanced node blocks (exact-count row exchange: 8 x bmax = 3.0 n)
+                                                               ("astroph", 8, 200, 3, 2, False)])
 def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, sweeps, chunks, sync):
     """svils_sweep_sharded in `world` processes on WORK-BALANCED node blocks (svils_balance_node_blocks: blocks of
     different sizes): per sweep one grouped {all-reduce of sum[k], in-place all-gather of the staged rows padded to the
@@ -154,6 +157,27 @@ def test_native_sweep_sharded_ranks(graph_files, tmp_path, graph, world, k, swee
         from svinet_amd.sharded import balanced_bounds
         b = balanced_bounds(Setup(path, n, k).links, n, world).astype(np.int64)
         assert np.diff(b)[0] * 2 < np.diff(b)[-1]
+
+
+def test_tags_after_a_seen_stop_wait_for_the_gather(graph_files, tmp_path):
+    """once a control block that says `stopped` has reached the host the getters skip their stream wait
+    -- but svils_gather_communities, called after it (the CLI's do_on_stop), ENQUEUES broadcasts that write the other
+    blocks' rows of the community bitmask.  On the asynchronous transport with every collective stretched by 30 ms a getter
+    that does not wait reads rank 0's bitmask with the other blocks' rows stale; every rank's tags, read straight after the
+    gather, must equal the oracle's."""
+    path, n, k, world = graph_files["lfr"], 1000, 28, 3
+    ref = O.LinkSampling(O.Network(path, n), k)
+    nsw = 0
+    while ref.sweep() != 2:
+        nsw += 1
+        assert nsw < 400
+    states, _ = _run_ranks(tmp_path, path, n, k, nsw + 1 + 8, world, "sweep-stop", {"FAKERCCL_DELAY_US": "30000", "NATIVE_RANK_NO_TIMING": "1"})
+    want = ref.communities()
+    assert want.sum() > 100
+    for s in states:
+        assert int(s["iter"]) == ref.iter and np.array_equal(s["conv"], ref.converged)
+        assert np.array_equal(s["member_early"], want)
+        assert np.array_equal(s["member"], want)
 
 
 @pytest.mark.parametrize("graph,world,k,sweeps,chunks", [("lfr", 2, 28, 70, 1), ("lfr", 3, 28, 45, 3), ("astroph", 4, 20, 12, 1),
@@ -217,12 +241,16 @@ def test_native_step_sharded_windows(graph_files, tmp_path, world):
 @pytest.mark.parametrize("world,k,sweeps,mode", [(2, 28, 40, "kshard"), (3, 100, 6, "kshard"), (3, 130, 5, "kshard-log"),
                                                   (2, 28, 40, "kshard-log"), (3, 28, 30, "kshard-lowt"),
                                                   # four and eight column slices (K = 28 on eight ranks: slices of 3 and 4 columns)
-                                                  (4, 28, 35, "kshard"), (8, 28, 35, "kshard"), (8, 200, 4, "kshard")])
+                                                  (4, 28, 35, "kshard"), (8, 28, 35, "kshard"), (8, 200, 4, "kshard"),
+                                                  # BASELINE config 4 K-sharded over eight ranks: ca-AstroPh, slices of 25 columns
+                                                  (8, 200, 3, "kshard-astroph")])
 def test_native_sweep_ksharded_ranks(graph_files, tmp_path, world, k, sweeps, mode):
     """svils_ksh_init_state + svils_sweep_ksharded in `world` processes (uneven slices at K=100/3, 130/3): the column
     slices put together equal the oracle, flags / rows / counters replicated; svils_validation_row and
     svils_comm_allgather_host (collective staging) with rank > 0"""
     path, n = graph_files["lfr"], 1000
+    if mode == "kshard-astroph":
+        path, n, mode = graph_files["astroph"], 17903, "kshard"
     states, (calls, _) = _run_ranks(tmp_path, path, n, k, sweeps, world, mode)
     ref = _oracle(path, n, k, sweeps, **({"link_thresh": 0.3} if mode == "kshard-lowt" else {}))
     g = np.concatenate([s["gamma"] for s in states], 1)

@@ -399,11 +399,21 @@ def test_lfr_long_run_into_the_active_set_regime(graph_files):
     np.testing.assert_allclose(eng.rows()[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
 
 
+def _testing_lib():
+    """libsvils_testing.so: the product sources + the two test hooks (-DSVILS_TESTING; svinet_amd/build.py: build_testing).
+    The product library does not contain them -- the tests that need a hook run in a child process that binds this build."""
+    path = os.path.join(ROOT_DIR, "svinet_amd", "lib", "libsvils_testing.so")
+    if not os.path.exists(path):
+        from svinet_amd import build
+        build.build_testing()
+    return path
+
+
 def test_in_launch_handoff_timeout_is_loud(graph_files, tmp_path):
     """The classification of a three-launch sweep hands tile counts from worker to worker inside ONE launch, with a
-    bounded wait.  A worker that never publishes (test hook SVILS_FAULT_INJECT=cls_handoff; in the field: role blocks
-    that are not co-resident, e.g. under CU masking) must not hang the device or corrupt the run: the waiters give up,
-    the run freezes where it is and the next call reports SVILS_ERR_DEVICE."""
+    bounded wait.  A worker that never publishes (test hook of the TESTING build, option fault_inject; in the field: role
+    blocks that are not co-resident, e.g. under CU masking) must not hang the device or corrupt the run: the waiters give
+    up, the run freezes where it is and the next call reports SVILS_ERR_DEVICE.  The product library ignores the hook."""
     import subprocess
     import sys
     code = (
@@ -418,18 +428,23 @@ def test_in_launch_handoff_timeout_is_loud(graph_files, tmp_path):
         "except _svils.SvilsError as exc:\n"
         "    print('FAULT', exc.code, str(exc)[:120])\n"
     ) % (ROOT_DIR, graph_files["lfr"])
-    env = dict(os.environ, SVILS_FAULT_INJECT="cls_handoff")
+    env = dict(os.environ, SVILS_FAULT_INJECT="cls_handoff", SVILS_LIB=_testing_lib())
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "FAULT" in r.stdout and "NOFAULT" not in r.stdout, r.stdout
     assert "hand-off" in r.stdout
+    env.pop("SVILS_LIB")                       # the shipped library has no such hook: the same environment changes nothing
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NOFAULT 40" in r.stdout, (r.stdout, r.stderr[-2000:])
 
 
-def test_small_device_keeps_the_four_launch_sweep(graph_files, monkeypatch):
+def test_small_device_keeps_the_four_launch_sweep(graph_files, monkeypatch, tmp_path):
     """The three-launch small-K sweep hands work between workgroups inside a launch, which needs its role blocks
-    co-resident.  Where the device cannot hold them (a CPX partition of 32 CUs; here: SVILS_ASSUME_CUS pretends), or a CU
-    mask hides how many CUs there are, the handle keeps the four-launch sweep (spin-free passes) instead of running into
-    the hand-off's time-out: same results, one k_tail launch per sweep."""
+    co-resident.  Where the device cannot hold them (a CPX partition of 32 CUs; here: the TESTING build's option assume_cus
+    pretends, in a child process), or a CU mask hides how many CUs there are, the handle keeps the four-launch sweep
+    (spin-free passes) instead of running into the hand-off's time-out: same results, one k_tail launch per sweep."""
+    import subprocess
+    import sys
     from svinet_amd.host_api import Setup
     setup = Setup(graph_files["lfr"], 1000, 28)
     a = setup.engine(use_validation_stop=False)
@@ -437,19 +452,45 @@ def test_small_device_keeps_the_four_launch_sweep(graph_files, monkeypatch):
     a.sweep(40)
     a.synchronize()
     assert a.timing()["tail"][1] <= 1        # three launches: the likelihood rides on the next phi launch
-    for env in ({"SVILS_ASSUME_CUS": "16"}, {"HSA_CU_MASK": "0:0-31"}):
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
-        b = setup.engine(use_validation_stop=False)
-        for k_ in env:
-            monkeypatch.delenv(k_)
-        b.enable_timing(1 << 6)
-        b.sweep(40)
-        b.synchronize()
-        assert b.timing()["tail"][1] == 40
-        ga, la, ca = a.state()
-        gb, lb, cb = b.state()
+    ga, la, ca = a.state()
+
+    def same(gb, lb, cb, member, rows):
         np.testing.assert_allclose(gb, ga, rtol=1e-12)
         np.testing.assert_allclose(lb, la, rtol=1e-12)
-        assert np.array_equal(ca, cb) and np.array_equal(a.communities(), b.communities())
-        np.testing.assert_allclose(b.rows()[:, 1:], a.rows()[:, 1:], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(ca, cb) and np.array_equal(a.communities(), member)
+        np.testing.assert_allclose(rows[:, 1:], a.rows()[:, 1:], rtol=1e-11, atol=1e-13)
+
+    # a CU mask: the attribute still counts every CU, so the handle cannot know -- four launches (product library, in process)
+    monkeypatch.setenv("HSA_CU_MASK", "0:0-31")
+    b = setup.engine(use_validation_stop=False)
+    monkeypatch.delenv("HSA_CU_MASK")
+    b.enable_timing(1 << 6)
+    b.sweep(40)
+    b.synchronize()
+    assert b.timing()["tail"][1] == 40
+    same(*b.state(), b.communities(), b.rows())
+    # the `fused3` row of the option table forces either form on a handle that has no graph yet
+    for forced, tails in ((0, 40), (1, 1)):
+        c = setup.engine(use_validation_stop=False, options={"fused3": forced})
+        c.enable_timing(1 << 6)
+        c.sweep(40)
+        c.synchronize()
+        assert (c.timing()["tail"][1] == 40) if tails == 40 else (c.timing()["tail"][1] <= 1)
+        same(*c.state(), c.communities(), c.rows())
+    # a device of 16 CUs: the TESTING build pretends
+    out = str(tmp_path / "small.npz")
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from svinet_amd.host_api import Setup\n"
+        "s = Setup(%r, 1000, 28)\n"
+        "e = s.engine(use_validation_stop=False)\n"
+        "e.enable_timing(1 << 6); e.sweep(40); e.synchronize()\n"
+        "g, lam, conv = e.state()\n"
+        "np.savez(%r, g=g, lam=lam, conv=conv, member=e.communities(), rows=e.rows(), tails=e.timing()['tail'][1])\n"
+    ) % (ROOT_DIR, graph_files["lfr"], out)
+    env = dict(os.environ, SVILS_ASSUME_CUS="16", SVILS_LIB=_testing_lib())
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out)
+    assert int(z["tails"]) == 40
+    same(z["g"], z["lam"], z["conv"], z["member"], z["rows"])

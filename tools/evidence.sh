@@ -16,7 +16,8 @@
 #   pytest       the whole -m gpu suite          (PYTEST_ARGS adds arguments, e.g. PYTEST_ARGS="-k config5"; PYTEST_PATHS
 #                replaces `tests` by a list of files)
 #   kscan        tools/k_scan.sh
-#   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations
+#   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations -> shard_cost_model.json
+#   pmc-shard    rocprofv3 kernel stats + --pmc FETCH_SIZE / WRITE_SIZE passes of rank 0 of 8 in both sharded layouts -> per-kernel roofline table
 #   cli          bench.py's cli_end_to_end record alone
 #   forced       bench.py --force-sharded (real librccl, world of one) on ca-AstroPh K=20 and K=200: sharded driver vs plain engine
 #   cli5         tools/cli_config5.py (the binary at config-5 size): 4 sweeps with -no-stop, then the default flags
@@ -71,15 +72,34 @@ for step in "$@"; do
     native) timeout 2400 python -m pytest tests/test_gpu_native_ranks.py tests/test_gpu_fakerccl_async.py -q -m gpu --timeout 900 $PYTEST_ARGS > $O/pytest_native.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_native.txt; tail -25 $O/pytest_native.txt ;;
     pytest) timeout 3000 python -m pytest ${PYTEST_PATHS:-tests} -q -m gpu --timeout 900 --durations=15 $PYTEST_ARGS > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -25 $O/pytest_gpu.txt ;;
     kscan) bash tools/k_scan.sh 2>&1 | tee $O/k_scan_astroph.txt ;;
-    shardcost)
+    shardcost)   # the cost model's inputs on one GPU -> shard_cost_model.json (what bench.py prints as `model` beside every N > 1 record)
       (cd /tmp; export TMPDIR=/tmp
+       for wl in astroph-k20 astroph-k200 synthetic:200000:512:24 mmsb:1000000:512:24; do
+         t=$(echo $wl | tr ':' '_')
+         python $R/tools/shard_cost.py $wl 2,4,8 --json $O/shard_cost_model.json 2>/dev/null | tee -a $O/shard_cost_model_inputs.txt
+       done
        for wl in astroph-k200 mmsb:1000000:512:24; do
          t=$(echo $wl | tr ':' '_')
-         python $R/tools/shard_cost.py $wl 2,4,8 2>/dev/null | tee -a $O/shard_cost_model_inputs.txt
          rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$t -o p -- python $R/tools/shard_cost.py $wl 8 > /dev/null 2>&1
          f=$(find $O/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/shard_rank0of8_kernel_stats_$t.csv
          rm -rf $O/prof_$t
        done) ;;
+    pmc-shard)   # roofline records of the kernels a SHARDED run executes: rank 0 of 8 of config 5 in both layouts, config 4 K-sharded
+      ARGS=""
+      for spec in "mmsb:1000000:512:24 kshard 8 0" "mmsb:1000000:512:24 nodeblock 8 0" "astroph-k200 kshard 8 0" "astroph-k200 nodeblock 8 0"; do
+        set -- $spec; w=$(echo $1 | tr ':' '_')_$2_r$4of$3
+        (cd /tmp && export TMPDIR=/tmp
+         timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$w -o p -- python $R/tools/shard_rank.py $spec 6 > $O/shard_rank_$w.log 2>&1
+         timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf_$w -o p -- python $R/tools/shard_rank.py $spec 6 > /dev/null 2>&1
+         timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw_$w -o p -- python $R/tools/shard_rank.py $spec 6 > /dev/null 2>&1)
+        f=$(find $O/st_$w -name '*kernel_stats.csv' | head -1); cp $f $O/shard_${w}_kernel_stats.csv
+        find $O/pf_$w $O/pw_$w -type f ! -name "*counter_collection.csv" -delete
+        ARGS="$ARGS $w $O/shard_${w}_kernel_stats.csv $O/pf_$w $O/pw_$w"
+        tail -1 $O/shard_rank_$w.log
+      done
+      set -- dummy
+      python tools/pmc_sharded.py $O/traffic_sharded.json $O/sharded_roofline_pmc.txt $ARGS
+      rm -rf $O/st_* $O/pf_* $O/pw_* ;;
     forced)   # the N > 1 driver of bench.py on the REAL librccl with a world of one (eager window, then hipGraph replay with the collectives captured)
       for wl in astroph-k20 astroph-k200; do
         timeout 600 python bench.py --force-sharded --workload $wl --no-cpu-baseline --no-extra > $O/bench_force_sharded_world1_$wl.json 2>> $O/bench_forced.err

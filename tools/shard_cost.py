@@ -4,7 +4,10 @@
 only), next to the plain engine, plus the bytes each layout exchanges per sweep and a predicted sweep time on
 G = 2, 4, 8 GPUs from a stated link model.  Nothing here is a multi-GPU measurement.
 
-  python tools/shard_cost.py [workload] [G,G,...]
+  python tools/shard_cost.py [workload] [G,G,...] [--json FILE]
+
+--json FILE merges this workload's rows into FILE (profiles/shard_cost_model.json: what bench.py prints as `model` beside every
+N > 1 record -- key "<workload>|<nodeblock or kshard>|<G>").
 
 Link model (MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point): a rank sends / receives over all
 its links at once at EFF = 300 GB/s aggregate when the collective uses them all (all-gather / broadcast of node blocks
@@ -22,12 +25,20 @@ from bench import _load_workload
 from svinet_amd import _svils
 from svinet_amd.sharded import balanced_bounds, equal_bounds
 
-wl = sys.argv[1] if len(sys.argv) > 1 else "astroph-k200"
-Gs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 4, 8]
+import json
+argv = list(sys.argv[1:])
+json_out = None
+if "--json" in argv:
+    i = argv.index("--json")
+    json_out = argv[i + 1]
+    del argv[i:i + 2]
+wl = argv[0] if len(argv) > 0 else "astroph-k200"
+Gs = [int(x) for x in argv[1].split(",")] if len(argv) > 1 else [2, 4, 8]
+rows = {}
 EFF, LAT = 300e9, 20e-6
 setup, _, _, n, k, _ = _load_workload(wl)
 L, V = int(setup.nlinks), int(setup.validation_sorted.shape[0])
-ld = (k + 15) // 16 * 16
+ld = (k + 15) // 16 * 16 if k > 56 else (k + 1) // 2 * 2     # the engine's row stride (packed rows at K <= 56)
 steps = 20 if n * k < 5e7 else 6
 
 
@@ -87,6 +98,13 @@ for G in Gs:
     t_pred = (t_nb - t_exp) + max(t_exp, link_time(rows_total * (G - 1) / G, G, 1)) + link_time(2 * kvec * (G - 1) / G, G, 1)
     print("node-block  %2d   %10.3f        %8.3f          %7.1f MB all-gather + %5.1f KB all-reduce   %6d    %8.3f    %10.3f        %6.2fx"
           % (G, t_nb, t_exp, rows_total / 1e6, kvec / 1e3, 2, t_link, t_pred, t_plain / t_pred))
+    rows["%s|nodeblock|%d" % (wl, G)] = {
+        "predicted_ms_per_step": t_pred, "compute_ms_per_rank": t_nb, "of_which_expand_ms": t_exp, "plain_engine_ms_per_step": t_plain,
+        "predicted_speedup_vs_one_gpu": t_plain / t_pred, "bytes_exchanged_per_step": rows_total + 2 * kvec, "collectives_per_step": 2,
+        "exposed_link_ms": max(t_exp, link_time(rows_total * (G - 1) / G, G, 1)) - t_exp + link_time(2 * kvec * (G - 1) / G, G, 1),
+        "csr_entries_max_over_mean": float(ent.max() / ent.mean()),
+        "how": "max over the measured ranks of {phi, light finalise, expand-all, s3, tail} launched back to back on ONE GPU with no exchange; "
+               "row exchange pipelined against the expansion (the longer of the two stays exposed) + one K-vector all-reduce"}
     print("#   balance: CSR entries per rank / mean = %s (equal-count blocks: %s); compute per measured rank (ms): %s"
           % (" ".join("%.2f" % x for x in ent / ent.mean()), " ".join("%.2f" % x for x in ent_eq / ent_eq.mean()),
              " ".join("r%d %.3f" % (r, t) for r, t in zip(ranks, t_rank))))
@@ -113,3 +131,24 @@ for G in Gs:
     t_pred = t_ks + t_link
     print("K-sharded   %2d   %10.3f        %8s          %7.1f MB all-reduce (den %s rowx q2 vdot)          %6d    %8.3f    %10.3f        %6.2fx"
           % (G, t_ks, "-", ar / 1e6, "+dmax" if log else "", ncoll, t_link, t_pred, t_plain / t_pred))
+    rows["%s|kshard|%d" % (wl, G)] = {
+        "predicted_ms_per_step": t_pred, "compute_ms_per_rank": t_ks, "plain_engine_ms_per_step": t_plain,
+        "predicted_speedup_vs_one_gpu": t_plain / t_pred, "bytes_exchanged_per_step": ar, "collectives_per_step": ncoll,
+        "exposed_link_ms": t_link,
+        "how": "rank 0 of G: every phase of a K-sharded sweep launched back to back on ONE GPU with no exchange; + %d all-reduces "
+               "(reduce-scatter + all-gather) of the coupling buffers, not overlapped" % ncoll}
+if json_out:
+    doc = {"rows": {}}
+    if os.path.exists(json_out):
+        try:
+            doc = json.load(open(json_out))
+        except Exception:
+            pass
+    doc.setdefault("rows", {}).update(rows)
+    doc["link_model"] = {"eff_GBps": EFF / 1e9, "lat_us": LAT * 1e6,
+                         "what": "a rank moves EFF aggregate over its xGMI links when a collective uses all 7 of them, EFF x (G-1)/7 with fewer "
+                                 "peers; every collective costs LAT on top; all-gather of S: S (G-1)/G received; all-reduce of M: 2 M (G-1)/G moved. "
+                                 "ASSUMPTIONS, nothing on real links has been measured"}
+    doc["source"] = "tools/shard_cost.py (per-rank compute measured on one MI355X, commit %s)" % os.environ.get("EVIDENCE_COMMIT", "?")
+    with open(json_out, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
