@@ -39,6 +39,35 @@ int fault_error(uint32_t code) {
   return fail(SVILS_ERR_DEVICE, "an in-launch hand-off between workgroups timed out (role blocks not co-resident on this device); the state is frozen");
 }
 
+int elogpi_rows(svils_handle *h, double **rows) {
+  *rows = h->d.elogpi;
+  if (h->d.ksh && !h->d.ksh_log) {   // K-sharded, product form: no stored Elogpi either -- from gamma and the summed row sums
+    if (!h->elogpi_view) {
+      int rc = dalloc(h, &h->elogpi_view, (size_t)h->geo.n_alloc * h->geo.ld);
+      if (rc) return rc;
+    }
+    DeviceState dv = h->d;
+    dv.elogpi = h->elogpi_view;
+    dv.epi = nullptr;
+    launch_ksh_phase(h->geo, dv, h->prm, 6, h->stream);
+    HIPCHK(hipGetLastError());
+    *rows = h->elogpi_view;
+    return 0;
+  }
+  if (!h->d.skip_elogpi) return 0;
+  if (!h->elogpi_view) {
+    int rc = dalloc(h, &h->elogpi_view, (size_t)h->geo.n_alloc * h->geo.ld);
+    if (rc) return rc;
+  }
+  DeviceState dv = h->d;
+  dv.elogpi = h->elogpi_view;
+  dv.epi = nullptr;                       // (k_dir_exp leaves the exp(Elogpi) rows of the state alone)
+  launch_dir_exp(h->geo, dv, h->stream);
+  HIPCHK(hipGetLastError());
+  *rows = h->elogpi_view;
+  return 0;
+}
+
 void drop_graphs_of(svils_handle *h) {
   for (auto &g_ : h->sgexec) if (g_) { (void)hipGraphExecDestroy(g_); g_ = nullptr; }
   if (h->gexec1) { (void)hipGraphExecDestroy(h->gexec1); h->gexec1 = nullptr; }
@@ -221,6 +250,8 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
     guard(dalloc(h, &d.rowx, 3 * (size_t)g.n));
     guard(dalloc(h, &d.q2v, g.Kt));
   }
+  d.skip_elogpi = (!d.ksh && d.epi && !use_lpl(g.K) && g.K <= 512u && cfg->link_thresh >= 0.5) ? 1 : 0;   // svils_internal.h
+  if (d.skip_elogpi) d.gacc = d.elogpi;   // (the array is free: nothing stores or reads Elogpi rows on such a handle)
   guard(dalloc(h, &d.mphi, nk));
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));
   guard(dalloc(h, &d.active_cnt, g.n_alloc));
@@ -767,9 +798,14 @@ int svils_get_aux(svils_handle *h, int which, void *out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   const Geometry &g = h->geo;
   switch (which) {
-    case 0:
-      HIPCHK(hipMemcpy2D(out, g.K * sizeof(double), h->d.elogpi, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
+    case 0: {
+      double *el = nullptr;
+      int rc = elogpi_rows(h, &el);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(h->stream));
+      HIPCHK(hipMemcpy2D(out, g.K * sizeof(double), el, g.ld * sizeof(double), g.K * sizeof(double), g.n, hipMemcpyDeviceToHost));
       return 0;
+    }
     case 1:
       HIPCHK(hipMemcpy(out, h->d.elogbeta, 2 * (size_t)g.K * sizeof(double), hipMemcpyDeviceToHost));
       return 0;
@@ -884,7 +920,12 @@ int svils_device_buffer(svils_handle *h, svils_buffer which, void **dptr, size_t
     case SVILS_BUF_KVEC_A: *dptr = d.kvec_a; *bytes = g.K * sizeof(double); *row_bytes = *bytes; return 0;
     case SVILS_BUF_KVEC_C: *dptr = d.kvec_c; *bytes = 3 * (size_t)g.K * sizeof(double); *row_bytes = *bytes; return 0;
     case SVILS_BUF_GAMMA: *dptr = d.gamma; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
-    case SVILS_BUF_ELOGPI: *dptr = d.elogpi; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
+    case SVILS_BUF_ELOGPI: {   // (computed at this call on a handle that does not store them: DeviceState::skip_elogpi)
+      double *el = nullptr;
+      int rc = elogpi_rows(h, &el);
+      if (rc) return rc;
+      *dptr = el; *row_bytes = g.ld * sizeof(double); *bytes = *row_bytes * g.n_alloc; return 0;
+    }
     case SVILS_BUF_MPHI:
       if (h->mphi_stale) {
         launch_mphi_from_gamma(h->geo, h->d, h->prm, h->stream);

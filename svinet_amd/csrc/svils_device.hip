@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : V <= 1
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double lds[V * 64];
+  __shared__ double2 logtab[PROD ? 128 : 1];   // (the underflow fall-back of a handle that does not store Elogpi evaluates psi itself)
+  if constexpr (PROD) {
+    if (d.skip_elogpi) { load_logtab(logtab, d.logtab); __syncthreads(); }
+  }
   // wave-uniform by construction; said so explicitly, or the compiler keeps the item loop and the neighbour loop
   // under exec masks with vector compares (it cannot see that threadIdx.x >> 6 is the same in all 64 lanes)
   // (measured: V = 4: phi -10 % and 96 instead of 111 VGPRs; V = 8: neutral; V <= 2: +7 %, left alone)
@@ -198,9 +202,25 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : V <= 1
           bool live = true;
           if (s < 1e-280) {   // wave-uniform, rare: the log-domain rows from Elogpi, column by column to
                               // keep the registers of the common path (two passes: max, then exp)
+            // (DeviceState::skip_elogpi: no stored Elogpi -- psi(gamma) - psi(row sum) of the two rows, the row sums added in
+            //  the order k_finalize adds them, so the values are the ones it would have stored)
+            double psp = 0.0, psq = 0.0;
+            if (d.skip_elogpi) {
+              double sp = 0.0, sq = 0.0;
+#pragma unroll 1
+              for (int v = 0; v < V; ++v)
+                if (kval[v]) { sp += d.gamma[(size_t)p * ld + kidx[v]]; sq += d.gamma[(size_t)q * ld + kidx[v]]; }
+              psp = digamma(group_sum<W>(sp), logtab);
+              psq = digamma(group_sum<W>(sq), logtab);
+            }
             auto xlog = [&](int v) {
               double t = NEG_INF;
-              if (kval[v]) t = (d.elogpi[(size_t)p * ld + kidx[v]] + d.elogbeta[2 * kidx[v]]) + d.elogpi[(size_t)q * ld + kidx[v]];
+              if (kval[v]) {
+                if (d.skip_elogpi)
+                  t = ((digamma(d.gamma[(size_t)p * ld + kidx[v]], logtab) - psp) + d.elogbeta[2 * kidx[v]]) +
+                      (digamma(d.gamma[(size_t)q * ld + kidx[v]], logtab) - psq);
+                else t = (d.elogpi[(size_t)p * ld + kidx[v]] + d.elogbeta[2 * kidx[v]]) + d.elogpi[(size_t)q * ld + kidx[v]];
+              }
               if (sparse) {
                 const uint64_t um = d.amask[(size_t)p * geo.kw + v] | d.amask[(size_t)q * geo.kw + v];
                 t = ((um >> lw) & 1ull) ? t : NEG_INF;
@@ -533,7 +553,7 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
 #pragma unroll
       for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
     }
-    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    if (!d.skip_elogpi) store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     store_epi<W, V>(d, p, lw, ld, K, el);
     // prune / check_and_set_converged, src/linksampling.cc:455-475
     uint32_t active = 0;
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(256) void k_expand(Geometry geo, DeviceState d, Par
 #pragma unroll
       for (int v = 0; v < V; ++v) m[v] = 0.0;
     }
-    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    if (!d.skip_elogpi) store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     store_epi<W, V>(d, p, lw, ld, K, el);
     store_row<W, V>(d.mphi + (size_t)p * ld, lw, ld, m);
     if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
@@ -743,7 +763,7 @@ __global__ __launch_bounds__(256) void k_expand_all(Geometry geo, DeviceState d,
     double el[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) el[v] = kval[v] ? digamma(gn[v], logtab) - psi_rs : 0.0;
-    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    if (!d.skip_elogpi) store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     store_epi<W, V>(d, p, lw, ld, K, el);
     // prune / check_and_set_converged, src/linksampling.cc:455-475
     uint32_t active = 0;
@@ -1036,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_expand_window(Geometry geo, DeviceState
     double el[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) el[v] = (uint32_t)kmap<W, V>(lw, v) < K ? digamma(gn[v], logtab) - psi_rs : 0.0;
-    store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
+    if (!d.skip_elogpi) store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
     store_epi<W, V>(d, p, lw, ld, K, el);
     if (lw == 0) unpack_flags<V>(geo, d, ctrl, p);
   }

@@ -126,6 +126,7 @@ struct svils_handle {
   hipGraphExec_t gexecP[kGraphMaxLog + 1] = {};        // [i]: 2^i sweeps (i = 0 and 3 stay null: gexec1, gexecN)
   bool graphs_ok = true;                               // false after a capture failure: stay eager
   uint32_t graph_after = 128;                          // sweeps a handle runs eagerly before it captures graphs (svils_sweep)
+  double *elogpi_view = nullptr;   // DeviceState::skip_elogpi: where svils_get_aux(0) / SVILS_BUF_ELOGPI get their Elogpi rows computed
   std::vector<void *> allocs;
   // pipelined reports (svils_report_enqueue): staging slots, a copy stream, per-slot events
   struct ReportSlot {
@@ -224,6 +225,7 @@ inline int settle(svils_handle *h) {
 int drain_timing(svils_handle *h);
 int fault_error(uint32_t code);
 void drop_graphs_of(svils_handle *h);
+int elogpi_rows(svils_handle *h, double **rows);   // the Elogpi rows of the state as it stands (computed now where a handle does not store them)
 void chunk_row(std::vector<Item> &items, uint32_t p, uint32_t off, uint32_t len, uint32_t ch,
                int32_t *next_slot, int32_t *first_slot, uint32_t *nsplit);
 // (node, community) pairs of a lane-layout community bitmask [n][kw]; counts them all, writes at most `cap`

@@ -155,6 +155,13 @@ struct DeviceState {
   double *s12run;       // [2K]     mini-batch mode: running s1, s2 over the stored mphi rows
   double *elogpi;       // [n_alloc][ld]
   double *epi;          // [n_alloc][ld] exp(Elogpi), K > 56 only (k_phi<V, false, true>); null otherwise
+  // 57 <= K <= 512 with exp(Elogpi) rows and link_thresh >= 1/2: NOTHING in a sweep reads Elogpi -- the phi pass multiplies
+  // exp(Elogpi) rows, the likelihood and the s3 pass read gamma -- so the finalise / expand passes do not store it (one n-by-k
+  // write less per sweep: 4.1 of 16.4 GB of the finalise launch at n = 1e6, k = 512).  The phi pass's underflow fall-back
+  // (a row product below 1e-280: out of reach below K ~ 600, where psi(1/K) > -600) re-derives the two rows from gamma --
+  // which is why such a handle accumulates gammanext in the buffer Elogpi used to occupy (gacc = elogpi) instead of in place:
+  // gamma stays intact during the phi pass.  svils_get_aux(0) / SVILS_BUF_ELOGPI compute a view on demand (k_dir_exp).
+  int skip_elogpi;
   // K-sharded sweeps (svils_ksh.h): what crosses ranks, each buffer summed over the ranks between two phases
   int ksh;              // 1: the handle holds a column slice
   uint32_t *elink;      // [2L]  training-link index of every CSR entry

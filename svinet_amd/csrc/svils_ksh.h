@@ -11,8 +11,11 @@
 //   DEN   k_phi_ksh<V,1>   den[link] = sum over own columns of e^x_k             -> SUM den        (L doubles)
 //   PHI   k_phi_ksh<V,2>   gammanext rows from e^x_k / den, `sum`, tags; k_colreduce; k_fin1_ksh:
 //                          mean indicators, gamma, partial row sums / active counts -> SUM rowx    (3n doubles)
-//   FIN2  k_fin2_ksh       Elogpi, exp(Elogpi), flags; k_s3_ksh + k_colreduce (Q2 across the slice edge)
-//                                                                                 -> SUM q2v       (Kt doubles)
+//                          and -- product form -- the exp(Elogpi) rows of the NEXT sweep: the softmax of a link does not see
+//                          a constant added to a row, so psi(gamma) is shifted by psi of the row sum the ranks ALREADY share
+//                          (last sweep's, in rowx) instead of waiting for this sweep's: no second pass over the rows
+//   FIN2  k_flags_ksh      prune() flags from the summed rowx (O(n); log-domain mode: k_fin2_ksh, Elogpi rows shifted by THIS
+//                          sweep's row sum); k_s3_ksh + k_colreduce (Q2 across the slice edge)  -> SUM q2v       (Kt doubles)
 //   LAM   k_lam_ksh        lambda, Elogbeta of own columns; k_vdot_ksh partial dot products -> SUM vdot (nv doubles)
 //   STOP  k_stop_ksh       likelihood row, stop rule, annealing switch, loop control (replicated)
 namespace svils {
@@ -84,13 +87,20 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
       return ((pc != 0) == (cc != 0)) && (MODE == 2 || qq > p || d.ksh_ent);   // MODE 0 and 1: one value per undirected link
     };
     double r[V], rnext[V];
-    if (len > 0 && needs_row(0)) load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, 0) * ld, lw, ld, r);
+    // (MODE 2: the link's summed denominator travels with its row -- requested one neighbour ahead, like the row)
+    double dcur = 1.0, dnext = 1.0;
+    if (len > 0 && needs_row(0)) {
+      load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, 0) * ld, lw, ld, r);
+      if constexpr (MODE == 2) dcur = d.den[__builtin_amdgcn_readlane(myel, 0)];
+    }
     for (uint32_t j = 0; j < len; ++j) {
       const uint32_t q = __builtin_amdgcn_readlane(mycol, j);
       const uint32_t qc = __builtin_amdgcn_readlane(myconv, j);
       const uint32_t el = __builtin_amdgcn_readlane(myel, j);
-      if (j + 1 < len && needs_row(j + 1))
+      if (j + 1 < len && needs_row(j + 1)) {
         load_row<W, V>(epi + (size_t)__builtin_amdgcn_readlane(mycol, j + 1) * ld, lw, ld, rnext);
+        if constexpr (MODE == 2) dnext = d.den[__builtin_amdgcn_readlane(myel, j + 1)];
+      }
       const bool count_me = q > p;
       bool handled = false;
       if ((pc != 0) != (qc != 0)) {
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
         s = group_sum<W>(s);
         if (lane == 0) d.den[el] = s;
       } else {
-        s = d.den[el];   // the link's denominator over ALL columns
+        s = dcur;        // the link's denominator over ALL columns (den[el], requested with the row)
         // a denominator that underflowed (possible only for rows of disjoint support at very large K): the product form
         // has no way back -- say so instead of dropping the link (the log-domain mode cannot get here: its sum is >= 1)
         if (!LOG && s < 1e-280 && !(sparse && s == 0.0)) ctrl->fault = 2u;
@@ -184,6 +194,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh(Geometry geo, DeviceState d, Pa
       }
 #pragma unroll
       for (int v = 0; v < V; ++v) r[v] = rnext[v];
+      dcur = dnext;
     }
     if constexpr (MODE == 2) {
 #pragma unroll
@@ -288,13 +299,22 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
     uint32_t q, qc, el;
     bool need;
     bool valid = mine(0, q, qc, el, need);
-    if (need) load_row<W, V>(epi + (size_t)q * ld, lw, ld, r);
+    // (MODE 2: the link's summed denominator is requested with its row, four neighbours ahead of its use)
+    double dcur = 1.0, dnext = 1.0;
+    if (need) {
+      load_row<W, V>(epi + (size_t)q * ld, lw, ld, r);
+      if constexpr (MODE == 2) dcur = d.den[el];
+    }
     for (uint32_t j = 0; j < len; j += 4) {
       uint32_t q1 = 0, qc1 = 0, el1 = 0;
       bool need1 = false, valid1 = false;
+      dnext = 1.0;
       if (j + 4 < len) {
         valid1 = mine(j + 4, q1, qc1, el1, need1);
-        if (need1) load_row<W, V>(epi + (size_t)q1 * ld, lw, ld, rnext);
+        if (need1) {
+          load_row<W, V>(epi + (size_t)q1 * ld, lw, ld, rnext);
+          if constexpr (MODE == 2) dnext = d.den[el1];
+        }
       }
       const bool count_me = valid && lw == 0 && q > p;
       if constexpr (MODE == 2) {
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
           s = group_sum<W>(s);
           if (need && lw == 0) d.den[el] = s;
         } else {
-          s = need ? d.den[el] : 1.0;   // the link's denominator over ALL columns
+          s = need ? dcur : 1.0;        // the link's denominator over ALL columns (den[el], requested with the row)
           if (need && s < 1e-280 && !(sparse && s == 0.0)) ctrl->fault = 2u;   // see k_phi_ksh
           const bool live = need && s > 0.0;
           const double inv = live ? fast_rcp(s) : 0.0;
@@ -343,6 +363,7 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
         }
       }
       q = q1; qc = qc1; el = el1; need = need1; valid = valid1;
+      dcur = dnext;
 #pragma unroll
       for (int v = 0; v < V; ++v) r[v] = rnext[v];
     }
@@ -395,14 +416,18 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
 // W = 64: one node per wavefront, V columns per lane.  W = 16, V = 4 (slices of <= 64 columns, see k_phi_ksh16): FOUR
 // nodes per wavefront, one per 16-lane row, so that a 512-byte row does not pay a wavefront's fixed costs alone and
 // every lane carries four independent chains.
+// fuse (product form, sweeps and steps): this kernel also leaves what k_fin2_ksh would -- the exp(Elogpi) row of the new gamma,
+// shifted by psi of the row sum every rank already holds (rowx[3p] still carries the SUMMED row sum of the previous state here;
+// any per-row constant cancels in a link's softmax, and this one is the same on every rank) -- and the row's active-set
+// candidate bits; what needs the summed rowx of THIS state (the flags) follows in k_flags_ksh, O(n).
 template <int W, int V, bool STOCH>
-__global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, Params prm, int init) {
+__global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, Params prm, int init, int fuse) {
   constexpr int G = 64 / W;
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   __shared__ double lds[2 * V * 64];
   __shared__ double2 logtab[128];
-  if constexpr (STOCH) { load_logtab(logtab, d.logtab); __syncthreads(); }
+  if (STOCH || fuse) { load_logtab(logtab, d.logtab); __syncthreads(); }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
@@ -509,6 +534,29 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
         for (int v = 0; v < V; ++v) gn[v] = kval[v] ? prm.alpha : 0.0;
       }
       if (ok) store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
+      if (fuse) {
+        const double psi_prev = digamma(d.rowx[3 * (size_t)p], logtab);
+        double ep[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) ep[v] = kval[v] ? exp_neg(digamma(gn[v], logtab) - psi_prev) : 0.0;
+        if (ok) store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, ep);
+        // the active-set candidates of the row (k_flags_ksh clears them where the whole row has more than K / 10)
+        if constexpr (W == 64) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const unsigned long long bits = __ballot(kval[v] && (gn[v] - prm.alpha >= 1.0));
+            if (lw == 0) d.amask[(size_t)p * geo.kw + v] = bits;
+          }
+        } else {                          // one word per node: bit k = column k of the slice
+          unsigned long long w = 0ull;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (kval[v] && (gn[v] - prm.alpha >= 1.0)) w |= 1ull << kidx[v];
+#pragma unroll
+          for (int o = 1; o < W; o <<= 1) w |= (unsigned long long)__shfl_xor((long long)w, o, 64);
+          if (lw == 0 && ok) d.amask[p] = w;
+        }
+      }
     }
     double rs = 0.0, na = 0.0, ix = 0.0;
 #pragma unroll
@@ -556,7 +604,7 @@ __global__ __launch_bounds__(256) void k_fin2_ksh(Geometry geo, DeviceState d, P
     }
     if (ok) {
       store_row<W, V>(d.elogpi + (size_t)p * ld, lw, ld, el);
-      store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, ep);
+      if (d.epi) store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, ep);
     }
     if (init) continue;
     const uint32_t active = (uint32_t)d.rowx[3 * (size_t)p + 1];
@@ -583,6 +631,23 @@ __global__ __launch_bounds__(256) void k_fin2_ksh(Geometry geo, DeviceState d, P
       conv_new[p] = (active == 1u) ? idx : conv_old[p];
       d.active_cnt[p] = active;
     }
+  }
+}
+
+// prune (src/linksampling.cc:455-491) from the summed rowx alone -- the product form's second half of the finalise pass
+// (k_fin1_ksh left the exp(Elogpi) rows and the active-set candidates): one thread per node.
+__global__ __launch_bounds__(256) void k_flags_ksh(Geometry geo, DeviceState d) {
+  const DevCtrl *ctrl = d.ctrl;
+  if (ctrl->stopped) return;
+  const uint32_t *__restrict__ conv_old = d.conv + (size_t)ctrl->parity * geo.n_alloc;
+  uint32_t *__restrict__ conv_new = d.conv + (size_t)(ctrl->parity ^ 1u) * geo.n_alloc;
+  for (uint32_t p = geo.node_begin + blockIdx.x * blockDim.x + threadIdx.x; p < geo.node_end; p += gridDim.x * blockDim.x) {
+    const uint32_t active = (uint32_t)d.rowx[3 * (size_t)p + 1];
+    const uint32_t idx = (uint32_t)d.rowx[3 * (size_t)p + 2];
+    conv_new[p] = (active == 1u) ? idx : conv_old[p];
+    d.active_cnt[p] = active;
+    if (active > geo.k10)
+      for (uint32_t v = 0; v < geo.kw; ++v) d.amask[(size_t)p * geo.kw + v] = 0ull;
   }
 }
 
@@ -916,22 +981,28 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
 #undef CALL
       }
       launch_reduce_a(g, d, s);
+      const int fuse = d.ksh_log ? 0 : 1;   // product form: the exp(Elogpi) rows come out of this pass (see k_fin1_ksh)
 #define CALL(V_)                                                                                            \
   do {                                                                                                      \
-    if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<64, V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);  \
-    else hipLaunchKernelGGL((k_fin1_ksh<64, V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);        \
+    if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<64, V_, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0, fuse);  \
+    else hipLaunchKernelGGL((k_fin1_ksh<64, V_, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0, fuse);        \
   } while (0)
       if (narrow) {
-        if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<16, 4, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);
-        else hipLaunchKernelGGL((k_fin1_ksh<16, 4, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0);
+        if (p.stoch) hipLaunchKernelGGL((k_fin1_ksh<16, 4, true>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0, fuse);
+        else hipLaunchKernelGGL((k_fin1_ksh<16, 4, false>), dim3(d.nb_b), dim3(256), 0, s, g, d, p, 0, fuse);
       } else KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;
     case 2: {   // second half of the finalise pass, s3
+      if (!d.ksh_log) {
+        const uint32_t nbf = std::max(1u, std::min(1024u, (nodes + 255u) / 256u));
+        hipLaunchKernelGGL(k_flags_ksh, dim3(nbf), dim3(256), 0, s, g, d);
+      } else {
 #define CALL(V_) hipLaunchKernelGGL((k_fin2_ksh<64, V_>), dim3(nbn), dim3(256), 0, s, g, d, p, 0)
-      if (narrow) hipLaunchKernelGGL((k_fin2_ksh<16, 4>), dim3(nbn), dim3(256), 0, s, g, d, p, 0);
-      else KSH_DISPATCH(g, CALL);
+        if (narrow) hipLaunchKernelGGL((k_fin2_ksh<16, 4>), dim3(nbn), dim3(256), 0, s, g, d, p, 0);
+        else KSH_DISPATCH(g, CALL);
 #undef CALL
+      }
       if (p.stoch) launch_carry_flags(g, d, s);   // rows outside the window keep their converged flag across the parity flip
       if (g.V == 1 && KSH_NARROW) hipLaunchKernelGGL(k_s3_ksh16, dim3(d.nb_c), dim3(256), 0, s, g, d);
       else {
@@ -958,8 +1029,8 @@ void launch_ksh_phase(const Geometry &g, const DeviceState &d, const Params &p, 
       hipLaunchKernelGGL(k_stop_ksh, dim3(1), dim3(256), 0, s, g, d, p, nvb);
     } break;
     case 5: {   // initial state: partial row sums of the gamma just set
-#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<64, V_, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1)
-      if (narrow) hipLaunchKernelGGL((k_fin1_ksh<16, 4, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1);
+#define CALL(V_) hipLaunchKernelGGL((k_fin1_ksh<64, V_, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1, 0)
+      if (narrow) hipLaunchKernelGGL((k_fin1_ksh<16, 4, false>), dim3(nbn), dim3(256), 0, s, g, d, p, 1, 0);
       else KSH_DISPATCH(g, CALL);
 #undef CALL
     } break;

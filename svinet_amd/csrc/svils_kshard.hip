@@ -75,6 +75,13 @@ int svils_ksh_log_domain(svils_handle *h, int on) {
   if (!h->d.ksh) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: not a K-sharded handle");
   if (on < 0) return h->d.ksh_log;   // query
   if (!on && h->d.ksh_lowt) return fail(SVILS_ERR_ARG, "svils_ksh_log_domain: link_thresh < 1/2 needs the log-domain exchange (it carries the link's maximum)");
+  if (on && !h->d.ksh_log && h->sweeps_issued > 0) {
+    // the product form keeps no Elogpi rows (k_fin1_ksh writes the exp(Elogpi) rows of the next sweep itself): bring them up
+    // to date from gamma and the summed row sums of the last sweep before the log-domain kernels read them
+    HIPCHK(hipSetDevice(h->cfg.device));
+    launch_ksh_phase(h->geo, h->d, h->prm, 6, h->stream);
+    HIPCHK(hipGetLastError());
+  }
   h->d.ksh_log = on ? 1 : 0;
   return 0;
 }

@@ -499,10 +499,10 @@ def test_bench_multi_gpu_code_path_two_ranks(tmp_path):
 def test_bench_side_record_that_hangs_does_not_cost_the_line(tmp_path):
     """a side record that never comes back (here: a test hook; on a node: a collective that blocks) is caught by the
     per-record watchdog: the JSON line still carries the headline value, the records measured before it, an error entry
-    for the hung one and "not run" for those behind it; every rank exits"""
+    for the hung one and "not run" for those behind it (bench.SIDE_RECORDS gives the order); every rank exits"""
     import json
     env = _env(tmp_path)
-    env["BENCH_TEST_HANG_RECORD"] = "minibatch_steps_astroph_k20"
+    env["BENCH_TEST_HANG_RECORD"] = "ksharded_config4_astroph_k200"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--test-one-gpu",
@@ -514,7 +514,9 @@ def test_bench_side_record_that_hangs_does_not_cost_the_line(tmp_path):
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["n_gpus"] == 2
     ex = out["sharded_extra"]
-    assert ex["config4_astroph_k200"]["value"] > 0
-    assert "did not finish" in ex["minibatch_steps_astroph_k20"]["error"]
-    assert "not run" in ex["ksharded_config4_astroph_k200"]["error"]
+    assert list(ex)[:1] == ["config4_astroph_k200"] and ex["config4_astroph_k200"]["value"] > 0
+    assert ex["config4_astroph_k200"]["model_ms_per_step"] > 0          # the cost model's prediction beside the record
+    assert "did not finish" in ex["ksharded_config4_astroph_k200"]["error"]
+    assert "not run" in ex["minibatch_steps_astroph_k20"]["error"]
+    assert out["model_ms_per_step"] > 0 and out["measured_over_model"] > 0
     assert out["load_balance"]["max_over_mean"] < 1.1 and out["rccl"]["devices_unique"] is False   # test mode: both ranks on GPU 0

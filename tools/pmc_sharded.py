@@ -44,11 +44,12 @@ def main():
         lines.append("# %s" % label)
         lines.append("%-44s %8s %12s %16s %10s %7s" % ("kernel", "calls", "avg us", "HBM bytes/launch", "TB/s", "frac"))
         ks = {}
-        # the sweep's own kernels: launched at least once per timed sweep (set-up launches of one or two calls are left out)
-        nmax = max((c for k, (_, c) in st.items() if k.startswith("k_")), default=1)
+        # the sweep's own kernels: launched at least once per sweep (set-up launches of one or two calls are left out); sweeps run =
+        # launches of the kernel the run spent most time in (the phi pass: one launch per sweep)
+        nmax = max(((ns * c, c) for k, (ns, c) in st.items() if k.startswith("k_")), default=(0, 1))[1]
         tot_b = tot_t = 0.0
         for k, (ns, calls) in sorted(st.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-            if not k.startswith("k_") or k not in fe or calls * 4 < nmax:
+            if not k.startswith("k_") or k not in fe or calls < nmax:
                 continue
             f = fe[k][0] / max(fe[k][1], 1)
             w = wr.get(k, [0.0, 1])[0] / max(wr.get(k, [0.0, 1])[1], 1)
