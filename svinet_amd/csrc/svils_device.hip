@@ -499,10 +499,11 @@ __global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(
     double gn[V];
     if (tl > 0.0) {
       double m[V];
+      const double rtl = 1.0 / tl;   // ONE division per node (an IEEE division per column was 8 % of this launch's instructions at V = 8)
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const double g0 = prm.alpha + acc[v];
-        m[v] = (g0 - prm.alpha) / tl;
+        m[v] = (g0 - prm.alpha) * rtl;
         gn[v] = g0 + ((double)geo.n - tl - 1.0) * m[v];
         if (annealing) gn[v] *= scale[v];
         if (kval[v]) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; }

@@ -503,10 +503,11 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
       }
       if (tl > 0.0) {
         double m[V];
+        const double rtl = 1.0 / tl;   // (one division per node, as k_finalize)
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const double g0 = prm.alpha + acc[v];
-          m[v] = (g0 - prm.alpha) / tl;
+          m[v] = (g0 - prm.alpha) * rtl;
           gn[v] = g0 + ((double)geo.n - tl - 1.0) * m[v];
           if (annealing) gn[v] *= scale[v];
           if (kval[v]) { if (ok) { s12[0][v] += m[v]; s12[1][v] += m[v] * m[v]; } }

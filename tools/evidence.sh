@@ -22,6 +22,7 @@
 #   forced       bench.py --force-sharded (real librccl, world of one) on ca-AstroPh K=20 and K=200: sharded driver vs plain engine
 #   cli5         tools/cli_config5.py (the binary at config-5 size): 4 sweeps with -no-stop, then the default flags
 #   benchN       bare `python bench.py --gpus 4|8 --test-one-gpu` (tests' transport)
+#   bench8       the same at 8 with ALL seven side records (flow rehearsal of the first real node: order, wall time)
 #   cliff        per-kernel times and sweep time on ca-AstroPh at K = 20 / 22 / 24 (the register cliff of the small-K kernels)
 #   ab-mid12     A/B of tools/build_variant.sh mid12 -DLPL_MID_KC=12 (K = 21..24 phi in the 4-wave block shape)
 TAG=$1; shift
@@ -122,6 +123,24 @@ PY
           --extra-list ksharded_config4_astroph_k200 --no-cpu-baseline > $O/bench_gpus${N}_one_gpu_test_mode.json 2> $O/benchN_err$N.txt
         echo "N=$N rc=$?"; tail -2 $O/benchN_err$N.txt; tail -c 600 $O/bench_gpus${N}_one_gpu_test_mode.json; echo
       done ;;
+    bench8)   # bare `python bench.py --gpus 8 --test-one-gpu` with ALL SEVEN side records (tests' transport; a flow rehearsal,
+              # never a measurement): the line, the order the records came in, the wall time
+      python -c "import __graft_entry__ as g; g.build_test_transport()" >/dev/null 2>&1
+      t0=$(date +%s)
+      SVILS_RCCL_LIBRARY=$R/tests/fakerccl/libfakerccl.so FAKERCCL_ASYNC=1 timeout 2400 python bench.py --gpus 8 --steps 10 --warmup 2 --test-one-gpu \
+        --no-cpu-baseline > $O/bench_gpus8_all_records_one_gpu_test_mode.json 2> $O/bench8_err.txt
+      rc=$?; t1=$(date +%s)
+      python - $O/bench_gpus8_all_records_one_gpu_test_mode.json $rc $((t1 - t0)) <<'PY' | tee $O/bench8_summary.txt
+import json, sys
+lines = [l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")]
+print("bare bench.py --gpus 8 --test-one-gpu, all side records: rc=%s wall=%s s, JSON lines: %d" % (sys.argv[2], sys.argv[3], len(lines)))
+if lines:
+    d = json.loads(lines[-1])
+    print("main: value=%s ms_per_step=%s model_ms_per_step=%s error=%s" % (d.get("value"), d.get("ms_per_step"), d.get("model_ms_per_step"), d.get("error")))
+    for k, v in (d.get("sharded_extra") or {}).items():
+        print("  %-34s %s" % (k, ("ms_per_step %.3f | model %.3f | n1_same_box %.3f" % (v.get("ms_per_step", float("nan")), v.get("model_ms_per_step") or float("nan"), v.get("n1_same_box_ms_per_step") or float("nan"))) if isinstance(v, dict) and "error" not in v else v))
+PY
+      tail -3 $O/bench8_err.txt ;;
     cli) python bench.py --cli-only > $O/bench_cli_end_to_end.json 2> $O/bench_cli.err; tail -c 1500 $O/bench_cli_end_to_end.json; echo ;;
     cliff) for k in 20 22 24; do python tools/kernel_times.py astroph-k$k 100 2>/dev/null | tail -1; python bench.py --workload astroph-k$k --steps 100 --warmup 5 --reps 20 --no-hbm-bound --no-config5 --no-cpu-baseline --no-cli 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('astroph-k$k graph-replayed sweep %.2f us' % (d['ms_per_step']*1e3))"; done | tee $O/k20_k24_cliff_kernel_times.txt ;;
     ab-mid12) WLS="astroph-k22 astroph-k24 astroph-k20 lfr-k28" bash tools/ab_libs.sh $O/ab_mid_kc12.txt libsvils.so libsvils_mid12.so ;;
