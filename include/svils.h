@@ -37,7 +37,7 @@ extern "C" {
                                     with ONE row exchange (SVILS_PHASE_B_LIGHT / SVILS_PHASE_EXPAND_ALL, SVILS_BUF_GSTAGE);
                                  7: k up to SVILS_MAX_K_TOTAL (column-tiled handles above SVILS_MAX_K; K-sharded k_total up to it),
                                     getters that do not wait behind a stop the caller has seen ("After the stop");
-                                 8: svils_set_option / svils_get_option / svils_option_table (every tunable in one documented table; nothing
+                                 8: svils_init_gamma (init_gamma2 on the device); svils_set_option / svils_get_option / svils_option_table (every tunable in one documented table; nothing
                                     on a sweep path reads the environment); svils_gather_communities ends the no-wait window of "After the stop" */
 
 typedef enum {
@@ -139,6 +139,22 @@ int svils_get_test_rows(svils_handle *h, uint32_t first, uint32_t count, double 
  * Computes Elogpi / Elogbeta (set_dir_exp, src/linksampling.hh:170-187). */
 int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
                     const uint32_t *converged);
+
+/* init_gamma2 (src/linksampling.cc:374-401) ON THE DEVICE, bit for bit: instead of drawing the E x k uniforms on the host, adding
+ * them into an n x k array and uploading it (svils_set_state), the caller hands over where its MT19937 stream stands and the
+ * library regenerates the draws, normalises them per link and adds them into the gamma rows in the reference's order.
+ *   edges      [nedges][2], p < q, EVERY link (held-out ones included) in the order the reference's loop visits them: p ascending,
+ *              then the order of p's adjacency list -- link j consumes outputs [j k, (j + 1) k) of the stream
+ *   mt_states  [nstreams][624] MT19937 states in canonical form (the next output is the first word of the next twist of the
+ *              state; gsl_rng's mt[] with mti == 624): state s stands outputs_per_stream * s outputs behind state 0, which stands
+ *              where the reference's generator stands when init_gamma2 starts (after the validation sampler's draws).
+ *              host/mtjump.hh computes them by jump-ahead; streams x outputs_per_stream must cover nedges * k exactly once.
+ *   lambda     [k][2] as for svils_set_state (init_lambda, src/linksampling.cc:364-372); the converged flags are zeroed.
+ * Whole-graph handles only (SVILS_ERR_UNSUPPORTED otherwise: upload the state).  Needs 4 * nedges * k bytes of device scratch
+ * for the duration of the call (24 GB at n = 1e6, k = 512; SVILS_ERR_NOMEM if it is not there: upload the state instead).
+ * Replaces 2.9 s of host work + a 4.1 GB upload by ~0.1 s of host work (the states) + ~30 ms of device work at that size. */
+int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, const uint32_t *mt_states, uint64_t nstreams,
+                     uint64_t outputs_per_stream, const double *lambda);
 
 /* Loop-carried scalars of infer()/validation_likelihood(). */
 typedef struct {

@@ -33,7 +33,7 @@ EXPORTS = (
     "svils_set_test", "svils_get_test_rows",
     "svils_report_tag_count", "svils_report_fetch_tags", "svils_get_community_tags",
     "svils_set_node_blocks", "svils_balance_node_blocks", "svils_prepare_graphs",
-    "svils_set_option", "svils_get_option", "svils_option_table",
+    "svils_set_option", "svils_get_option", "svils_option_table", "svils_init_gamma",
 )
 
 
@@ -145,6 +145,7 @@ def load():
     L.svils_report_fetch_tags.argtypes = [vp, C.c_int, C.POINTER(Control), vp, C.POINTER(C.c_uint32), vp, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
     L.svils_get_community_tags.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svils_init_gamma.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp]
     L.svils_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.svils_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
     L.svils_option_table.restype = C.c_char_p
@@ -287,6 +288,15 @@ class Engine:
             assert converged.shape == (self.n,)
             cptr = converged.ctypes.data
         _chk(load().svils_set_state(self._h, gamma.ctypes.data, lam.ctypes.data, cptr))
+
+    def init_gamma(self, edges, mt_states, outputs_per_stream, lam):
+        """init_gamma2 on the device (svils_init_gamma): edges [E][2] in drawing order, mt_states [S][624] uint32"""
+        edges = np.ascontiguousarray(edges, dtype=np.uint32)
+        st = np.ascontiguousarray(mt_states, dtype=np.uint32)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        assert edges.ndim == 2 and edges.shape[1] == 2 and st.ndim == 2 and st.shape[1] == 624 and lam.shape == (self.k, 2)
+        _chk(load().svils_init_gamma(self._h, edges.ctypes.data, edges.shape[0], st.ctypes.data, st.shape[0],
+                                     int(outputs_per_stream), lam.ctypes.data))
 
     def control(self):
         c = Control()

@@ -624,14 +624,24 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
     return tiles_set_state(h, gamma, lambda, converged);
   }
   if (!h || !gamma || !lambda) return fail(SVILS_ERR_ARG, "svils_set_state: null argument");
-  h->mphi_stale = false;   // the stored rows have nothing to do with the new gamma (nor has the reference's _mphi after load_model)
-  h->frozen = false;       // whatever stop the caller had seen belongs to the old state
   HIPCHK(hipSetDevice(h->cfg.device));
   const Geometry &g = h->geo;
   DeviceState &d = h->d;
   HIPCHK(hipMemsetAsync(d.gamma, 0, (size_t)g.n_alloc * g.ld * sizeof(double), h->stream));
   HIPCHK(hipMemcpy2DAsync(d.gamma, g.ld * sizeof(double), gamma, g.K * sizeof(double),
                           g.K * sizeof(double), g.n, hipMemcpyHostToDevice, h->stream));
+  return state_arrived(h, lambda, converged);
+}
+
+}  // extern "C"
+namespace svils_impl {
+// what follows a new gamma on the device, however it got there (svils_set_state: uploaded; svils_init_gamma: drawn in place):
+// lambda, the converged flags, the expectations, the bookkeeping of a handle whose state has just been replaced
+int state_arrived(svils_handle *h, const double *lambda, const uint32_t *converged) {
+  const Geometry &g = h->geo;
+  DeviceState &d = h->d;
+  h->mphi_stale = false;   // the stored rows have nothing to do with the new gamma (nor has the reference's _mphi after load_model)
+  h->frozen = false;       // whatever stop the caller had seen belongs to the old state
   HIPCHK(hipMemcpyAsync(d.lambda, lambda, 2 * (size_t)g.K * sizeof(double), hipMemcpyHostToDevice, h->stream));
   DevCtrl c;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -648,6 +658,8 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
   h->have_state = true;
   return 0;
 }
+}  // namespace svils_impl
+extern "C" {
 
 int svils_get_control(svils_handle *h, svils_control *out) {
   if (TILED(h)) return svils_get_control(h->tiles[0], out);   // the loop control is replicated on the tiles

@@ -8,6 +8,7 @@
 //   svils_tiles.hip       column-tiled handles (k > SVILS_MAX_K on one device)
 //   svils_stoch.hip       mini-batch (Robbins-Monro) steps
 //   svils_report_api.hip  pipelined reports, test set
+//   svils_init.hip        init_gamma2 on the device (svils_init_gamma: MT19937 streams, per-link draws, rows in link order)
 //   svils_options.hip     the option table (svils_set_option, SVILS_* environment defaults)
 //
 // Host-side work in all of them is plumbing only: argument checks, CSR construction, uploads/downloads, launch
@@ -225,7 +226,8 @@ inline int settle(svils_handle *h) {
 int drain_timing(svils_handle *h);
 int fault_error(uint32_t code);
 void drop_graphs_of(svils_handle *h);
-int elogpi_rows(svils_handle *h, double **rows);   // the Elogpi rows of the state as it stands (computed now where a handle does not store them)
+int elogpi_rows(svils_handle *h, double **rows);
+int state_arrived(svils_handle *h, const double *lambda, const uint32_t *converged);   // the tail of svils_set_state   // the Elogpi rows of the state as it stands (computed now where a handle does not store them)
 void chunk_row(std::vector<Item> &items, uint32_t p, uint32_t off, uint32_t len, uint32_t ch,
                int32_t *next_slot, int32_t *first_slot, uint32_t *nsplit);
 // (node, community) pairs of a lane-layout community bitmask [n][kw]; counts them all, writes at most `cap`

@@ -88,6 +88,20 @@ const uint32_t *svih_validation_accept(const svih_setup *s) { return s->ls->vali
 uint64_t svih_nlinks(svih_setup *s) { return s->ls->training_links().size() / 2; }
 const uint32_t *svih_links(svih_setup *s) { return s->ls->training_links().data(); }
 const uint32_t *svih_edges(const svih_setup *s) { return &s->net->edges()[0].first; }
+// what svils_init_gamma takes (tests/test_gpu_init.py): the links in drawing order, the generator's states by jump-ahead
+uint64_t svih_init_links(const svih_setup *s, uint32_t *out /* [ones][2] or null */) {
+  std::vector<uint32_t> e;
+  s->ls->init_links(&e);
+  if (out) memcpy(out, e.data(), e.size() * sizeof(uint32_t));
+  return e.size() / 2;
+}
+uint64_t svih_init_offset(const svih_setup *s) { return s->ls->init_offset(); }   // outputs drawn before init_gamma2 began
+int svih_init_streams(const svih_setup *s, uint64_t nstreams, uint64_t per_stream, uint32_t *out /* [nstreams][624] */) {
+  std::vector<uint32_t> st;
+  if (!s->ls->init_streams(nstreams, per_stream, &st)) return -1;
+  memcpy(out, st.data(), st.size() * sizeof(uint32_t));
+  return 0;
+}
 uint32_t svih_deg(const svih_setup *s, uint32_t p) { return s->net->deg(p); }
 
 // normalised mutual information of a communities.txt-style file against a ground-truth file in the

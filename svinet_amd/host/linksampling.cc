@@ -144,11 +144,13 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     init_gamma_external();
     init_lambda();
   } else {
-    init_gamma2();
+    init_o0_ = rng_.position();
+    defer_init_ = device_init_wanted(attach_device);
+    if (!defer_init_) init_gamma2();
     init_lambda();
   }
 
-  mark("gamma / lambda initialised");
+  mark(defer_init_ ? "lambda initialised (gamma: on the device, below)" : "gamma / lambda initialised");
   if (env_.write_files) {
     tf_ = open_or_die(Env::file_str("/test.txt"), "test");
     vf_ = open_or_die(Env::file_str("/validation.txt"), "validation");
@@ -304,7 +306,10 @@ void LinkSampling::attach() {
     if (svils_set_state(h_, g.data(), &lambda_[2 * (size_t)k0_], nullptr)) die_svils("svils_set_state");
     if (svils_ksh_init_state(h_)) die_svils("svils_ksh_init_state");
   } else if (dev_of_.empty()) {
-    if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
+    if (!(defer_init_ && init_gamma2_on_device())) {
+      if (defer_init_) init_gamma2();            // (the device path was not taken after all: draw on the host as always)
+      if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
+    }
   } else {
     std::vector<double> g((size_t)n_ * k_);
     for (uint32_t i = 0; i < n_; ++i)
@@ -507,6 +512,72 @@ void LinkSampling::init_gamma_external() {
     for (size_t e = 0; e < deg; ++e)
       for (uint32_t k = 0; k < k_; ++k) g[k] += phi[k];
   }
+}
+
+// ---- init_gamma2 on the device (svils_init_gamma, csrc/svils_init.hip)
+// Taken by the binary's one-GPU whole-graph run when the draws are worth it (E k >= 2^24 uniforms: below that the host loop is
+// milliseconds); SVINET_INIT_DEVICE=1 / 0 forces / forbids it (tests: the two paths leave the same files, bit for bit).
+bool LinkSampling::device_init_wanted(bool attach_device) const {
+  if (!attach_device || env_.kshard || env_.sharded || env_.gpus > 1 || env_.minibatch || k_ > SVILS_MAX_K) return false;
+  if (const char *e = getenv("SVINET_INIT_DEVICE")) return atoi(e) != 0;
+  return (uint64_t)network_.ones() * k_ >= (1ull << 24);
+}
+
+void LinkSampling::init_links(std::vector<uint32_t> *edges) const {
+  edges->clear();
+  edges->reserve(2 * (size_t)network_.ones());
+  for (uint32_t p = 0; p < n_; ++p)
+    for (uint32_t q : network_.get_edges(p))
+      if (p < q) { edges->push_back(p); edges->push_back(q); }   // all links, held-out ones included (src/linksampling.cc:378-386)
+}
+
+bool LinkSampling::init_streams(uint64_t nstreams, uint64_t per_stream, std::vector<uint32_t> *states) const {
+  states->assign((size_t)nstreams * 624, 0u);
+  MtJump stride;
+  if (nstreams > 1 && !stride.make(per_stream)) return false;
+  // thread t: the state at its first stream by a jump from the seed, then along the chain with the one stride polynomial
+  const unsigned T = (unsigned)std::min<uint64_t>(std::min(usable_cpus(), 64u), nstreams);
+  std::vector<char> ok(T, 1);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      const uint64_t s0 = nstreams * t / T, s1 = nstreams * (t + 1) / T;
+      if (s0 >= s1) return;
+      GslMt19937 g;
+      uint32_t *st = states->data() + (size_t)s0 * 624;
+      if (!rng_.at(init_o0_ + s0 * per_stream, &g) || !g.canonical_state(st)) { ok[t] = 0; return; }
+      for (uint64_t s = s0 + 1; s < s1; ++s) {
+        uint32_t *nx = states->data() + (size_t)s * 624;
+        memcpy(nx, nx - 624, 624 * sizeof(uint32_t));
+        stride.apply(nx);
+      }
+    });
+  for (auto &x : th) x.join();
+  for (char c : ok) if (!c) return false;
+  return true;
+}
+
+bool LinkSampling::init_gamma2_on_device() {
+  const double t0 = now_s();
+  std::vector<uint32_t> edges, states;
+  init_links(&edges);
+  const uint64_t E = edges.size() / 2, total = E * (uint64_t)k_;
+  if (!total) return false;
+  // streams: enough wavefronts to fill the device (one per stream), each long enough to amortise its state (>= 256 twists),
+  // few enough that the host's jump chain stays short (~1 ms per state and thread)
+  const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(2048, total / (624ull * 256ull)));
+  const uint64_t per = ((total + want - 1) / want + 623) / 624 * 624;
+  const uint64_t ns = (total + per - 1) / per;
+  if (!init_streams(ns, per, &states)) return false;
+  const double t1 = now_s();
+  if (svils_init_gamma(h_, edges.data(), E, states.data(), ns, per, lambda_.data())) {
+    fprintf(stderr, "note: init_gamma2 on the device not taken (%s); drawing on the host\n", svils_last_error());
+    return false;
+  }
+  if (getenv("SVINET_TRACE_LOOP"))
+    fprintf(stderr, "[ctor] init_gamma2 on the device: %llu links x %u, %llu streams of %llu outputs: host %.3f s (links + states), device call %.3f s\n",
+            (unsigned long long)E, k_, (unsigned long long)ns, (unsigned long long)per, t1 - t0, now_s() - t1);
+  return true;
 }
 
 void LinkSampling::init_gamma2() {

@@ -52,6 +52,12 @@ class LinkSampling {
   double ones_prob() const { return ones_prob_; }
   double zeros_prob() const { return zeros_prob_; }
   const double *row0() const { return have_row0_ ? row0_ : nullptr; }
+  // init_gamma2 as svils_init_gamma takes it: every link (held-out ones included) in the order the reference draws for them
+  // ([E][2], p < q), and `nstreams` MT19937 states, `per_stream` outputs apart, the first one standing where the generator stood
+  // when init_gamma2 began (mtjump.hh) -- false if the jump machinery is unavailable
+  uint64_t init_offset() const { return init_o0_; }
+  void init_links(std::vector<uint32_t> *edges) const;
+  bool init_streams(uint64_t nstreams, uint64_t per_stream, std::vector<uint32_t> *states) const;
 
  private:
   void init_validation();
@@ -64,6 +70,8 @@ class LinkSampling {
   void accept_pair(const Edge &e, bool y);
   std::string edgelist_s(const std::vector<uint32_t> &triples) const;
   void init_gamma2();
+  bool init_gamma2_on_device();                // svils_init_gamma instead of init_gamma2 + the upload of its result; false: not taken
+  bool device_init_wanted(bool attach_device) const;
   int init_lambda();
   int load_model();
   void attach();
@@ -94,6 +102,8 @@ class LinkSampling {
   std::map<Edge, bool> test_map_;              // -load-test
   std::vector<uint32_t> test_sorted_;          // [T][3] p, q, y in map order
   std::vector<double> gamma_, lambda_;
+  uint64_t init_o0_ = 0;                       // outputs the generator had produced when init_gamma2 began
+  bool defer_init_ = false;                    // init_gamma2 runs on the device, in attach()
   std::vector<uint32_t> links_;
   bool links_done_ = false;
   uint32_t k0_ = 0, k1_ = 0;                   // -kshard: this rank's columns

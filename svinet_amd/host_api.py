@@ -50,6 +50,12 @@ def load():
         f = getattr(L, "svih_" + name)
         f.argtypes = [vp]
         f.restype = res
+    L.svih_init_links.argtypes = [vp, vp]
+    L.svih_init_links.restype = u64
+    L.svih_init_offset.argtypes = [vp]
+    L.svih_init_offset.restype = u64
+    L.svih_init_streams.argtypes = [vp, u64, u64, vp]
+    L.svih_init_streams.restype = C.c_int
     L.svih_deg.argtypes = [vp, u32]
     L.svih_deg.restype = u32
     _lib = L
@@ -110,6 +116,25 @@ class Setup:
 
     def deg(self, p):
         return load().svih_deg(self._h, p)
+
+    # ---- what svils_init_gamma takes (init_gamma2 on the device, csrc/svils_init.hip) ----
+    def init_links(self):
+        """every link (held-out ones included) in the order init_gamma2 draws for them: [E][2], p < q"""
+        e = load().svih_init_links(self._h, None)
+        out = np.empty((e, 2), dtype=np.uint32)
+        load().svih_init_links(self._h, out.ctypes.data)
+        return out
+
+    def init_offset(self):
+        """outputs the MT19937 stream had produced when init_gamma2 began (the held-out sampler's draws)"""
+        return int(load().svih_init_offset(self._h))
+
+    def init_streams(self, nstreams, per_stream):
+        """[nstreams][624] MT19937 states, per_stream outputs apart, the first at init_offset() (jump-ahead, host/mtjump.hh)"""
+        out = np.empty((nstreams, 624), dtype=np.uint32)
+        if load().svih_init_streams(self._h, nstreams, per_stream, out.ctypes.data):
+            raise RuntimeError("the jump-ahead machinery is unavailable")
+        return out
 
     def engine(self, **kw):
         """An svils Engine loaded with this setup (graph, validation set, state)."""

@@ -222,3 +222,53 @@ def test_init_gamma_threaded_draws_are_the_sequential_stream(graph_files):
                 {"SVINET_INIT_THREADS": "16", "SVINET_INIT_CHUNK_LINKS": "12311"}):  # one round only
         g, v = run(env)
         assert np.array_equal(g, g0) and np.array_equal(v, v0), env
+
+
+def test_init_streams_are_the_sequential_stream(graph_files):
+    """what svils_init_gamma is handed (host/linksampling.cc: init_streams): state s of the jump-ahead chain is the generator
+    s * per_stream outputs behind state 0, and state 0 stands where init_gamma2 began -- checked by running the twist forward in
+    numpy from state 0 and by reproducing the host's gamma from the regenerated draws (the device kernel's recipe, on the CPU)"""
+    from svinet_amd.host_api import Setup
+
+    def twist(x):
+        x = x.copy()
+        up, lo = np.uint32(0x80000000), np.uint32(0x7fffffff)
+        def tw(u, v):
+            y = (u & up) | (v & lo)
+            return (y >> np.uint32(1)) ^ (np.uint32(0x9908b0df) * (y & np.uint32(1)))
+        x[:227] = x[397:624] ^ tw(x[:227], x[1:228])
+        x[227:454] = x[0:227] ^ tw(x[227:454], x[228:455])
+        x[454:623] = x[227:396] ^ tw(x[454:623], x[455:624])
+        x[623] = x[396] ^ tw(x[623:624], x[0:1])[0]
+        return x
+
+    def temper(y):
+        y = y ^ (y >> np.uint32(11))
+        y = y ^ ((y << np.uint32(7)) & np.uint32(0x9d2c5680))
+        y = y ^ ((y << np.uint32(15)) & np.uint32(0xefc60000))
+        return y ^ (y >> np.uint32(18))
+
+    s = Setup(graph_files["lfr"], 1000, 28)
+    per, ns = 624 * 5, 4
+    st = s.init_streams(ns, per)
+    x = st[0].copy()
+    raw = []
+    for b in range(5 * (ns - 1) + 2):
+        if b % 5 == 0 and b // 5 < ns:
+            assert np.array_equal(x, st[b // 5]), "state %d is not %d outputs behind state 0" % (b // 5, b * 624)
+        x = twist(x)
+        raw.append(temper(x))
+    raw = np.concatenate(raw)
+    # the first links' draws, normalised and added in drawing order, give the host's gamma rows of nodes no later link touches
+    edges = s.init_links()
+    k = 28
+    nl = raw.shape[0] // k
+    g = np.zeros((1000, k))
+    for l in range(nl):
+        u = raw[l * k:(l + 1) * k].astype(np.float64) / 4294967296.0
+        v = u / u.sum()
+        g[edges[l, 0]] += v
+        g[edges[l, 1]] += v
+    done = np.setdiff1d(np.unique(edges[:nl]), np.unique(edges[nl:]))
+    assert done.size > 0 and np.array_equal(g[done], s.gamma[done])
+    assert s.init_offset() > 0

@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-D = os.path.join(HERE, "scratch_perm")
+D = os.path.join(HERE, "scratch_perm")   # (created by `make`; .npy files of 4 MB each travel to the GPU box with the snapshot: delete them afterwards)
+os.makedirs(D, exist_ok=True)
 mode = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 512
