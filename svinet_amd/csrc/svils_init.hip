@@ -20,6 +20,8 @@
 // Then the tail of svils_set_state (lambda, flags, expectations).  Same bits as the host path: tests/test_gpu_init.py.
 #include "svils_handle.h"
 
+#include <time.h>
+
 namespace svils_impl {
 
 namespace {
@@ -130,23 +132,12 @@ int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, co
     return fail(SVILS_ERR_ARG, "svils_init_gamma: %llu streams of %llu outputs do not cover the %llu x %u uniforms exactly once",
                 (unsigned long long)nstreams, (unsigned long long)outputs_per_stream, (unsigned long long)nedges, g.K);
   HIPCHK(hipSetDevice(h->cfg.device));
-  // the ALL-links CSR in the order of the reference's additions: row x = {p < x, ascending} ++ {q > x in link order}
+#ifdef SVILS_TESTING
+  const auto tclock = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+  const double tt0 = tclock();
+  double tt1 = tt0, tt2 = tt0, tt3 = tt0;
+#endif
   const uint32_t n = g.n;
-  std::vector<uint64_t> rowptr((size_t)n + 1, 0);
-  for (uint64_t l = 0; l < nedges; ++l) {
-    const uint32_t p = edges[2 * l], q = edges[2 * l + 1];
-    if (p >= q || q >= n) return fail(SVILS_ERR_ARG, "svils_init_gamma: link %llu = (%u,%u): need p < q < n", (unsigned long long)l, p, q);
-    if (l && edges[2 * l - 2] > p) return fail(SVILS_ERR_ARG, "svils_init_gamma: links must come in the order they are drawn (sorted by first endpoint; link %llu)", (unsigned long long)l);
-    rowptr[p + 1]++;
-    rowptr[q + 1]++;
-  }
-  for (uint32_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
-  std::vector<uint32_t> elink(std::max<uint64_t>(2 * nedges, 1));
-  {
-    std::vector<uint64_t> fill(rowptr.begin(), rowptr.end() - 1);
-    for (uint64_t l = 0; l < nedges; ++l) elink[fill[edges[2 * l + 1]]++] = (uint32_t)l;   // lower parts: ascending p
-    for (uint64_t l = 0; l < nedges; ++l) elink[fill[edges[2 * l]]++] = (uint32_t)l;       // upper parts: link order
-  }
   // scratch of this call alone (the raw words are 4 E K bytes: 24 GB at n = 1e6, k = 512): freed before returning
   uint32_t *d_raw = nullptr, *d_states = nullptr, *d_elink = nullptr;
   uint64_t *d_rowptr = nullptr;
@@ -162,15 +153,43 @@ int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, co
     return fail(e == hipErrorOutOfMemory ? SVILS_ERR_NOMEM : SVILS_ERR_DEVICE, "svils_init_gamma: %s failed: %s", what, hipGetErrorString(e));
   };
   int rc;
+  // the draws first: they need nothing but the states, and run while the host builds the row lists below
   if ((rc = chk(hipMalloc((void **)&d_raw, std::max<uint64_t>(total, 1) * sizeof(uint32_t) + 512), "hipMalloc (raw MT19937 outputs)"))) return rc;
   if ((rc = chk(hipMalloc((void **)&d_states, nstreams * MT_N * sizeof(uint32_t)), "hipMalloc"))) return rc;
+  if ((rc = chk(hipMemcpyAsync(d_states, mt_states, nstreams * MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "upload"))) return rc;
+  hipLaunchKernelGGL(k_mt_generate, dim3((uint32_t)nstreams), dim3(64), 0, h->stream, d_states, nstreams, outputs_per_stream, total, d_raw);
+  if ((rc = chk(hipMemsetAsync(h->d.gamma, 0, (size_t)g.n_alloc * g.ld * sizeof(double), h->stream), "memset"))) return rc;
+#ifdef SVILS_TESTING
+  tt1 = tclock();
+#endif
+  // the ALL-links CSR in the order of the reference's additions: row x = {p < x, ascending} ++ {q > x in link order}
+  std::vector<uint64_t> rowptr((size_t)n + 1, 0);
+  for (uint64_t l = 0; l < nedges; ++l) {
+    const uint32_t p = edges[2 * l], q = edges[2 * l + 1];
+    if (p >= q || q >= n) { (void)hipStreamSynchronize(h->stream); release(); return fail(SVILS_ERR_ARG, "svils_init_gamma: link %llu = (%u,%u): need p < q < n", (unsigned long long)l, p, q); }
+    if (l && edges[2 * l - 2] > p) { (void)hipStreamSynchronize(h->stream); release(); return fail(SVILS_ERR_ARG, "svils_init_gamma: links must come in the order they are drawn (sorted by first endpoint; link %llu)", (unsigned long long)l); }
+    rowptr[p + 1]++;
+    rowptr[q + 1]++;
+  }
+  for (uint32_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+  std::vector<uint32_t> elink(std::max<uint64_t>(2 * nedges, 1));
+  {
+    std::vector<uint64_t> fill(rowptr.begin(), rowptr.end() - 1);
+    for (uint64_t l = 0; l < nedges; ++l) elink[fill[edges[2 * l + 1]]++] = (uint32_t)l;   // lower parts: ascending p
+    // upper parts: the links (x, .) are consecutive in link order -- row x's upper part is simply its run of link indices
+    uint64_t l = 0;
+    for (uint32_t x = 0; x < n && l < nedges; ++x) {
+      uint64_t f = fill[x];
+      while (l < nedges && edges[2 * l] == x) elink[f++] = (uint32_t)l++;
+    }
+  }
+#ifdef SVILS_TESTING
+  tt2 = tclock();
+#endif
   if ((rc = chk(hipMalloc((void **)&d_elink, elink.size() * sizeof(uint32_t)), "hipMalloc"))) return rc;
   if ((rc = chk(hipMalloc((void **)&d_rowptr, rowptr.size() * sizeof(uint64_t)), "hipMalloc"))) return rc;
-  if ((rc = chk(hipMemcpyAsync(d_states, mt_states, nstreams * MT_N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "upload"))) return rc;
   if ((rc = chk(hipMemcpyAsync(d_elink, elink.data(), elink.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "upload"))) return rc;
   if ((rc = chk(hipMemcpyAsync(d_rowptr, rowptr.data(), rowptr.size() * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream), "upload"))) return rc;
-  if ((rc = chk(hipMemsetAsync(h->d.gamma, 0, (size_t)g.n_alloc * g.ld * sizeof(double), h->stream), "memset"))) return rc;
-  hipLaunchKernelGGL(k_mt_generate, dim3((uint32_t)nstreams), dim3(64), 0, h->stream, d_states, nstreams, outputs_per_stream, total, d_raw);
   const uint32_t nb = (n + 3) / 4;
   const int J = (int)((g.K + 63) / 64);
 #define ROWS(J_) hipLaunchKernelGGL((k_init_rows<J_>), dim3(nb), dim3(256), 0, h->stream, n, g.K, g.ld, d_rowptr, d_elink, d_raw, h->d.gamma)
@@ -183,8 +202,16 @@ int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, co
 #undef ROWS
   if ((rc = chk(hipGetLastError(), "launch"))) return rc;
   if ((rc = chk(hipStreamSynchronize(h->stream), "the init kernels"))) return rc;
+#ifdef SVILS_TESTING
+  tt3 = tclock();
+#endif
   release();
-  return state_arrived(h, lambda, nullptr);
+  rc = state_arrived(h, lambda, nullptr);
+#ifdef SVILS_TESTING
+  fprintf(stderr, "[svils_init_gamma] scratch + states + generate launched %.3f s | row lists on the host %.3f s | uploads + kernels %.3f s | free + expectations %.3f s\n",
+          tt1 - tt0, tt2 - tt1, tt3 - tt2, tclock() - tt3);
+#endif
+  return rc;
 }
 
 }  // extern "C"

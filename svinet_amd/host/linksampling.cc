@@ -136,8 +136,9 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
   }
 
   mark("held-out sets done");
-  gamma_.assign((size_t)n_ * k_, 0.0);
   lambda_.assign(2 * (size_t)k_, 0.0);
+  defer_init_ = !env_.model_load && !env_.use_init_communities && device_init_wanted(attach_device);
+  if (!defer_init_) gamma_.assign((size_t)n_ * k_, 0.0);   // (left to the device: no host copy until the final fetch)
   if (env_.model_load) {
     if (load_model() < 0) exit(-1);
   } else if (env_.use_init_communities) {        // src/linksampling.cc:112-115 (nolambda is never set on this path)
@@ -145,7 +146,6 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
     init_lambda();
   } else {
     init_o0_ = rng_.position();
-    defer_init_ = device_init_wanted(attach_device);
     if (!defer_init_) init_gamma2();
     init_lambda();
   }
@@ -207,6 +207,9 @@ LinkSampling::~LinkSampling() {
 }
 
 void LinkSampling::attach() {
+  const double t_attach = now_s();
+  const bool trace_attach = getenv("SVINET_TRACE_LOOP") != nullptr;
+  auto amark = [&](const char *what) { if (trace_attach) fprintf(stderr, "[attach] +%.3f s: %s\n", now_s() - t_attach, what); };
   svils_config cfg;
   svils_config_default(&cfg, n_, k_);
   cfg.ones = network_.ones();
@@ -283,6 +286,7 @@ void LinkSampling::attach() {
     if (env_.sharded) sc.shard_block = (n_ + (uint32_t)env_.gpus - 1) / (uint32_t)env_.gpus;   // every rank steps through its own block
     if (svils_set_stochastic(h_, &sc)) die_svils("svils_set_stochastic");
   }
+  amark("handle created (device arrays), communicator / mini-batch set up");
   if (env_.kshard || k_ > SVILS_MAX_K) send_graph();   // the K-sharded (and column-tiled) initial state needs the link list (row sums cross slices)
   // with -accuracy validation_likelihood() returns at once (:969-970)
   if (!env_.accuracy && !val_sorted_.empty()) {
@@ -307,7 +311,10 @@ void LinkSampling::attach() {
     if (svils_ksh_init_state(h_)) die_svils("svils_ksh_init_state");
   } else if (dev_of_.empty()) {
     if (!(defer_init_ && init_gamma2_on_device())) {
-      if (defer_init_) init_gamma2();            // (the device path was not taken after all: draw on the host as always)
+      if (defer_init_) {                         // (the device path was not taken after all: draw on the host as always)
+        gamma_.assign((size_t)n_ * k_, 0.0);
+        init_gamma2();
+      }
       if (svils_set_state(h_, gamma_.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
     }
   } else {
@@ -316,11 +323,14 @@ void LinkSampling::attach() {
       std::copy(&gamma_[(size_t)i * k_], &gamma_[(size_t)(i + 1) * k_], &g[(size_t)dev_of_[i] * k_]);
     if (svils_set_state(h_, g.data(), lambda_.data(), nullptr)) die_svils("svils_set_state");
   }
+  amark("held-out sets and state on the device");
   // the pipelined loop issues chunks of 1, 2, 4, 8, 16, 16 ... sweeps: their graphs are captured here, in the set-up,
   // not inside a run that may be over after 31 sweeps (svils.h: svils_prepare_graphs)
   if (pipelined_reports() && !getenv("SVILS_GRAPH_AFTER")) {
     send_graph();
+    amark("training links on the device (svils_set_graph)");
     if (svils_prepare_graphs(h_, env_.sweep_batch ? std::min<uint32_t>(env_.sweep_batch, 64) : 16)) die_svils("svils_prepare_graphs");
+    amark("hipGraphs of the chunks captured");
   }
 }
 
@@ -760,7 +770,7 @@ int LinkSampling::init_lambda() {                         // src/linksampling.cc
 // The path is gamma_location + "gamma.txt" with no separator added (src/env.hh:277-282).
 int LinkSampling::load_model() {
   auto parse = [&](const std::string &path, uint32_t skip, uint32_t cols, uint32_t rows,
-                   std::vector<double> &out) -> int {
+                   double *out) -> int {
     FILE *f = fopen(path.c_str(), "r");
     if (!f) { fprintf(stderr, "no %s found\n", path.c_str()); return -1; }
     std::vector<char> line(32 * (size_t)k_ + 64);
@@ -784,8 +794,8 @@ int LinkSampling::load_model() {
     if (r != rows) { fprintf(stderr, "%s: expected %u rows, read %u\n", path.c_str(), rows, r); return -1; }
     return 0;
   };
-  if (parse(env_.gamma_location + "gamma.txt", 2, k_, n_, gamma_) < 0) return -1;
-  if (parse(env_.gamma_location + "lambda.txt", 1, 2, k_, lambda_) < 0) return -1;
+  if (parse(env_.gamma_location + "gamma.txt", 2, k_, n_, gamma_.data()) < 0) return -1;
+  if (parse(env_.gamma_location + "lambda.txt", 1, 2, k_, lambda_.data()) < 0) return -1;
   return 0;
 }
 
@@ -917,16 +927,18 @@ void LinkSampling::save_model() {                          // src/linksampling.c
   // the state comes back into the host copies the constructor filled (n k doubles: allocating and zeroing a second 4 GB
   // array at n = 1e6, k = 512 cost a second); only the layouts that have to be re-ordered take a scratch array
   const bool direct = !env_.kshard && dev_of_.empty();
-  std::vector<double> g(direct ? 0 : (size_t)n_ * k_), l(2 * (size_t)k_);
+  DVec g(direct ? 0 : (size_t)n_ * k_);
+  std::vector<double> l(2 * (size_t)k_);
   const double tf = now_s();
   if (direct) {
+    if (gamma_.size() != (size_t)n_ * k_) gamma_.resize((size_t)n_ * k_);   // (init_gamma2 ran on the device: first host copy, no zero fill)
     if (svils_get_state(h_, gamma_.data(), l.data(), nullptr)) die_svils("svils_get_state");
     g.swap(gamma_);
   } else if (env_.kshard) fetch_state_ksharded(g, l);
   else if (svils_get_state(h_, g.data(), l.data(), nullptr)) die_svils("svils_get_state");
   if (getenv("SVINET_TRACE_LOOP")) fprintf(stderr, "[final] state fetched in %.3f s\n", now_s() - tf);
   if (!dev_of_.empty()) {   // back to sequence-id order
-    std::vector<double> t((size_t)n_ * k_);
+    DVec t((size_t)n_ * k_);
     for (uint32_t i = 0; i < n_; ++i)
       std::copy(&g[(size_t)dev_of_[i] * k_], &g[(size_t)(dev_of_[i] + 1) * k_], &t[(size_t)i * k_]);
     g.swap(t);
@@ -947,7 +959,7 @@ void LinkSampling::save_model() {                          // src/linksampling.c
 
 // -kshard: every rank holds the columns [k0_, k1_); the slices are padded to the widest one, gathered
 // (svils_comm_allgather_host) and put back side by side.  Collective: every rank calls it.
-void LinkSampling::fetch_state_ksharded(std::vector<double> &g, std::vector<double> &l) {
+void LinkSampling::fetch_state_ksharded(DVec &g, std::vector<double> &l) {
   const uint32_t G = (uint32_t)env_.gpus, w = k1_ - k0_, wmax = (k_ + G - 1) / G;
   std::vector<double> mine((size_t)n_ * w + 2 * (size_t)w), send(((size_t)n_ + 2) * wmax, 0.0);
   if (svils_get_state(h_, mine.data(), mine.data() + (size_t)n_ * w, nullptr)) die_svils("svils_get_state");
@@ -1023,7 +1035,8 @@ void LinkSampling::do_on_stop_impl() {
   if (env_.kshard) {
     fetch_communities_ksharded();
     if (!env_.write_files) {   // the other ranks take part in the gather of the model, rank 0 writes it
-      std::vector<double> g((size_t)n_ * k_), l(2 * (size_t)k_);
+      DVec g((size_t)n_ * k_);
+      std::vector<double> l(2 * (size_t)k_);
       fetch_state_ksharded(g, l);
       return;
     }

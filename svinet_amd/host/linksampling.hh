@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <ctime>
 #include <map>
+#include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,19 @@
 struct svils_handle;
 
 namespace svinet {
+
+// n x k doubles WITHOUT a zero fill when resized (4.1 GB at n = 1e6, k = 512: 0.8 s of page zeroing the state fetched from the
+// device overwrites anyway); assign(count, value) still fills
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  template <class U, class... A>
+  void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+using DVec = std::vector<double, default_init_allocator<double>>;
 
 class LinkSampling {
  public:
@@ -41,7 +56,7 @@ class LinkSampling {
   // ---- host-side state (flat row-major) ----
   uint32_t n() const { return n_; }
   uint32_t k() const { return k_; }
-  const std::vector<double> &gamma() const { return gamma_; }
+  const DVec &gamma() const { return gamma_; }
   const std::vector<double> &lambda() const { return lambda_; }
   const std::vector<uint32_t> &validation_accept() const { return val_accept_; }   // [V][3]
   const std::vector<uint32_t> &validation_sorted() const { return val_sorted_; }   // [V][3]
@@ -86,7 +101,7 @@ class LinkSampling {
   bool pipelined_reports() const;
   void send_graph();                           // training links to the device (once)
   int sweep_loop();                            // the body of infer()
-  void fetch_state_ksharded(std::vector<double> &g, std::vector<double> &l);   // -kshard: merged gamma / lambda (collective)
+  void fetch_state_ksharded(DVec &g, std::vector<double> &l);   // -kshard: merged gamma / lambda (collective)
   void fetch_communities_ksharded();           // -kshard: merged tags_ (collective)
   void write_groups();
   uint32_t duration() const { return (uint32_t)(time(0) - start_time_); }
@@ -101,7 +116,8 @@ class LinkSampling {
   std::vector<uint32_t> val_accept_, val_sorted_;
   std::map<Edge, bool> test_map_;              // -load-test
   std::vector<uint32_t> test_sorted_;          // [T][3] p, q, y in map order
-  std::vector<double> gamma_, lambda_;
+  DVec gamma_;                                 // (empty while init_gamma2 is left to the device: defer_init_)
+  std::vector<double> lambda_;
   uint64_t init_o0_ = 0;                       // outputs the generator had produced when init_gamma2 began
   bool defer_init_ = false;                    // init_gamma2 runs on the device, in attach()
   std::vector<uint32_t> links_;

@@ -38,6 +38,9 @@ def main():
         print("graph: %d links, file %.0f MB, generated + written in %.1f s" % (pairs.shape[0], os.path.getsize(path) / 1e6, time.perf_counter() - t0), flush=True)
         tf = os.path.join(d, "timing.json")
         env = dict(os.environ, SVINET_TIMING_FILE=tf, SVINET_TRACE_LOOP="1")   # (the trace marks go to stderr: where the constructor and the writers spend their time)
+        # CFG5_TESTING_LIB=1: the run binds libsvils_testing.so (LD_PRELOAD), whose svils_init_gamma prints where its time went
+        if os.environ.get("CFG5_TESTING_LIB"):
+            env["LD_PRELOAD"] = os.path.join(ROOT, "svinet_amd", "lib", "libsvils_testing.so")
         # CFG5_THREADS=16,32,64: the same run once per thread count of the host-side pools (init_gamma2, file writers)
         for th in [x for x in os.environ.get("CFG5_THREADS", "").split(",") if x]:
             e2 = dict(env, SVINET_INIT_THREADS=th, SVINET_WRITE_THREADS=th)
@@ -62,7 +65,7 @@ def main():
             sys.exit(1)
         print("timing:", json.dumps(json.load(open(tf))), flush=True)
         for line in r.stderr.split("\n"):       # SVINET_TRACE_LOOP=1: the binary's own marks
-            if line.startswith("[ctor]") or line.startswith("[final]"):
+            if line.startswith(("[ctor]", "[final]", "[attach]", "[svils_init_gamma]")):
                 print("  " + line)
         outdir = [x for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
         for fn in sorted(os.listdir(os.path.join(d, outdir))):
