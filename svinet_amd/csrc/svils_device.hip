@@ -425,7 +425,10 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
 template <int W, int V, bool STOCH, bool LIGHT = false>
 // V = 16: two waves per SIMD asked for (256 VGPRs with spills instead of 277 + one wave): ca-AstroPh K=1024 354 -> 273 us,
 // n=1e5 K=1024 1.22 -> 1.04 ms
-__global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : 1)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
+#ifndef FIN_OCC8   // waves per SIMD asked of the compiler at V = 8 (K = 257..512)
+#define FIN_OCC8 1
+#endif
+__global__ __launch_bounds__(256, (V == 16 || V == 12 ? 2 : V == 8 ? FIN_OCC8 : 1)) void k_finalize(Geometry geo, DeviceState d, Params prm) {
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
   constexpr int G = 64 / W;

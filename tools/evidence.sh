@@ -17,6 +17,7 @@
 #                replaces `tests` by a list of files)
 #   kscan        tools/k_scan.sh
 #   shardcost    per-rank cost-model inputs (tools/shard_cost.py) with per-kernel durations -> shard_cost_model.json
+#   pmc-sq       one SQ-counter pass: share of wave cycles parked / issue-stalled / issuing per kernel (config 5, K = 200)
 #   pmc-shard    rocprofv3 kernel stats + --pmc FETCH_SIZE / WRITE_SIZE passes of rank 0 of 8 in both sharded layouts -> per-kernel roofline table
 #   cli          bench.py's cli_end_to_end record alone
 #   forced       bench.py --force-sharded (real librccl, world of one) on ca-AstroPh K=20 and K=200: sharded driver vs plain engine
@@ -85,6 +86,17 @@ for step in "$@"; do
          f=$(find $O/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/shard_rank0of8_kernel_stats_$t.csv
          rm -rf $O/prof_$t
        done) ;;
+    pmc-sq)   # where the wave cycles go (parked on memory / issue-stalled / issuing, VALU share): config 5 and config 4's shape on one GPU
+      ARGS=""
+      for wl in mmsb:1000000:512:24 astroph-k200; do
+        w=$(echo $wl | tr ':' '_')
+        (cd /tmp && export TMPDIR=/tmp
+         timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES \
+           --kernel-trace --output-format csv -d $O/sq_$w -o p -- python $R/tools/kernel_times.py $wl 6 > $O/pmcsq_$w.log 2>&1)
+        ARGS="$ARGS $wl $O/sq_$w"
+      done
+      python tools/pmc_sq.py $O/sq_wave_cycles_pmc.txt $ARGS
+      rm -rf $O/sq_* ;;
     pmc-shard)   # roofline records of the kernels a SHARDED run executes: rank 0 of 8 of config 5 in both layouts, config 4 K-sharded
       ARGS=""
       for spec in "mmsb:1000000:512:24 kshard 8 0" "mmsb:1000000:512:24 nodeblock 8 0" "astroph-k200 kshard 8 0" "astroph-k200 nodeblock 8 0"; do
