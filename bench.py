@@ -146,13 +146,12 @@ def dense_only_window(setup, k, device, min_launches=10):
     scratch set-up) that belong to no sweep."""
     from svinet_amd import _svils
     e = setup.engine(use_validation_stop=False, device=device)
-    gamma0, lam0 = setup.gamma, setup.lam
+    gamma0 = setup.gamma if setup.host_gamma else None
     tot_ms, tot_n, tot_links, reps = 0.0, 0, [0, 0, 0], 0
     first = True
     while tot_n < min_launches:
         if not first:
-            e.set_state(gamma0, lam0)
-            e.set_control(iter=0, annealing=1, write_comm=0, nh=0, prev_h=-2147483647.0, max_h=-2147483647.0)
+            _reseed(e, setup, gamma0)
         e.enable_timing(0 if first else (1 << _svils.KERNEL_PHI), 1)
         before = e.control().sweeps_done
         e.sweep(4)
@@ -195,10 +194,13 @@ def _pull_model(rec, k, n_nodes):
             "model": "16*K*L_softmax + 16*K*N (neighbour rows + own row + one gammanext row per node)"}
 
 
-def _reseed(eng, gamma0, lam0):
+def _reseed(eng, setup, gamma0=None):
     """back to the seeded initial state of `LinkSampling ls(env, network)`: gamma / lambda of init_gamma2 /
     init_lambda, the constructor's loop state (src/linksampling.cc:19-33), no converged flag"""
-    eng.set_state(gamma0, lam0)
+    if setup.host_gamma:
+        eng.set_state(setup.gamma if gamma0 is None else gamma0, setup.lam)
+    else:
+        setup.device_init(eng)          # drawn again on the device (svils_init_gamma: the same bits, ~30 ms at n = 1e6, k = 512)
     eng.set_control(iter=0, annealing=1, write_comm=0, nh=0, prev_h=-2147483647.0, max_h=-2147483647.0)
 
 
@@ -208,11 +210,11 @@ def repeated_windows(eng, setup, warmup, steps, reps, torch, runner=None, dist=N
     hipGraph replay, no per-kernel events).  A 20-sweep window is 1.2 ms of GPU time: a single one on a fresh
     lease sees clocks that have not settled, the median over repetitions does not."""
     import numpy as np
-    gamma0, lam0 = setup.gamma, setup.lam
+    gamma0 = setup.gamma if setup.host_gamma else None
     times, finals = [], []
     runner = runner or eng     # N > 1: the sharded driver (every rank re-seeds its replica of the state; MAX over ranks per window)
     for _ in range(reps):
-        _reseed(eng, gamma0, lam0)
+        _reseed(eng, setup, gamma0)
         runner.sweep(warmup)
         times.append(_timed(runner, eng, steps, dist, torch))
         c = eng.control()
@@ -416,21 +418,22 @@ def cli_end_to_end(path, n, k, value_ms_per_step):
 
 
 def _load_workload(name):
-    """-> (setup, path, pairs, n, k, data description)"""
+    """-> (setup, path, pairs, n, k, data description).  The generated graphs (hundreds of thousands of nodes and up) leave
+    init_gamma2 to the device (Setup(host_gamma=False) -> svils_init_gamma, bit-identical): no n x k array on the host"""
     from svinet_amd.host_api import Setup
     path, pairs = None, None
     if name.startswith("synthetic"):
         _, sn, sk, sd = name.split(":")
         n, k = int(sn), int(sk)
         pairs = _synthetic_pairs(n, int(sd), 20240517)
-        setup = Setup(n=n, k=k, pairs=pairs)
+        setup = Setup(n=n, k=k, pairs=pairs, host_gamma=False)
         data = "synthetic sparse graph (ring + uniform random pairs, seed 20240517), seeded init"
     elif name.startswith("mmsb"):
         from svinet_amd import mmsbgen_sparse
         _, sn, sk, sd = name.split(":")
         n, k = int(sn), int(sk)
         pairs = mmsbgen_sparse.generate(n, k, int(sd))
-        setup = Setup(n=n, k=k, pairs=pairs)
+        setup = Setup(n=n, k=k, pairs=pairs, host_gamma=False)
         data = ("synthetic sparse MMSB graph (svinet_amd/mmsbgen_sparse.py: Dirichlet(0.05) top-4 memberships, "
                 "Beta(4700.59,0.77) rates, Philox seed %d), seeded init" % mmsbgen_sparse.DEFAULT_SEED)
     else:
@@ -503,7 +506,10 @@ class _KSharded:
                                      use_validation_stop=False, device=device, k_slice=(k0, k1))
         e.set_graph(setup.links)
         e.set_validation(setup.validation_sorted)
-        e.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+        if setup.host_gamma:
+            e.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+        else:
+            setup.device_init(e, lam=np.ascontiguousarray(setup.lam[k0:k1]))
         ids = [_svils.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         e.comm_init(ids[0], rank, world)
@@ -781,7 +787,7 @@ def main():
                          "config": {"workload": "%s: n=%d k=%d links/sweep=%d, sweeps %d..%d of the seeded run, node blocks x%d"
                                                 % (args.workload, n, k, L, args.warmup, args.warmup + args.steps, world)}})
         eng.set_option("sharded_graphs", 1)
-        _reseed(eng, setup.gamma, setup.lam)
+        _reseed(eng, setup)
     runner.sweep(args.warmup)
     period = max(1, min(args.event_period, args.steps // 10))   # >= 10 timed launches whenever steps >= 10
     # The timed region carries no hipEvents: svils_sweep replays whole sweeps as hipGraphs (N = 1) / the sharded
@@ -821,7 +827,7 @@ def main():
             elapsed = float(np.median(np.asarray(times)))
             ctrl = eng.control()
         # event pass of its own over the same window: every `period`-th sweep launches eagerly between hipEvents
-        _reseed(eng, setup.gamma, setup.lam)
+        _reseed(eng, setup)
         eng.sweep(args.warmup)
         eng.enable_timing(1 << _svils.KERNEL_PHI, period)
         eng.sweep(args.steps)

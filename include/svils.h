@@ -150,7 +150,9 @@ int svils_set_state(svils_handle *h, const double *gamma, const double *lambda,
  *              where the reference's generator stands when init_gamma2 starts (after the validation sampler's draws).
  *              host/mtjump.hh computes them by jump-ahead; streams x outputs_per_stream must cover nedges * k exactly once.
  *   lambda     [k][2] as for svils_set_state (init_lambda, src/linksampling.cc:364-372); the converged flags are zeroed.
- * Whole-graph handles only (SVILS_ERR_UNSUPPORTED otherwise: upload the state).  Needs 4 * nedges * k bytes of device scratch
+ * Any handle: a node-block handle holds every row anyway; a K-sharded one (k_total columns drawn per link, its slice kept,
+ * lambda = the slice's rows; svils_ksh_init_state follows as after svils_set_state) regenerates the whole stream on every
+ * rank -- what a rank saves is the host's 2.9 s and its n x k_total array.  Needs 4 * nedges * k_total bytes of device scratch
  * for the duration of the call (24 GB at n = 1e6, k = 512; SVILS_ERR_NOMEM if it is not there: upload the state instead).
  * Replaces 2.9 s of host work + a 4.1 GB upload by ~0.1 s of host work (the states) + ~30 ms of device work at that size. */
 int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, const uint32_t *mt_states, uint64_t nstreams,

@@ -18,6 +18,8 @@
 //                   compiler's correctly rounded sequence) column by column in link order.  No atomics, no scatter.
 //
 // Then the tail of svils_set_state (lambda, flags, expectations).  Same bits as the host path: tests/test_gpu_init.py.
+// Node-block handles (the state is replicated) take the same call; a K-sharded handle draws the whole stream too and keeps
+// its column slice of every link's vector, divided by the sum over ALL columns (k_link_sums).
 #include "svils_handle.h"
 
 #include <time.h>
@@ -67,10 +69,27 @@ __global__ __launch_bounds__(64) void k_mt_generate(const uint32_t *__restrict__
   }
 }
 
-// one wavefront per node; lane t holds columns t, t + 64, ... (J of them)
+// the links' sums as 64-bit integers (K-sharded handles: a rank divides its COLUMN SLICE of every link's vector by the sum over
+// ALL k_total draws): one wavefront per link
+__global__ __launch_bounds__(256) void k_link_sums(uint64_t nedges, uint32_t Kt, const uint32_t *__restrict__ raw,
+                                                   unsigned long long *__restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  for (uint64_t l = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); l < nedges; l += (uint64_t)gridDim.x * 4) {
+    unsigned long long tot = 0;
+    for (uint32_t k = (uint32_t)lane; k < Kt; k += 64u) tot += raw[l * Kt + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += (unsigned long long)__shfl_xor((long long)tot, o, 64);
+    if (lane == 0) sums[l] = tot;
+  }
+}
+
+// one wavefront per node; lane t holds columns t, t + 64, ... (J of them) of the handle's K columns, which are the columns
+// [K0, K0 + K) of the Kt every link draws (whole-row handles: K0 = 0, K = Kt, and the link's sum is formed here from the words
+// the wavefront holds anyway; column slices read it from `sums`)
 template <int J>
-__global__ __launch_bounds__(256) void k_init_rows(uint32_t n, uint32_t K, uint32_t ld, const uint64_t *__restrict__ rowptr,
-                                                   const uint32_t *__restrict__ elink, const uint32_t *__restrict__ raw,
+__global__ __launch_bounds__(256) void k_init_rows(uint32_t n, uint32_t K, uint32_t K0, uint32_t Kt, uint32_t ld,
+                                                   const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ elink,
+                                                   const uint32_t *__restrict__ raw, const unsigned long long *__restrict__ sums,
                                                    double *__restrict__ gamma) {
   const int lane = threadIdx.x & 63;
   const uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -80,26 +99,32 @@ __global__ __launch_bounds__(256) void k_init_rows(uint32_t n, uint32_t K, uint3
   for (int j = 0; j < J; ++j) acc[j] = 0.0;
   const uint64_t b = rowptr[x], e = rowptr[x + 1];
   uint32_t wnext[J];
-  auto fetch = [&](uint64_t ent, uint32_t (&w)[J]) {
-    const uint64_t base = (uint64_t)elink[ent] * K;
+  unsigned long long snext = 0;
+  auto fetch = [&](uint64_t ent, uint32_t (&w)[J], unsigned long long &sl) {
+    const uint32_t l = elink[ent];
+    const uint64_t base = (uint64_t)l * Kt + K0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const uint32_t k = (uint32_t)lane + 64u * (uint32_t)j;
       w[j] = k < K ? raw[base + k] : 0u;
     }
+    if (sums) sl = sums[l];
   };
-  if (b < e) fetch(b, wnext);
+  if (b < e) fetch(b, wnext, snext);
   for (uint64_t ent = b; ent < e; ++ent) {
     uint32_t w[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) w[j] = wnext[j];
-    if (ent + 1 < e) fetch(ent + 1, wnext);   // the next link's words are in flight while this one is divided
-    unsigned long long tot = 0;
+    unsigned long long tot = snext;
+    if (ent + 1 < e) fetch(ent + 1, wnext, snext);   // the next link's words are in flight while this one is divided
+    if (!sums) {
+      tot = 0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) tot += w[j];
+      for (int j = 0; j < J; ++j) tot += w[j];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += (unsigned long long)__shfl_xor((long long)tot, o, 64);
-    const double s = (double)tot * 2.3283064365386963e-10;   // 2^-32: the sum of the K uniforms, exact
+      for (int o = 32; o > 0; o >>= 1) tot += (unsigned long long)__shfl_xor((long long)tot, o, 64);
+    }
+    const double s = (double)tot * 2.3283064365386963e-10;   // 2^-32: the sum of the link's uniforms, exact
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const double u = (double)w[j] * 2.3283064365386963e-10;   // gsl_rng_uniform: w / 4294967296.0
@@ -124,13 +149,12 @@ int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, co
   if (!h || (!edges && nedges) || !mt_states || !lambda || nstreams == 0 || outputs_per_stream == 0)
     return fail(SVILS_ERR_ARG, "svils_init_gamma: null argument");
   const Geometry &g = h->geo;
-  if (h->d.ksh || g.node_begin != 0 || g.node_end != g.n)
-    return fail(SVILS_ERR_UNSUPPORTED, "svils_init_gamma: whole-graph handles only (a sharded run uploads its share: svils_set_state)");
-  const uint64_t total = nedges * (uint64_t)g.K;
+  // (node-block handles hold every row of the state; K-sharded ones their column slice of every row: both are drawn here in full)
+  const uint64_t total = nedges * (uint64_t)g.Kt;
   if (nedges >= (1ull << 32)) return fail(SVILS_ERR_UNSUPPORTED, "svils_init_gamma: links are indexed with 32 bits");
   if (nstreams > (1ull << 24) || (total && (nstreams - 1) * outputs_per_stream >= total) || nstreams * outputs_per_stream < total)
     return fail(SVILS_ERR_ARG, "svils_init_gamma: %llu streams of %llu outputs do not cover the %llu x %u uniforms exactly once",
-                (unsigned long long)nstreams, (unsigned long long)outputs_per_stream, (unsigned long long)nedges, g.K);
+                (unsigned long long)nstreams, (unsigned long long)outputs_per_stream, (unsigned long long)nedges, g.Kt);
   HIPCHK(hipSetDevice(h->cfg.device));
 #ifdef SVILS_TESTING
   const auto tclock = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
@@ -141,7 +165,9 @@ int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, co
   // scratch of this call alone (the raw words are 4 E K bytes: 24 GB at n = 1e6, k = 512): freed before returning
   uint32_t *d_raw = nullptr, *d_states = nullptr, *d_elink = nullptr;
   uint64_t *d_rowptr = nullptr;
+  unsigned long long *d_sums = nullptr;
   auto release = [&] {
+    if (d_sums) (void)hipFree(d_sums);
     if (d_raw) (void)hipFree(d_raw);
     if (d_states) (void)hipFree(d_states);
     if (d_elink) (void)hipFree(d_elink);
@@ -190,9 +216,14 @@ int svils_init_gamma(svils_handle *h, const uint32_t *edges, uint64_t nedges, co
   if ((rc = chk(hipMalloc((void **)&d_rowptr, rowptr.size() * sizeof(uint64_t)), "hipMalloc"))) return rc;
   if ((rc = chk(hipMemcpyAsync(d_elink, elink.data(), elink.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "upload"))) return rc;
   if ((rc = chk(hipMemcpyAsync(d_rowptr, rowptr.data(), rowptr.size() * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream), "upload"))) return rc;
+  if (g.K != g.Kt) {   // a column slice: the links' sums over all k_total draws first
+    if ((rc = chk(hipMalloc((void **)&d_sums, std::max<uint64_t>(nedges, 1) * sizeof(unsigned long long)), "hipMalloc"))) return rc;
+    const uint32_t nbs = (uint32_t)std::min<uint64_t>((nedges + 3) / 4 + 1, 1u << 16);
+    hipLaunchKernelGGL(k_link_sums, dim3(nbs), dim3(256), 0, h->stream, nedges, g.Kt, d_raw, d_sums);
+  }
   const uint32_t nb = (n + 3) / 4;
   const int J = (int)((g.K + 63) / 64);
-#define ROWS(J_) hipLaunchKernelGGL((k_init_rows<J_>), dim3(nb), dim3(256), 0, h->stream, n, g.K, g.ld, d_rowptr, d_elink, d_raw, h->d.gamma)
+#define ROWS(J_) hipLaunchKernelGGL((k_init_rows<J_>), dim3(nb), dim3(256), 0, h->stream, n, g.K, g.K0, g.Kt, g.ld, d_rowptr, d_elink, d_raw, d_sums, h->d.gamma)
   if (J <= 1) ROWS(1);
   else if (J <= 2) ROWS(2);
   else if (J <= 4) ROWS(4);

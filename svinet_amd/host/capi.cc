@@ -25,6 +25,7 @@ typedef struct {
   uint32_t lt_min_deg;
   int32_t eta_type;        // 0 uniform, 1 fromdata, 2 sparse, 3 dense
   int32_t accuracy;
+  int32_t defer_gamma;     // 1: no host init_gamma2 (the caller draws on the device: svih_init_links / svih_init_streams -> svils_init_gamma)
 } svih_options;
 
 struct svih_setup {
@@ -46,6 +47,7 @@ static svih_setup *make_setup(const svih_options *o, const char *path, const int
   a.lt_min_deg = o->lt_min_deg;
   a.eta_type = eta_names[(o->eta_type >= 0 && o->eta_type < 4) ? o->eta_type : 0];
   a.accuracy = o->accuracy != 0;
+  a.defer_init_gamma = o->defer_gamma != 0;
   a.write_files = false;
   svih_setup *s = new svih_setup();
   s->env.reset(new Env(a));
@@ -63,7 +65,7 @@ static svih_setup *make_setup(const svih_options *o, const char *path, const int
 void svih_options_default(svih_options *o, uint32_t n, uint32_t k) {
   memset(o, 0, sizeof *o);
   o->n = n; o->k = k; o->seed = 0; o->heldout_ratio = 0.01; o->link_thresh = 0.5;
-  o->lt_min_deg = 0; o->eta_type = 0; o->accuracy = 0;
+  o->lt_min_deg = 0; o->eta_type = 0; o->accuracy = 0; o->defer_gamma = 0;
 }
 svih_setup *svih_setup_from_file(const char *path, const svih_options *o) { return make_setup(o, path, nullptr, 0); }
 svih_setup *svih_setup_from_pairs(const int32_t *pairs, uint64_t nlines, const svih_options *o) {
@@ -80,7 +82,7 @@ double svih_ones_prob(const svih_setup *s) { return s->ls->ones_prob(); }
 double svih_eta0(const svih_setup *s) { return s->env->eta0; }
 double svih_eta1(const svih_setup *s) { return s->env->eta1; }
 const uint32_t *svih_seq2id(const svih_setup *s) { return s->net->seq2id().data(); }
-const double *svih_gamma(const svih_setup *s) { return s->ls->gamma().data(); }
+const double *svih_gamma(const svih_setup *s) { return s->ls->gamma().empty() ? nullptr : s->ls->gamma().data(); }   // null: defer_gamma
 const double *svih_lambda(const svih_setup *s) { return s->ls->lambda().data(); }
 uint64_t svih_nvalidation(const svih_setup *s) { return s->ls->validation_sorted().size() / 3; }
 const uint32_t *svih_validation_sorted(const svih_setup *s) { return s->ls->validation_sorted().data(); }

@@ -57,6 +57,7 @@ Env::Env(const Args &a)
       eta_type(a.eta_type),
       use_validation_stop(a.use_validation_stop),
       accuracy(a.accuracy),
+      defer_init_gamma(a.defer_init_gamma),
       link_thresh(a.link_thresh), lt_min_deg(a.lt_min_deg),
       model_load(a.load), gamma_location(a.location),
       load_heldout(a.val_load), load_heldout_fname(a.val_file_location),

@@ -30,6 +30,7 @@ class Env {
     std::string eta_type = "uniform";
     uint32_t rfreq = 1;
     bool accuracy = false;
+    bool defer_init_gamma = false;   // library callers (host_api.Setup(host_gamma=False)): init_gamma2 is left to svils_init_gamma
     uint32_t max_iterations = 0;
     bool use_validation_stop = true;
     double rand_seed = 0;
@@ -75,6 +76,7 @@ class Env {
   std::string eta_type;
   bool use_validation_stop;
   bool accuracy;
+  bool defer_init_gamma;
   double link_thresh;
   uint32_t lt_min_deg;
   bool model_load;

@@ -137,7 +137,7 @@ LinkSampling::LinkSampling(Env &env, Network &network, bool attach_device)
 
   mark("held-out sets done");
   lambda_.assign(2 * (size_t)k_, 0.0);
-  defer_init_ = !env_.model_load && !env_.use_init_communities && device_init_wanted(attach_device);
+  defer_init_ = !env_.model_load && !env_.use_init_communities && (device_init_wanted(attach_device) || (!attach_device && env_.defer_init_gamma));
   if (!defer_init_) gamma_.assign((size_t)n_ * k_, 0.0);   // (left to the device: no host copy until the final fetch)
   if (env_.model_load) {
     if (load_model() < 0) exit(-1);

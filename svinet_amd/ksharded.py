@@ -41,7 +41,10 @@ class KShard:
         self.engine = e = Engine(setup.n, setup.k, **args)
         e.set_graph(setup.links)
         e.set_validation(setup.validation_sorted)
-        e.set_state(np.ascontiguousarray(setup.gamma[:, self.k0:self.k1]), np.ascontiguousarray(setup.lam[self.k0:self.k1]))
+        if getattr(setup, "host_gamma", True):
+            e.set_state(np.ascontiguousarray(setup.gamma[:, self.k0:self.k1]), np.ascontiguousarray(setup.lam[self.k0:self.k1]))
+        else:   # init_gamma2 on the device: this rank's column slice of every link's draws (svils_init_gamma)
+            setup.device_init(e, lam=np.ascontiguousarray(setup.lam[self.k0:self.k1]))
         dev = torch.device("cuda", device_index)
         self.stream = torch.cuda.ExternalStream(e.stream(), device=dev)
         self.buf = {}

@@ -21,7 +21,9 @@ def config5():
     from svinet_amd.host_api import Setup
     n, k = 1_000_000, 512
     pairs, truth = G.generate(n, k, 24, return_truth=True)
-    s = Setup(n=n, k=k, pairs=pairs)
+    # host_gamma=False: the seeded gamma of every engine below is DRAWN ON THE DEVICE (svils_init_gamma: whole rows for the plain
+    # engines, column slices for the eight K-shards) -- so the oracle digests also hold the device form of init_gamma2 at full size
+    s = Setup(n=n, k=k, pairs=pairs, host_gamma=False)
     yield n, k, pairs, truth, s
     s.close()
 

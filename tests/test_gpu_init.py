@@ -64,3 +64,38 @@ def test_cli_device_init_leaves_the_same_files(graph_files, tmp_path):
         assert (outs[0] / name).read_bytes() == (outs[1] / name).read_bytes(), name
     va, vb = np.loadtxt(outs[0] / "validation.txt"), np.loadtxt(outs[1] / "validation.txt")
     assert np.array_equal(np.delete(va, 1, axis=1), np.delete(vb, 1, axis=1))      # (column 1 is the wall-clock duration)
+
+
+def test_device_init_on_node_block_and_ksharded_handles(graph_files):
+    """svils_init_gamma on the handles of the two multi-GPU layouts: a node-block handle (the replicated state: every row) and
+    K-sharded handles (uneven column slices of every link's vector, divided by the sum over ALL columns) -- the host path's bits"""
+    from svinet_amd import _svils
+    from svinet_amd.host_api import Setup
+    from svinet_amd.ksharded import KShard, column_slices, init_virtual, sweep_virtual
+    s = Setup(graph_files["lfr"], 1000, 100)
+    nb = s.engine(use_validation_stop=False, node_block=(250, 700))
+    s.device_init(nb)
+    assert np.array_equal(nb.state()[0], s.gamma)
+    for (k0, k1) in column_slices(100, 3):
+        e = _svils.Engine(s.n, s.k, ones=s.ones, ones_prob=s.ones_prob, eta=s.eta, use_validation_stop=False, k_slice=(k0, k1))
+        e.set_graph(s.links)
+        e.set_validation(s.validation_sorted)
+        s.device_init(e, lam=np.ascontiguousarray(s.lam[k0:k1]))
+        assert np.array_equal(e.state()[0], s.gamma[:, k0:k1]), (k0, k1)
+    # a Setup WITHOUT a host gamma (what bench.py and the config-5 tests use at n = 1e6): its engines and K-shards draw on the
+    # device and then run like the ones that were handed the host's array
+    s2 = Setup(graph_files["lfr"], 1000, 100, host_gamma=False)
+    with pytest.raises(AttributeError):
+        s2.gamma
+    a, b = s2.engine(use_validation_stop=False), s.engine(use_validation_stop=False)
+    assert np.array_equal(a.state()[0], s.gamma)
+    a.sweep(5)
+    b.sweep(5)
+    assert np.array_equal(a.state()[0], b.state()[0])
+    sh2 = [KShard(s2, r, 3, 0, use_validation_stop=False) for r in range(3)]
+    sh1 = [KShard(s, r, 3, 0, use_validation_stop=False) for r in range(3)]
+    for sh in (sh1, sh2):
+        init_virtual(sh)
+        sweep_virtual(sh, 4)
+    for x, y in zip(sh1, sh2):
+        assert np.array_equal(x.engine.state()[0], y.engine.state()[0])

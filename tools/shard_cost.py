@@ -113,7 +113,10 @@ for G in Gs:
     ks = _svils.Engine(n, k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, link_thresh=setup.link_thresh,
                        lt_min_deg=setup.lt_min_deg, use_validation_stop=False, k_slice=(k0, k1))
     ks.set_graph(setup.links); ks.set_validation(setup.validation_sorted)
-    ks.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+    if setup.host_gamma:
+        ks.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+    else:
+        setup.device_init(ks, lam=np.ascontiguousarray(setup.lam[k0:k1]))
     ks.ksh_init_state()
     log = ks.ksh_log_domain() == 1
     def run_ks(s):

@@ -23,7 +23,10 @@ if layout == "kshard":
     e = _svils.Engine(n, k, ones=setup.ones, ones_prob=setup.ones_prob, eta=setup.eta, link_thresh=setup.link_thresh,
                       lt_min_deg=setup.lt_min_deg, use_validation_stop=False, k_slice=(k0, k1))
     e.set_graph(setup.links); e.set_validation(setup.validation_sorted)
-    e.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+    if setup.host_gamma:
+        e.set_state(np.ascontiguousarray(setup.gamma[:, k0:k1]), np.ascontiguousarray(setup.lam[k0:k1]))
+    else:
+        setup.device_init(e, lam=np.ascontiguousarray(setup.lam[k0:k1]))
     e.ksh_init_state()
     log = e.ksh_log_domain() == 1
     phases = ([_svils.KPHASE_DENMAX] if log else []) + list(range(5))
