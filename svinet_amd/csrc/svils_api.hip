@@ -250,7 +250,11 @@ int svils_create(const svils_config *cfg, svils_handle **out) {
     guard(dalloc(h, &d.rowx, 3 * (size_t)g.n));
     guard(dalloc(h, &d.q2v, g.Kt));
   }
-  d.skip_elogpi = (!d.ksh && d.epi && !use_lpl(g.K) && g.K <= 512u && cfg->link_thresh >= 0.5) ? 1 : 0;   // svils_internal.h
+  {   // svils_internal.h: DeviceState::skip_elogpi
+    const bool can = !d.ksh && d.epi && !use_lpl(g.K) && g.K <= 512u && cfg->link_thresh >= 0.5;
+    const bool big = nk * sizeof(double) >= ((size_t)256 << 20);
+    d.skip_elogpi = (can && (h->opt.skip_elogpi < 0 ? big : h->opt.skip_elogpi != 0)) ? 1 : 0;
+  }
   if (d.skip_elogpi) d.gacc = d.elogpi;   // (the array is free: nothing stores or reads Elogpi rows on such a handle)
   guard(dalloc(h, &d.mphi, nk));
   guard(dalloc(h, &d.conv, 2 * (size_t)g.n_alloc));

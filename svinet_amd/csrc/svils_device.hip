@@ -68,13 +68,41 @@ __device__ __forceinline__ void store_epi(const DeviceState &d, uint32_t p, int 
   store_row<W, V>(d.epi + (size_t)p * ld, lw, ld, e);
 }
 
+// The rare path of the product form on a handle that stores no Elogpi (DeviceState::skip_elogpi): x_k = Elogpi[p][k] +
+// Elogbeta[k][0] + Elogpi[q][k] of this lane's columns, re-derived from the gamma rows (psi(gamma) - psi(row sum), the row sums
+// added in the order k_finalize adds them: the values it would have stored) into the wavefront's LDS scratch xl[v][lane].
+// Only the REDO launch (k_phi<V, false, true, 2>) contains it: in the launch every sweep runs its mere presence -- inline or as a
+// call -- cost 24 - 61 spilled VGPRs and a stack (ca-AstroPh K = 200: phi 88 -> 130 us with the code never executed).
+template <int W, int V>
+__device__ __noinline__ void elogpi_pair_from_gamma(const double *__restrict__ gamma, const double *__restrict__ elogbeta, uint32_t p,
+                                                    uint32_t q, uint32_t ld, uint32_t K, int lw, const double2 *logtab, double *xl) {
+  double sp = 0.0, sq = 0.0;
+#pragma unroll 1
+  for (int v = 0; v < V; ++v) {
+    const int k = kmap<W, V>(lw, v);
+    if ((uint32_t)k < K) { sp += gamma[(size_t)p * ld + k]; sq += gamma[(size_t)q * ld + k]; }
+  }
+  const double psp = digamma(group_sum<W>(sp), logtab), psq = digamma(group_sum<W>(sq), logtab);
+#pragma unroll 1
+  for (int v = 0; v < V; ++v) {
+    const int k = kmap<W, V>(lw, v);
+    double t = NEG_INF;
+    if ((uint32_t)k < K)
+      t = ((digamma(gamma[(size_t)p * ld + k], logtab) - psp) + elogbeta[2 * k]) + (digamma(gamma[(size_t)q * ld + k], logtab) - psq);
+    xl[v * 64 + lw] = t;
+  }
+}
+
 // ============================================================== phi pass (A6)
 // src/linksampling.cc:605-725, pull-style, K > 32 (K <= 32 uses k_phi_lpl).  One
 // wavefront per Item (a chunk of <= 32 neighbours of one node), all 64 lanes on one
 // row, V doubles per lane.  The chunk's column indices and converged flags are
 // fetched with one coalesced load each, and the next neighbour's Elogpi row is in
 // flight while the current one is reduced (two rows per wave in flight).
-template <int V, bool LOWT, bool EPI>
+// FB (product form only): what a link does whose row product underflows -- 0: the log-domain rows from the stored Elogpi; handles
+// that store none (DeviceState::skip_elogpi): 1 = the launch every sweep runs: raise DevCtrl::phi_redo, nothing else; 2 = the redo
+// launch behind it: returns at once unless the flag is this sweep's, else the whole pass again with the rows re-derived from gamma.
+template <int V, bool LOWT, bool EPI, int FB = 0>
 // waves per SIMD asked of the compiler.  V = 16 (K = 513..1024): two -- the kernel then keeps 256 VGPRs and spills ~90 to
 // scratch, which still beats one 512-register wave per SIMD (ca-AstroPh K=640 phi 576 -> 397 us, K=1024 574 -> 503 us; n=2e5
 // K=640 5.5 -> 4.6 ms, n=1e5 K=1024 unchanged; three waves per SIMD: 4x slower) -- profiles/r02_ubench_and_rejected_variants.txt
@@ -83,11 +111,14 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : V <= 1
   constexpr bool PROD = EPI && !LOWT;   // product form on exp(Elogpi) rows, else exps of sums of Elogpi rows
   DevCtrl *ctrl = d.ctrl;
   if (ctrl->stopped) return;
-  __shared__ double lds[V * 64];
-  __shared__ double2 logtab[PROD ? 128 : 1];   // (the underflow fall-back of a handle that does not store Elogpi evaluates psi itself)
-  if constexpr (PROD) {
-    if (d.skip_elogpi) { load_logtab(logtab, d.logtab); __syncthreads(); }
+  if constexpr (FB == 2) {
+    if (ctrl->phi_redo != ctrl->sweeps_done + 1u) return;   // no link of this sweep's fast launch underflowed: nothing to redo
   }
+  __shared__ double lds[V * 64];
+  // (the redo launch evaluates psi itself and parks the re-derived x_k in LDS)
+  __shared__ double2 logtab[FB == 2 ? 128 : 1];
+  __shared__ double xlds[FB == 2 ? 4 * V * 64 : 1];
+  if constexpr (FB == 2) { load_logtab(logtab, d.logtab); __syncthreads(); }
   // wave-uniform by construction; said so explicitly, or the compiler keeps the item loop and the neighbour loop
   // under exec masks with vector compares (it cannot see that threadIdx.x >> 6 is the same in all 64 lanes)
   // (measured: V = 4: phi -10 % and 96 instead of 111 VGPRs; V = 8: neutral; V <= 2: +7 %, left alone)
@@ -170,8 +201,12 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : V <= 1
           if (kidx[v] == c) acc[v] += 1.0;
         if (count_me && lane == 0) n_short++;
       } else {
-        bool sparse = false;
-        if (sparse_iter) sparse = p_active < geo.k10 && d.active_cnt[q] < geo.k10;
+        bool sparse = false, empty_union = false;
+        if (sparse_iter) {
+          const uint32_t q_active = d.active_cnt[q];
+          sparse = p_active < geo.k10 && q_active < geo.k10;
+          empty_union = sparse && (p_active | q_active) == 0u;   // (both bitmasks are the nodes' exact active sets on this branch)
+        }
         // x_k = Elogpi[p][k] + Elogpi[q][k] + Elogbeta[k][0]; padding columns and, on the active-set
         // path, columns outside the union -> -inf
         auto xk = [&](int v) {
@@ -200,25 +235,19 @@ __global__ __launch_bounds__(256, (V <= 2 ? 6 : V == 4 ? 5 : V == 8 ? 3 : V <= 1
           }
           s = group_sum<W>(s);
           bool live = true;
-          if (s < 1e-280) {   // wave-uniform, rare: the log-domain rows from Elogpi, column by column to
-                              // keep the registers of the common path (two passes: max, then exp)
-            // (DeviceState::skip_elogpi: no stored Elogpi -- psi(gamma) - psi(row sum) of the two rows, the row sums added in
-            //  the order k_finalize adds them, so the values are the ones it would have stored)
-            double psp = 0.0, psq = 0.0;
-            if (d.skip_elogpi) {
-              double sp = 0.0, sq = 0.0;
-#pragma unroll 1
-              for (int v = 0; v < V; ++v)
-                if (kval[v]) { sp += d.gamma[(size_t)p * ld + kidx[v]]; sq += d.gamma[(size_t)q * ld + kidx[v]]; }
-              psp = digamma(group_sum<W>(sp), logtab);
-              psq = digamma(group_sum<W>(sq), logtab);
-            }
+          if (FB == 1 && empty_union) {
+            live = false;       // an empty active-set union contributes nothing (:642-664): a plain zero, not an underflow
+          } else if (FB == 1 && s < 1e-280) {
+            if (lane == 0) ctrl->phi_redo = ctrl->sweeps_done + 1u;   // the launch behind this one redoes the pass (see FB)
+            live = false;
+          } else if (FB != 1 && s < 1e-280) {   // wave-uniform, rare: the log-domain rows, column by column to
+                                                 // keep the registers of the common path (two passes: max, then exp)
+            double *xl = xlds + (size_t)wave * V * 64;
+            if constexpr (FB == 2) elogpi_pair_from_gamma<W, V>(d.gamma, d.elogbeta, p, q, ld, K, lw, logtab, xl);
             auto xlog = [&](int v) {
               double t = NEG_INF;
               if (kval[v]) {
-                if (d.skip_elogpi)
-                  t = ((digamma(d.gamma[(size_t)p * ld + kidx[v]], logtab) - psp) + d.elogbeta[2 * kidx[v]]) +
-                      (digamma(d.gamma[(size_t)q * ld + kidx[v]], logtab) - psq);
+                if constexpr (FB == 2) t = xl[v * 64 + lw];
                 else t = (d.elogpi[(size_t)p * ld + kidx[v]] + d.elogbeta[2 * kidx[v]]) + d.elogpi[(size_t)q * ld + kidx[v]];
               }
               if (sparse) {
@@ -1444,7 +1473,10 @@ void launch_phi(const Geometry &g, const DeviceState &d, const Params &p, hipStr
 #define PHI(V_)                                                                                    \
   do {                                                                                             \
     if (p.link_thresh < 0.5) hipLaunchKernelGGL((k_phi<V_, true, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p); \
-    else if (d.epi) hipLaunchKernelGGL((k_phi<V_, false, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);       \
+    else if (d.epi && d.skip_elogpi && V_ <= 8) {                                                                 \
+      hipLaunchKernelGGL((k_phi<(V_ <= 8 ? V_ : 8), false, true, 1>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);   \
+      hipLaunchKernelGGL((k_phi<(V_ <= 8 ? V_ : 8), false, true, 2>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);   \
+    } else if (d.epi) hipLaunchKernelGGL((k_phi<V_, false, true>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);       \
     else hipLaunchKernelGGL((k_phi<V_, false, false>), dim3(d.nb_a), dim3(256), 0, s, g, d, p);                  \
   } while (0)
   switch (g.V) {   // K > 32 => W == 64

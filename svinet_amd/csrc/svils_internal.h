@@ -41,6 +41,10 @@ struct DevCtrl {
   // blocks of a launch are not co-resident (a partitioned or masked device); every host entry that reads
   // the control block turns it into SVILS_ERR_DEVICE
   uint32_t fault;
+  // Handles that store no Elogpi (DeviceState::skip_elogpi): the fast phi launch carries no log-domain fall-back; when a link's row
+  // product underflows it writes sweeps_done + 1 here, and the launch behind it -- the same pass with the fall-back compiled in,
+  // which otherwise returns at once -- redoes the whole pass (gamma is intact: such handles accumulate beside it)
+  uint32_t phi_redo;
 };
 
 struct Geometry {
@@ -158,9 +162,14 @@ struct DeviceState {
   // 57 <= K <= 512 with exp(Elogpi) rows and link_thresh >= 1/2: NOTHING in a sweep reads Elogpi -- the phi pass multiplies
   // exp(Elogpi) rows, the likelihood and the s3 pass read gamma -- so the finalise / expand passes do not store it (one n-by-k
   // write less per sweep: 4.1 of 16.4 GB of the finalise launch at n = 1e6, k = 512).  The phi pass's underflow fall-back
-  // (a row product below 1e-280: out of reach below K ~ 600, where psi(1/K) > -600) re-derives the two rows from gamma --
-  // which is why such a handle accumulates gammanext in the buffer Elogpi used to occupy (gacc = elogpi) instead of in place:
-  // gamma stays intact during the phi pass.  svils_get_aux(0) / SVILS_BUF_ELOGPI compute a view on demand (k_dir_exp).
+  // (a row product below 1e-280: reachable at K <= 512 only in degenerate annealing states, psi(1 / 2K) = -1024) re-derives the two
+  // rows from gamma -- NOT in the launch every sweep runs (the mere presence of that code, inline or as a call, costs the phi kernel
+  // 24 - 61 spilled VGPRs and a stack: ca-AstroPh K = 200 phi 88 -> 130 us, profiles/r07j): the fast launch only raises
+  // DevCtrl::phi_redo, and a second launch with the fall-back compiled in, which otherwise returns at once, redoes the pass.
+  // That is possible because such a handle accumulates gammanext in the buffer Elogpi used to occupy (gacc = elogpi) instead of
+  // in place: gamma stays intact during the phi pass.  Taken where the n-by-k state is at least 256 MB (below, the state is
+  // cache-resident and the second launch's ~2 us outweigh the write saved; option skip_elogpi forces either way).
+  // svils_get_aux(0) / SVILS_BUF_ELOGPI compute a view on demand (k_dir_exp).
   int skip_elogpi;
   // K-sharded sweeps (svils_ksh.h): what crosses ranks, each buffer summed over the ranks between two phases
   int ksh;              // 1: the handle holds a column slice

@@ -15,6 +15,7 @@ struct Options {
   int derive_m = 1;             // whole sweeps derive the mean indicators from gamma instead of storing them (K > 56)
   int64_t epi_max_mb = -1;      // largest n-by-k array for which exp(Elogpi) is kept; -1: automatic (svils_create)
   uint32_t graph_after = 128;   // sweeps a handle runs eagerly before svils_sweep captures hipGraphs (0: at once)
+  int skip_elogpi = -1;         // 57 <= K <= 512: Elogpi not stored (DeviceState::skip_elogpi): -1 where the n-by-k state is >= 256 MB, 0 / 1 forced
   int shard_fold = 1;           // node-block sweeps, K <= 32: the kernels leave the K-vectors themselves (no k_colreduce)
   int graph_pow2 = 1;           // replay as few graphs as possible (powers of two up to 64 sweeps); 0: 8-sweep graphs + singles
   // ---- read by svils_set_graph

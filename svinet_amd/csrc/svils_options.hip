@@ -30,6 +30,9 @@ const Row kRows[] = {
     {"epi_max_mb", "SVILS_EPI_MAX_MB", "-1", CREATE, I64, OFF(epi_max_mb), -1, 1ll << 40,
      "largest n-by-k array (MB) for which exp(Elogpi) rows are kept for the product form of the phi pass; -1: always on "
      "whole-graph handles, 1536 on node-block handles"},
+    {"skip_elogpi", "SVILS_SKIP_ELOGPI", "-1", CREATE, I32, OFF(skip_elogpi), -1, 1,
+     "57 <= K <= 512, link_thresh >= 1/2: the finalise / expand passes store no Elogpi rows (nothing in a sweep reads them; the phi pass's "
+     "underflow fall-back becomes a second launch that returns at once unless a link underflowed): -1 where the n-by-k state is >= 256 MB, 0 / 1 forced"},
     {"graph_after", "SVILS_GRAPH_AFTER", "128", ANY, U32, OFF(graph_after), 0, 0xffffffffll,
      "sweeps a handle runs eagerly before svils_sweep / svils_sweep_sharded capture hipGraphs (0: at the first call of >= 4 sweeps)"},
     {"shard_fold", "SVILS_SHARD_FOLD", "1", ANY, I32, OFF(shard_fold), 0, 1,

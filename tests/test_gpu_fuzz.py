@@ -144,13 +144,17 @@ def test_empty_and_tiny_graphs():
         assert np.allclose(g, ref.gamma, rtol=1e-10) and np.allclose(lam, ref.lam, rtol=1e-10)
 
 
-@pytest.mark.parametrize("k", [20, 64, 200])
-def test_softmax_rows_that_underflow(k):
+@pytest.mark.parametrize("k,no_elogpi", [(20, False), (64, False), (200, False), (64, True), (200, True), (500, True)])
+def test_softmax_rows_that_underflow(k, no_elogpi, monkeypatch):
     """Links whose endpoints have (almost) disjoint supports: every exp(x_k) underflows without a
     shift (x_k < -745 for all k).  The row-per-wavefront kernel computes its softmax without the max
     shift and must fall back to the shifted form for such rows; the lane-per-link kernel always shifts.
-    Both must agree with the oracle's sequential log-sum-exp."""
+    Both must agree with the oracle's sequential log-sum-exp.
+    no_elogpi: the handle stores no Elogpi rows (option skip_elogpi, by itself only from 256 MB of state on) -- its fast phi launch
+    only raises DevCtrl::phi_redo and the launch behind it redoes the pass with the rows re-derived from gamma."""
     from svinet_amd.host_api import Setup
+    if no_elogpi:
+        monkeypatch.setenv("SVILS_SKIP_ELOGPI", "1")
     n = 2 * k + 20          # every community keeps some mass (an empty one makes E/sum[k] infinite in the reference too)
     ring = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
     chords = np.stack([np.arange(n), (np.arange(n) + 7) % n], 1)
@@ -166,6 +170,7 @@ def test_softmax_rows_that_underflow(k):
     x = ref.elogpi[0] + ref.elogpi[1] + ref.elogbeta[:, 0]
     assert x.max() < -745, "the test must exercise the underflow path"
     eng = s.engine(use_validation_stop=False)
+    assert eng.get_option("skip_elogpi") == (1 if no_elogpi else -1)
     eng.set_state(g, lam)
     for nsw in (1, 2):
         ref.sweep()

@@ -494,3 +494,27 @@ def test_small_device_keeps_the_four_launch_sweep(graph_files, monkeypatch, tmp_
     z = np.load(out)
     assert int(z["tails"]) == 40
     same(z["g"], z["lam"], z["conv"], z["member"], z["rows"])
+
+
+def test_handles_that_store_no_elogpi_run_the_same_sweeps(graph_files, monkeypatch):
+    """57 <= K <= 512 from 256 MB of state on (config 5): the finalise / expand passes store no Elogpi rows, gammanext
+    accumulates beside gamma and the phi pass is two launches (DeviceState::skip_elogpi).  Forced here on ca-AstroPh K = 200: the
+    same bits as the handle that stores them -- state, flags, tags, likelihood rows -- through the annealing switch, and
+    svils_get_aux(0) computes the rows on demand."""
+    from svinet_amd.host_api import Setup
+    setup = Setup(graph_files["astroph"], 17903, 200)
+    a = setup.engine(use_validation_stop=False)
+    monkeypatch.setenv("SVILS_SKIP_ELOGPI", "1")
+    b = setup.engine(use_validation_stop=False)
+    monkeypatch.delenv("SVILS_SKIP_ELOGPI")
+    assert (a.get_option("skip_elogpi"), b.get_option("skip_elogpi")) == (-1, 1)
+    for n in (3, 25):
+        a.sweep(n)
+        b.sweep(n)
+        ga, la, ca = a.state()
+        gb, lb, cb = b.state()
+        assert np.array_equal(ga, gb) and np.array_equal(la, lb) and np.array_equal(ca, cb)
+        assert np.array_equal(a.rows(), b.rows()) and np.array_equal(a.communities(), b.communities())
+        np.testing.assert_allclose(b.aux(0), a.aux(0), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(b.aux(2), a.aux(2), rtol=1e-12, atol=0)
+    assert not bool(a.control().annealing)

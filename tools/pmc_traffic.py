@@ -56,7 +56,7 @@ def main():
             b = (2 * f + w) * 1024
             lines.append("%-24s %-34s %14.0f %14.0f %18.0f %6d" % (wl, k[:34], f, w, b, n))
             per_kernel[k] = (b, n)
-            if k.startswith("k_phi"):
+            if k.startswith("k_phi") and (phi is None or b > phi):   # (handles that store no Elogpi launch a second, normally empty, phi kernel)
                 phi, nphi = b, n
         if phi is None:
             continue
