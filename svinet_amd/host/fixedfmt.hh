@@ -72,7 +72,7 @@ inline char *fmt_int(char *p, long v, char sep) {
 // The text of a block of rows: numbers are formatted into a scratch the writing thread owns (its cursor lives in a
 // register) and reach the block's string 60 KB at a time.  Appending every number to the std::string itself cost 7.6 ns per
 // number on one thread and 28 - 54 ns on 4 - 16: the strings of the threads sit next to each other in one vector and
-// every append stores its size field -- two threads per cache line (profiles/r05h_fmt_bench_before.txt).
+// every append stores its size field -- two threads per cache line (profiles/archive/r05h_fmt_bench_before.txt).
 class RowOut {
  public:
   explicit RowOut(std::string &o) : o_(o), p_(buf_) {}
