@@ -679,7 +679,9 @@ def main():
                          "concurrent 25 s host set-ups under a 16-core quota)")
     args = ap.parse_args()
     if args.extra_timeout <= 0:
-        args.extra_timeout = side_record_plan(args.extra_list)[1]
+        # scaled with the records requested, but never more than five minutes behind the main measurement by default: the one JSON line
+        # is owed to a driver whose own limit is unknown, and the records run in order of what they are worth (config 5 K-sharded first)
+        args.extra_timeout = min(side_record_plan(args.extra_list)[1], 300)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # bare `python bench.py --gpus N`: be the launcher (before anything touches HIP in this process)

@@ -95,7 +95,7 @@ for step in "$@"; do
            --kernel-trace --output-format csv -d $O/sq_$w -o p -- python $R/tools/kernel_times.py $wl 6 > $O/pmcsq_$w.log 2>&1)
         ARGS="$ARGS $wl $O/sq_$w"
       done
-      python tools/pmc_sq.py $O/sq_wave_cycles_pmc.txt $ARGS
+      python tools/pmc_sq.py $O/wave_cycles_sq_pmc.txt $ARGS
       rm -rf $O/sq_* ;;
     pmc-shard)   # roofline records of the kernels a SHARDED run executes: rank 0 of 8 of config 5 in both layouts, config 4 K-sharded
       ARGS=""
