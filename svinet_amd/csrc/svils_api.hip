@@ -426,6 +426,15 @@ int svils_set_graph(svils_handle *h, const uint32_t *links, uint64_t nlinks) {
     d.nb_a = cap(want, (want < 16ull * res ? 1u : 4u) * res);
   }
   d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + 4 * G - 1) / (4 * G), rpw_resident_blocks(g, 2, h->cfg.device));
+  if (d.ksh) {
+    // K-sharded handles: their finalise pass (k_fin1_ksh) is a small-register kernel of its own, sized here rather than by
+    // k_finalize's occupancy: eight blocks per CU.  (It stays the weakest kernel of a rank-sweep -- 650 us at n = 1e6 on a
+    // 64-column slice, 60 % of its wave cycles parked on memory, profiles/r07p_kshard_sq.txt; the grid is not why.)
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+    const uint32_t npb = g.V == 1 ? 16u : 4u;   // nodes per block: four per wavefront on slices of <= 64 columns
+    d.nb_b = cap(((uint64_t)(g.node_end - g.node_begin) + npb - 1) / npb, 8u * (uint32_t)(cus > 0 ? cus : 256));
+  }
   d.nb_c = cap((d.nitems_s3 + 3) / 4, 2 * rpw_resident_blocks(g, 1, h->cfg.device));
   // lane-per-link layout for small K: wave-items of 64 consecutive entries of a class list
   // The class lists pack an entry index into 27 bits: graphs of 2^26 training links or more take the
