@@ -405,7 +405,9 @@ struct ReduceJob {
 };
 __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, uint32_t nblk0,
                                                    const DevCtrl *ctrl) {
-  if (ctrl->stopped) return;
+  // the stop flag is requested beside the partial rows and looked at before the store (a test first was a round trip of
+  // its own in front of the rows': these launches are two round trips long)
+  const uint32_t stopped = ctrl->stopped;
   __shared__ double lds[64][5];
   const ReduceJob j = blockIdx.x < nblk0 ? j0 : j1;
   const uint32_t blk = blockIdx.x < nblk0 ? blockIdx.x : blockIdx.x - nblk0;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void k_colreduce(ReduceJob j0, ReduceJob j1, u
     if (seg < o) lds[seg][cl] += lds[seg + o][cl];
     __syncthreads();
   }
-  if (seg == 0 && c < j.ncols) j.out[c] = lds[0][cl];
+  if (seg == 0 && c < j.ncols && !stopped) j.out[c] = lds[0][cl];
 }
 
 // ======================================= node finalise (A7 + swap + A5 + A9)
@@ -986,23 +988,27 @@ __global__ __launch_bounds__(256) void k_s3(Geometry geo, DeviceState d, Params 
 // window's change), and the result is blended into the old lambda with the step size rho_lambda.
 // Returns the running s1, s2 through s1r/s2r (what k_tail stores back in mini-batch mode).
 template <bool STOCH>
-__device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Params &prm, uint32_t K, uint32_t k,
-                                                const double *s3v, double &l0, double &l1, double &s1r, double &s2r) {
-  double s1 = d.kvec_c[k], s2 = d.kvec_c[K + k], s3 = s3v[k];
+__device__ __forceinline__ void lambda_from(const DeviceState &d, const Params &prm, uint32_t K, uint32_t k, double sum,
+                                            double s1, double s2, double s3, double &l0, double &l1, double &s1r, double &s2r) {
   if constexpr (!STOCH) {
-    l0 = prm.eta0 + d.kvec_a[k];
+    l0 = prm.eta0 + sum;
     l1 = prm.eta1 + (s1 * s1 - s2 - s3);
   } else {
     s1 += d.s12run[k];
     s2 += d.s12run[K + k];
     s3 *= prm.scale_c;
-    const double h0 = prm.eta0 + d.kvec_a[k] * prm.scale_a;
+    const double h0 = prm.eta0 + sum * prm.scale_a;
     const double h1 = prm.eta1 + (s1 * s1 - s2 - s3);
     l0 = (1.0 - prm.rho_lambda) * d.lambda[2 * k] + prm.rho_lambda * h0;
     l1 = (1.0 - prm.rho_lambda) * d.lambda[2 * k + 1] + prm.rho_lambda * h1;
   }
   s1r = s1;
   s2r = s2;
+}
+template <bool STOCH>
+__device__ __forceinline__ void lambda_of_sweep(const DeviceState &d, const Params &prm, uint32_t K, uint32_t k,
+                                                const double *s3v, double &l0, double &l1, double &s1r, double &s2r) {
+  lambda_from<STOCH>(d, prm, K, k, d.kvec_a[k], d.kvec_c[k], d.kvec_c[K + k], s3v[k], l0, l1, s1r, s2r);
 }
 
 // ================================================== validation likelihood (A10)
@@ -1113,6 +1119,9 @@ __global__ __launch_bounds__(256) void k_carry_flags(Geometry geo, DeviceState d
 // blocks' partial sums in block order and runs the serial part: lambda update + set_dir_exp(lambda)
 // (:748-759), the likelihood row, stop rule and annealing switch (:994-1049), write_comm for the
 // next sweep (:768-774) and _iter++ (:787).
+#ifndef TAIL_BETAL   // K up to here: the rates of lambda go through LDS, once per block (0: every lane loads and divides its own)
+#define TAIL_BETAL 256
+#endif
 template <int W, int V, bool STOCH>
 __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Params prm) {
   if (blockIdx.x >= d.nb_t) {
@@ -1125,9 +1134,6 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     return;
   }
   STAMP(3, 0);
-  DevCtrl c = *d.ctrl;
-  if (c.stopped) return;
-  STAMP(3, 1);
   constexpr int G = 64 / W;
   constexpr int NPRE = V <= 4 ? 2 : 1;   // held-out pairs whose rows are fetched before lambda is known (a group has ~2 pairs at 2000 held-out links: V = 4, K = 129..256, took its second pair in a dependent round of its own until round 4)
   __shared__ double red[2][256];
@@ -1135,44 +1141,68 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   __shared__ double2 logtab[128];
   __shared__ double s3l[32];
   __shared__ double ftmp[8 * 32];
+#if TAIL_BETAL > 0
+  __shared__ double betal[TAIL_BETAL];
+#endif
   __shared__ uint32_t lastflag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / W, lw = lane % W;
   const uint32_t K = geo.K, ld = geo.ld;
-  const uint32_t iter = c.iter;
-  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
   // Every dependent global access of this launch costs a cold miss, so the independent chains are
   // started together, the one with a second level first: (1) the held-out pairs, whose gamma rows
   // (level 2) do not need lambda -- their products wait in registers; (2) the log table the last
-  // block will need; (3) the s3 pass's partial rows to fold.
+  // block will need; (3) the s3 pass's partial rows to fold.  What does not depend on the control
+  // block -- the pairs' indices, the log table, the reduced K-vectors of the serial part's first
+  // round of columns -- is requested BESIDE it, not behind it.
   const uint32_t i0 = (blockIdx.x * 4 + wave) * G + g, istride = d.nb_t * 4 * G;
+  // (a load under a per-lane condition is waited for where the branches join: two pairs, each with its rows behind it,
+  // were four round trips in a row.  Indices past the end are clamped instead and their results dropped at the sums.)
   uint32_t pp[NPRE], qq[NPRE], yy[NPRE];
 #pragma unroll
-  for (int t = 0; t < NPRE; ++t) {
-    const uint32_t i = i0 + t * istride;
-    pp[t] = 0; qq[t] = 0; yy[t] = 0;
-    if (do_val && i < d.nv) {
-      pp[t] = d.vpairs[3 * (size_t)i]; qq[t] = d.vpairs[3 * (size_t)i + 1]; yy[t] = d.vpairs[3 * (size_t)i + 2];
+  for (int t = 0; t < NPRE; ++t) { pp[t] = 0; qq[t] = 0; yy[t] = 0; }
+  if (d.nv) {
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {
+      const uint32_t i = i0 + t * istride, ic = i < d.nv ? i : d.nv - 1u;
+      pp[t] = d.vpairs[3 * (size_t)ic]; qq[t] = d.vpairs[3 * (size_t)ic + 1]; yy[t] = d.vpairs[3 * (size_t)ic + 2];
     }
   }
   double2 ltv = make_double2(0.0, 0.0);
   if (threadIdx.x < 128) ltv = make_double2(d.logtab[2 * threadIdx.x], d.logtab[2 * threadIdx.x + 1]);
+  double pre_sum = 0.0, pre_s1 = 0.0, pre_s2 = 0.0, pre_s3 = 0.0;
+  if (threadIdx.x < K) {
+    pre_sum = d.kvec_a[threadIdx.x]; pre_s1 = d.kvec_c[threadIdx.x]; pre_s2 = d.kvec_c[K + threadIdx.x];
+    if (!d.fold) pre_s3 = d.kvec_c[2 * (size_t)K + threadIdx.x];
+  }
+  DevCtrl c = *d.ctrl;
+  if (c.stopped) return;
+  STAMP(3, 1);
+  const uint32_t iter = c.iter;
+  const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
+  // A sweep without a likelihood row (nine of ten at the default report frequency) leaves the other blocks nothing to
+  // do: block 0 runs the serial part alone -- no partial sums, no ticket (nb_t arrivals at one address in a row).
+  if (!do_val && blockIdx.x != 0u) return;
   FoldRows<32, 256> fold;
   if (d.fold) fold.issue(d.part_c, d.nb_c, K);
   double prod[NPRE][V], spq[NPRE];
 #pragma unroll
   for (int t = 0; t < NPRE; ++t) {
-    const uint32_t i = i0 + t * istride;
     spq[t] = 1.0;
 #pragma unroll
     for (int v = 0; v < V; ++v) prod[t][v] = 0.0;
-    if (do_val && i < d.nv) {
-      double gp[V], gq[V];
-      load_row<W, V>(d.gamma + (size_t)pp[t] * ld, lw, ld, gp);
-      load_row<W, V>(d.gamma + (size_t)qq[t] * ld, lw, ld, gq);
+  }
+  if (do_val) {
+    double gp[NPRE][V], gq[NPRE][V];
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {   // every row of every pair in flight before anything is waited for
+      load_row<W, V>(d.gamma + (size_t)pp[t] * ld, lw, ld, gp[t]);
+      load_row<W, V>(d.gamma + (size_t)qq[t] * ld, lw, ld, gq[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {
       double sp = 0.0, sq = 0.0;
 #pragma unroll
-      for (int v = 0; v < V; ++v) { sp += gp[v]; sq += gq[v]; prod[t][v] = gp[v] * gq[v]; }
+      for (int v = 0; v < V; ++v) { sp += gp[t][v]; sq += gq[t][v]; prod[t][v] = gp[t][v] * gq[t][v]; }
       spq[t] = group_sum<W>(sp) * group_sum<W>(sq);
     }
   }
@@ -1188,14 +1218,33 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   unsigned long long kz = 0;
   if (do_val) {
     double beta[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int k = kmap<W, V>(lw, v);
-      beta[v] = 0.0;
-      if ((uint32_t)k < K) {
+#if TAIL_BETAL > 0
+    // the rates of this sweep's lambda, once per block into LDS from the K-vectors requested at the top
+    if (K <= (uint32_t)TAIL_BETAL) {
+      for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
         double l0, l1, s1r, s2r;
-        lambda_of_sweep<STOCH>(d, prm, K, (uint32_t)k, s3v, l0, l1, s1r, s2r);
-        beta[v] = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
+        if (k == threadIdx.x) lambda_from<STOCH>(d, prm, K, k, pre_sum, pre_s1, pre_s2, d.fold ? s3v[k] : pre_s3, l0, l1, s1r, s2r);
+        else lambda_of_sweep<STOCH>(d, prm, K, k, s3v, l0, l1, s1r, s2r);
+        betal[k] = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
+      }
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int k = kmap<W, V>(lw, v);
+        beta[v] = (uint32_t)k < K ? betal[k] : 0.0;
+      }
+    } else
+#endif
+    {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int k = kmap<W, V>(lw, v);
+        beta[v] = 0.0;
+        if ((uint32_t)k < K) {
+          double l0, l1, s1r, s2r;
+          lambda_of_sweep<STOCH>(d, prm, K, (uint32_t)k, s3v, l0, l1, s1r, s2r);
+          beta[v] = l0 / (l0 + l1);  // estimate_bernoulli_rate, src/linksampling.hh:216-225
+        }
       }
     }
 #pragma unroll
@@ -1219,9 +1268,8 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
       uint32_t bp[NB], bq[NB], by[NB];
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
-        const uint32_t i = ib + t * istride;
-        bp[t] = 0; bq[t] = 0; by[t] = 0;
-        if (i < d.nv) { bp[t] = d.vpairs[3 * (size_t)i]; bq[t] = d.vpairs[3 * (size_t)i + 1]; by[t] = d.vpairs[3 * (size_t)i + 2]; }
+        const uint32_t i = ib + t * istride, ic = i < d.nv ? i : d.nv - 1u;   // clamped, not branched: see the top
+        bp[t] = d.vpairs[3 * (size_t)ic]; bq[t] = d.vpairs[3 * (size_t)ic + 1]; by[t] = d.vpairs[3 * (size_t)ic + 2];
       }
       double gp[NB][V], gq[NB][V];
 #pragma unroll
@@ -1246,49 +1294,76 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     }
   }
   STAMP(3, 3);
-  // block partial in thread order (fixed tree), published for the last block
-  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = kz;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + o];
-      red[1][threadIdx.x] += red[1][threadIdx.x + o];
-      cred[0][threadIdx.x] += cred[0][threadIdx.x + o];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    st_agent(d.tail_part + (size_t)blockIdx.x * 4, red[0][0]);
-    st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 1, red[1][0]);
-    st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 2, (double)cred[0][0]);
-  }
-  STAMP(3, 4);
-  if (!last_block_arrives(d.tail_ctl, d.nb_t, &lastflag)) return;
-  STAMP(3, 5);
-
-  // ---- last block only ----
-  // the blocks' partial sums: thread t adds blocks t, t + 256, ..., then a fixed-order tree
-  sz = 0.0; so = 0.0;
   double kzd = 0.0;
-  unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  for (uint32_t b = threadIdx.x; b < d.nb_t; b += 256u) {   // (one round up to 256 blocks)
-    sz += ld_agent(d.tail_part + (size_t)b * 4);
-    so += ld_agent(d.tail_part + (size_t)b * 4 + 1);
-    kzd += ld_agent(d.tail_part + (size_t)b * 4 + 2);
+  if (do_val) {
+    // block partial in thread order (fixed tree), published for the last block
+    red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = kz;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        red[0][threadIdx.x] += red[0][threadIdx.x + o];
+        red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        cred[0][threadIdx.x] += cred[0][threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      st_agent(d.tail_part + (size_t)blockIdx.x * 4, red[0][0]);
+      st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 1, red[1][0]);
+      st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 2, (double)cred[0][0]);
+    }
+    STAMP(3, 4);
+    if (!last_block_arrives(d.tail_ctl, d.nb_t, &lastflag)) return;
+    STAMP(3, 5);
+    sz = 0.0; so = 0.0;
+  } else {
+    __syncthreads();   // block 0 alone: the log table is in LDS for every wave
   }
-  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = (unsigned long long)kzd;
+  // ---- the last block (a sweep with a likelihood row) or block 0 (a sweep without) ----
+  // the blocks' partial sums: thread t adds blocks t, t + 256, ..., then a fixed-order tree.  The first round is only
+  // REQUESTED here (clamped index, dropped below): the link counts that follow travel beside it, not behind it.
+  double pz = 0.0, po = 0.0, pk = 0.0;
+  if (do_val) {
+    const uint32_t bc = threadIdx.x < d.nb_t ? threadIdx.x : 0u;
+    pz = ld_agent(d.tail_part + (size_t)bc * 4);
+    po = ld_agent(d.tail_part + (size_t)bc * 4 + 1);
+    pk = ld_agent(d.tail_part + (size_t)bc * 4 + 2);
+  }
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
   const uint32_t cpar0 = c.cls_par;
   uint32_t *ltot = d.lpl ? d.ltot + cpar0 * 8u : nullptr;
-  if (!d.lpl)
-    for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {   // link statistics of the phi pass
-      t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+  if (!d.lpl) {
+    // link statistics of the phi pass: eight blocks' counts per thread requested at once (one block per round was a cold
+    // miss per round on the serial part's critical path: five in a row at 1 280 phi blocks; integers, so any order)
+    for (uint32_t b0 = threadIdx.x; b0 < d.nb_a; b0 += 8u * blockDim.x) {
+      unsigned long long w[8][3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t b = b0 + (uint32_t)j * blockDim.x, bc = b < d.nb_a ? b : b0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w[j][e] = d.part_links[(size_t)bc * 3 + e];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (b0 + (uint32_t)j * blockDim.x < d.nb_a) { t0 += w[j][0]; t1 += w[j][1]; t2 += w[j][2]; }
     }
+  }
+  if (do_val) {
+    if (threadIdx.x < d.nb_t) { sz += pz; so += po; kzd += pk; }
+    for (uint32_t b = threadIdx.x + 256u; b < d.nb_t; b += 256u) {   // (one round up to 256 blocks)
+      sz += ld_agent(d.tail_part + (size_t)b * 4);
+      so += ld_agent(d.tail_part + (size_t)b * 4 + 1);
+      kzd += ld_agent(d.tail_part + (size_t)b * 4 + 2);
+    }
+  }
+  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = (unsigned long long)kzd;
   cred[1][threadIdx.x] = t0; cred[2][threadIdx.x] = t1; cred[3][threadIdx.x] = t2;
   __syncthreads();
   // lambda update + set_dir_exp(lambda), src/linksampling.cc:748-759
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
     double l0, l1, s1r, s2r;
-    lambda_of_sweep<STOCH>(d, prm, K, k, s3v, l0, l1, s1r, s2r);
+    if (k == threadIdx.x) lambda_from<STOCH>(d, prm, K, k, pre_sum, pre_s1, pre_s2, d.fold ? s3v[k] : pre_s3, l0, l1, s1r, s2r);
+    else lambda_of_sweep<STOCH>(d, prm, K, k, s3v, l0, l1, s1r, s2r);
     d.lambda[2 * k] = l0;
     d.lambda[2 * k + 1] = l1;
     if constexpr (STOCH) { d.s12run[k] = s1r; d.s12run[K + k] = s2r; }
