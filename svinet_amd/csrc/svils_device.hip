@@ -1119,6 +1119,37 @@ __global__ __launch_bounds__(256) void k_carry_flags(Geometry geo, DeviceState d
 // blocks' partial sums in block order and runs the serial part: lambda update + set_dir_exp(lambda)
 // (:748-759), the likelihood row, stop rule and annealing switch (:994-1049), write_comm for the
 // next sweep (:768-774) and _iter++ (:787).
+// The control block as the tail of a sweep leaves it: the fields a tail changes (bytes 0 .. 79), one by one.  A whole-struct
+// `*d.ctrl = c` keeps the 16 bytes a tail never touches in a private 16-byte object per lane; the compiler then either spills
+// that to scratch, or -- when the block's LDS is small enough -- promotes it to LDS and indexes it by the work-group
+// size, which it READS FROM THE DISPATCH PACKET: host memory, once per wavefront.  246 blocks of four waves doing that in
+// a row made the launch 20 us longer (15.5 -> 36 us, profiles/r07v_ab_tail_dispatch_packet_read.txt).
+__device__ __forceinline__ void store_ctrl_of_tail(DevCtrl *dst, const DevCtrl &c) {
+  dst->iter = c.iter; dst->annealing = c.annealing; dst->write_comm = c.write_comm; dst->nh = c.nh;
+  dst->prev_h = c.prev_h; dst->max_h = c.max_h;
+  dst->stopped = c.stopped; dst->why = c.why; dst->sweeps_done = c.sweeps_done; dst->rows = c.rows;
+  dst->links_dense = c.links_dense; dst->links_sparse = c.links_sparse; dst->links_shortcut = c.links_shortcut;
+  dst->parity = c.parity; dst->cls_par = c.cls_par;
+}
+
+// Sums of N per-thread values over a 256-thread block, every thread ends with the totals: DPP inside the wavefronts,
+// the four wave totals through LDS, added in wave order -- a fixed order, and 0.3 us where a shared-memory tree of eight
+// barrier levels over six arrays took 1.2 (profiles/r07t_tail_timeline_astroph_k200_first.txt).  Ends with no barrier: a
+// second call on the same `wl` needs one in between (k_tail has the ticket's).
+template <int N>
+__device__ __forceinline__ void block_sums(double (&x)[N], double (*wl)[6]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < N; ++j) x[j] = group_sum<64>(x[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) wl[wave][j] = x[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j) x[j] = ((wl[0][j] + wl[1][j]) + wl[2][j]) + wl[3][j];
+}
+
 #ifndef TAIL_BETAL   // K up to here: the rates of lambda go through LDS, once per block (0: every lane loads and divides its own)
 #define TAIL_BETAL 256
 #endif
@@ -1136,8 +1167,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   STAMP(3, 0);
   constexpr int G = 64 / W;
   constexpr int NPRE = V <= 4 ? 2 : 1;   // held-out pairs whose rows are fetched before lambda is known (a group has ~2 pairs at 2000 held-out links: V = 4, K = 129..256, took its second pair in a dependent round of its own until round 4)
-  __shared__ double red[2][256];
-  __shared__ unsigned long long cred[4][256];
+  __shared__ double wsum[4][6];
   __shared__ double2 logtab[128];
   __shared__ double s3l[32];
   __shared__ double ftmp[8 * 32];
@@ -1296,21 +1326,14 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
   STAMP(3, 3);
   double kzd = 0.0;
   if (do_val) {
-    // block partial in thread order (fixed tree), published for the last block
-    red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = kz;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) {
-        red[0][threadIdx.x] += red[0][threadIdx.x + o];
-        red[1][threadIdx.x] += red[1][threadIdx.x + o];
-        cred[0][threadIdx.x] += cred[0][threadIdx.x + o];
-      }
-      __syncthreads();
-    }
+    // the block's partial sums (fixed order; the count is an integer far below 2^53: exact as a double), published for
+    // the last block
+    double bp3[3] = {sz, so, (double)kz};
+    block_sums<3>(bp3, wsum);
     if (threadIdx.x == 0) {
-      st_agent(d.tail_part + (size_t)blockIdx.x * 4, red[0][0]);
-      st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 1, red[1][0]);
-      st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 2, (double)cred[0][0]);
+      st_agent(d.tail_part + (size_t)blockIdx.x * 4, bp3[0]);
+      st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 1, bp3[1]);
+      st_agent(d.tail_part + (size_t)blockIdx.x * 4 + 2, bp3[2]);
     }
     STAMP(3, 4);
     if (!last_block_arrives(d.tail_ctl, d.nb_t, &lastflag)) return;
@@ -1356,9 +1379,9 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
       kzd += ld_agent(d.tail_part + (size_t)b * 4 + 2);
     }
   }
-  red[0][threadIdx.x] = sz; red[1][threadIdx.x] = so; cred[0][threadIdx.x] = (unsigned long long)kzd;
-  cred[1][threadIdx.x] = t0; cred[2][threadIdx.x] = t1; cred[3][threadIdx.x] = t2;
-  __syncthreads();
+  // (link counts: integers below 2^53, exact as doubles)
+  double tot[6] = {sz, so, kzd, (double)t0, (double)t1, (double)t2};
+  block_sums<6>(tot, wsum);
   // lambda update + set_dir_exp(lambda), src/linksampling.cc:748-759
   for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
     double l0, l1, s1r, s2r;
@@ -1371,20 +1394,11 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     d.elogbeta[2 * k] = digamma(l0, logtab) - ps;
     d.elogbeta[2 * k + 1] = digamma(l1, logtab) - ps;
   }
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + o];
-      red[1][threadIdx.x] += red[1][threadIdx.x + o];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) cred[cc][threadIdx.x] += cred[cc][threadIdx.x + o];
-    }
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    sz = red[0][0]; so = red[1][0]; kzd = (double)cred[0][0];
+    sz = tot[0]; so = tot[1]; kzd = tot[2];
     c.parity ^= 1u;  // prune()'s flags become current
     if (d.lpl) { c.links_dense = ltot[3]; c.links_sparse = ltot[4]; c.links_shortcut = ltot[5]; }
-    else { c.links_dense = cred[1][0]; c.links_sparse = cred[2][0]; c.links_shortcut = cred[3][0]; }
+    else { c.links_dense = (unsigned long long)tot[3]; c.links_sparse = (unsigned long long)tot[4]; c.links_shortcut = (unsigned long long)tot[5]; }
     if (d.sweep_stats) {
       unsigned long long *st = d.sweep_stats + (size_t)(c.sweeps_done % d.sweep_stats_cap) * 4;
       st[0] = c.links_dense; st[1] = c.links_sparse; st[2] = c.links_shortcut; st[3] = c.sweeps_done;
@@ -1426,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_tail(Geometry geo, DeviceState d, Param
     // the classes the count / scatter passes computed for the next sweep become current -- unless they did not run
     // because no flag changed (cls_args[5], the count pass's verdict): then the current ones stay
     if (!(d.lpl && d.cls_next && d.cls_args[5] == 0u)) c.cls_par ^= 1u;
-    *d.ctrl = c;
+    store_ctrl_of_tail(d.ctrl, c);
   }
   STAMP(3, 6);
   // the link counts / shortcut histogram of the finished sweep are consumed: clear them for the

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
   }
   if (exit_now) c.stopped = 1;
   else c.iter = iter + 1;
-  *d.ctrl = c;
+  store_ctrl_of_tail(d.ctrl, c);   // field by field (svils_device.hip): a whole-struct copy made this kernel read the dispatch packet
 }
 
 // ------------------------------------------------------------------ launchers
