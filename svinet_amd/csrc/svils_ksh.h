@@ -447,7 +447,24 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
 #pragma unroll
   for (int v = 0; v < V; ++v) { s12[0][v] = 0.0; s12[1][v] = 0.0; }
   // full sweeps: every node; mini-batch steps: the window [node_begin, node_end)
-  for (uint32_t p0 = geo.node_begin + (blockIdx.x * 4 + wave) * G; p0 < geo.node_end; p0 += gridDim.x * 4 * G) {
+  // Everything a node's turn reads sits at an address the node number alone decides -- the two row pointers, the split marker,
+  // the accumulator row (taken whether or not the node was split: a split node's row is ignored), the row sum the ranks
+  // share -- so it is requested in one go, and the NEXT turn's before this turn's arithmetic: the loop was three dependent
+  // round trips per node (pointers + marker, then the row behind the branch on the marker, then the row sum behind the
+  // stores it might alias), with 60 % of the launch's wave cycles parked on memory (profiles/r07p_kshard_sq.txt).
+  struct Turn { uint64_t r0, r1; int32_t sf; double acc[V]; double rsum; };
+  const uint32_t stride = gridDim.x * 4 * G;
+  auto request = [&](uint32_t q0, Turn &t) {
+    const uint32_t q = (q0 + (uint32_t)g < geo.node_end) ? q0 + (uint32_t)g : (q0 < geo.node_end ? q0 : geo.node_begin);
+    t.r0 = d.rowptr[q]; t.r1 = d.rowptr[q + 1];
+    t.sf = d.split_first[q];
+    load_row<W, V>(d.gacc + (size_t)q * ld, lw, ld, t.acc);
+    t.rsum = fuse ? d.rowx[3 * (size_t)q] : 1.0;
+  };
+  Turn nxt;
+  const uint32_t pfirst = geo.node_begin + (blockIdx.x * 4 + wave) * G;
+  if (!init && pfirst < geo.node_end) request(pfirst, nxt);
+  for (uint32_t p0 = pfirst; p0 < geo.node_end; p0 += stride) {
     const bool ok = p0 + (uint32_t)g < geo.node_end;       // (G > 1: the last wavefront's rows past the end idle on p0's node)
     const uint32_t p = ok ? p0 + (uint32_t)g : p0;
     double gn[V];
@@ -456,11 +473,14 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
 #pragma unroll
       for (int v = 0; v < V; ++v) if (!kval[v]) gn[v] = 0.0;
     } else {
-      const double tl = 2.0 * (double)(d.rowptr[p + 1] - d.rowptr[p]);  // quirk Q3
+      const Turn cur = nxt;
+      if (p0 + stride < geo.node_end) request(p0 + stride, nxt);
+      const double tl = 2.0 * (double)(cur.r1 - cur.r0);  // quirk Q3
       double acc[V];
-      const int32_t sf = d.split_first[p];
+      const int32_t sf = cur.sf;
       if (sf < 0) {
-        load_row<W, V>(d.gacc + (size_t)p * ld, lw, ld, acc);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = cur.acc[v];
       } else {
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = 0.0;
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
       }
       if (ok) store_row<W, V>(d.gamma + (size_t)p * ld, lw, ld, gn);
       if (fuse) {
-        const double psi_prev = digamma(d.rowx[3 * (size_t)p], logtab);
+        const double psi_prev = digamma(cur.rsum, logtab);
         double ep[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) ep[v] = kval[v] ? exp_neg(digamma(gn[v], logtab) - psi_prev) : 0.0;
@@ -883,9 +903,26 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
   __shared__ unsigned long long cred[3][256];
   const uint32_t iter = c.iter;
   const bool do_val = d.nv > 0 && (iter % prm.reportfreq == 0);
+  // the k_vsum_ksh blocks' partial sums (nvb <= 256): one per thread into LDS, requested beside the link counts -- thread 0
+  // adding them straight from memory in block order was a cold miss per block, 32 us at 118 blocks
+  __shared__ double pv[3][256];
+  {
+    const uint32_t bc = threadIdx.x < nvb ? threadIdx.x : 0u;
+    const double v0 = d.tail_part[(size_t)bc * 4], v1 = d.tail_part[(size_t)bc * 4 + 1], v2 = d.tail_part[(size_t)bc * 4 + 2];
+    pv[0][threadIdx.x] = v0; pv[1][threadIdx.x] = v1; pv[2][threadIdx.x] = v2;
+  }
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  for (uint32_t b = threadIdx.x; b < d.nb_a; b += blockDim.x) {
-    t0 += d.part_links[(size_t)b * 3]; t1 += d.part_links[(size_t)b * 3 + 1]; t2 += d.part_links[(size_t)b * 3 + 2];
+  for (uint32_t b0 = threadIdx.x; b0 < d.nb_a; b0 += 8u * blockDim.x) {   // eight blocks' counts per thread in flight (integers: any order)
+    unsigned long long w[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t b = b0 + (uint32_t)j * blockDim.x, bc = b < d.nb_a ? b : b0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) w[j][e] = d.part_links[(size_t)bc * 3 + e];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (b0 + (uint32_t)j * blockDim.x < d.nb_a) { t0 += w[j][0]; t1 += w[j][1]; t2 += w[j][2]; }
   }
   cred[0][threadIdx.x] = t0; cred[1][threadIdx.x] = t1; cred[2][threadIdx.x] = t2;
   __syncthreads();
@@ -897,7 +934,7 @@ __global__ __launch_bounds__(256) void k_stop_ksh(Geometry geo, DeviceState d, P
   if (threadIdx.x != 0) return;
   double szeros = 0.0, sones = 0.0, kzd = 0.0;
   for (uint32_t b = 0; b < nvb; ++b) {   // block order
-    szeros += d.tail_part[(size_t)b * 4]; sones += d.tail_part[(size_t)b * 4 + 1]; kzd += d.tail_part[(size_t)b * 4 + 2];
+    szeros += pv[0][b]; sones += pv[1][b]; kzd += pv[2][b];
   }
   c.parity ^= 1u;
   c.links_dense = cred[0][0]; c.links_sparse = cred[1][0]; c.links_shortcut = cred[2][0];
