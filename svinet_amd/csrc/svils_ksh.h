@@ -420,6 +420,9 @@ __global__ __launch_bounds__(256) void k_phi_ksh16(Geometry geo, DeviceState d, 
 // shifted by psi of the row sum every rank already holds (rowx[3p] still carries the SUMMED row sum of the previous state here;
 // any per-row constant cancels in a link's softmax, and this one is the same on every rank) -- and the row's active-set
 // candidate bits; what needs the summed rowx of THIS state (the flags) follows in k_flags_ksh, O(n).
+#ifndef KSH_FIN_PREFETCH   // 1: (four-node wavefronts) the next turn's loads are requested before this turn's arithmetic
+#define KSH_FIN_PREFETCH 1
+#endif
 template <int W, int V, bool STOCH>
 __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, Params prm, int init, int fuse) {
   constexpr int G = 64 / W;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
   // full sweeps: every node; mini-batch steps: the window [node_begin, node_end)
   // Everything a node's turn reads sits at an address the node number alone decides -- the two row pointers, the split marker,
   // the accumulator row (taken whether or not the node was split: a split node's row is ignored), the row sum the ranks
-  // share -- so it is requested in one go, and the NEXT turn's before this turn's arithmetic: the loop was three dependent
+  // share -- so it is requested in one go, and (PREF) the NEXT turn's before this turn's arithmetic: the loop was three dependent
   // round trips per node (pointers + marker, then the row behind the branch on the marker, then the row sum behind the
   // stores it might alias), with 60 % of the launch's wave cycles parked on memory (profiles/r07p_kshard_sq.txt).
   struct Turn { uint64_t r0, r1; int32_t sf; double acc[V]; double rsum; };
@@ -461,9 +464,12 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
     load_row<W, V>(d.gacc + (size_t)q * ld, lw, ld, t.acc);
     t.rsum = fuse ? d.rowx[3 * (size_t)q] : 1.0;
   };
-  Turn nxt;
+  // (the run-ahead pays where a turn is short -- four 512-byte rows per wavefront: 597 -> 551 us at 64 columns per rank --, not where
+  //  a wavefront owns one wide row: 1 033 -> 1 050 us at 128 columns, 1 837 -> 1 850 at 256; profiles/r07zc_ab_fin1_ksh_by_world.txt)
+  constexpr bool PREF = KSH_FIN_PREFETCH && W == 16;
   const uint32_t pfirst = geo.node_begin + (blockIdx.x * 4 + wave) * G;
-  if (!init && pfirst < geo.node_end) request(pfirst, nxt);
+  Turn nxt;
+  if constexpr (PREF) { if (!init && pfirst < geo.node_end) request(pfirst, nxt); }
   for (uint32_t p0 = pfirst; p0 < geo.node_end; p0 += stride) {
     const bool ok = p0 + (uint32_t)g < geo.node_end;       // (G > 1: the last wavefront's rows past the end idle on p0's node)
     const uint32_t p = ok ? p0 + (uint32_t)g : p0;
@@ -473,8 +479,9 @@ __global__ __launch_bounds__(256) void k_fin1_ksh(Geometry geo, DeviceState d, P
 #pragma unroll
       for (int v = 0; v < V; ++v) if (!kval[v]) gn[v] = 0.0;
     } else {
-      const Turn cur = nxt;
-      if (p0 + stride < geo.node_end) request(p0 + stride, nxt);
+      Turn cur;
+      if constexpr (PREF) { cur = nxt; if (p0 + stride < geo.node_end) request(p0 + stride, nxt); }
+      else request(p0, cur);
       const double tl = 2.0 * (double)(cur.r1 - cur.r0);  // quirk Q3
       double acc[V];
       const int32_t sf = cur.sf;
