@@ -113,6 +113,36 @@ def test_reportfreq(graph_files, rfreq):
     np.testing.assert_allclose(rows[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
 
 
+@pytest.mark.parametrize("graph,n,k,rfreq,options", [
+    ("assort", 75, 60, 2, None),             # row-per-wavefront kernels (K > 56): k_tail
+    ("lfr", 1000, 64, 3, None),
+    ("assort", 75, 4, 2, {"fused3": "0"}),   # small K as four launches per sweep: k_tail with the folded s3
+    ("lfr", 1000, 28, 5, {"fused3": "0"}),
+])
+def test_reportfreq_where_the_tail_is_a_launch_of_its_own(graph_files, graph, n, k, rfreq, options):
+    """-rfreq > 1 on the sweeps that end in k_tail: a sweep without a likelihood row runs the serial part (lambda,
+    Elogbeta, link statistics, _iter++) on block 0 alone, a sweep with one on the last block behind the ticket --
+    the run to its stop, every likelihood row and the final state against the oracle (src/linksampling.cc:768-787)"""
+    from svinet_amd.host_api import Setup
+    s = Setup(graph_files[graph], n, k)
+    ref = O.LinkSampling(O.Network(graph_files[graph], n), k, reportfreq=rfreq)
+    eng = s.engine(reportfreq=rfreq, options=options)
+    m = 0
+    while ref.sweep() != 2:
+        m += 1
+        assert m < 3000
+    eng.sweep(m + 1 + 4)
+    c = eng.control()
+    assert c.stopped == 1 and c.iter == ref.iter and c.sweeps_done == m + 1
+    g, lam, conv = eng.state()
+    assert np.max(np.abs(g - ref.gamma) / ref.gamma) < 1e-7
+    assert np.max(np.abs(lam - ref.lam) / np.abs(ref.lam)) < 1e-7
+    assert np.array_equal(eng.communities(), ref.communities())
+    rows = eng.rows()
+    assert np.array_equal(rows[:, 0], ref.rows[1:, 0]) and np.all(rows[:, 0] % rfreq == 0)
+    np.testing.assert_allclose(rows[:, 1:], ref.rows[1:, 1:], rtol=1e-7, atol=1e-12)
+
+
 def test_empty_and_tiny_graphs():
     """degenerate inputs through the C ABI: no training link at all, and an 8-node ring"""
     from svinet_amd._svils import Engine
